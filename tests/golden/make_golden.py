@@ -1,0 +1,357 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own glue code.
+
+Runs ONLY in the build container (needs /root/reference, which is absent on the GPU box).
+Recipe = SURVEY.md Appendix A: pre-seed sys.modules with stubs for the third-party packages the
+reference imports but that are not installed (pytorch_lightning, fairseq, clip, s3prl, librosa,
+torchvision), plug the oracle's restatements of the fairseq / openai backbones in *through those
+stubs*, then import `avssl.*` from /root/reference and execute it.  Outputs are small .npz files:
+inputs, (tiny) weights and the reference's outputs.  Every fixture is also recomputed with the
+standalone oracle (oracle/speechclip_ref.py) and must agree, which pins the oracle.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+# transformers first (Appendix A step 1), before the librosa stub exists
+import transformers  # noqa: F401,E402
+
+from oracle import clip_ref, hubert_ref, speechclip_ref  # noqa: E402
+
+STATE = {"hubert_cfg": None, "clip_cfg": None}
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    class LightningModule(nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+        def log_dict(self, *a, **k):
+            pass
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+        logger = None
+        global_step = 0
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+    pl = _mod("pytorch_lightning", LightningModule=LightningModule, Trainer=_Dummy, seed_everything=lambda s: torch.manual_seed(s))
+    _mod("pytorch_lightning.callbacks", ModelCheckpoint=_Dummy, TQDMProgressBar=_Dummy, Callback=_Dummy)
+    _mod("pytorch_lightning.loggers", TensorBoardLogger=_Dummy, WandbLogger=_Dummy, LightningLoggerBase=_Dummy)
+    _mod("pytorch_lightning.loggers.wandb", WandbLogger=_Dummy)
+    pl.loggers = sys.modules["pytorch_lightning.loggers"]
+
+    class SimpleTokenizer:
+        def __init__(self):
+            self.encoder = {"<|startoftext|>": 49406, "<|endoftext|>": 49407}
+
+    def clip_load(name, device="cpu"):
+        torch.manual_seed(1234)
+        return clip_ref.ClipRef(STATE["clip_cfg"]).eval().float(), (lambda img: img)
+
+    _mod("clip", load=clip_load, tokenize=lambda *a, **k: None)
+    _mod("clip.simple_tokenizer", SimpleTokenizer=SimpleTokenizer)
+
+    def load_model_ensemble_and_task(paths):
+        torch.manual_seed(4321)
+        cfg = STATE["hubert_cfg"]
+        model = hubert_ref.HubertModelRef(cfg)
+        hubert_ref.randomize_norm_affine(model, torch.Generator().manual_seed(99))
+        task = types.SimpleNamespace(cfg=types.SimpleNamespace(normalize=cfg.normalize))
+        return [model], cfg, task
+
+    fs = _mod("fairseq")
+    fs.checkpoint_utils = _mod("fairseq.checkpoint_utils", load_model_ensemble_and_task=load_model_ensemble_and_task)
+    _mod("fairseq.models")
+    _mod("fairseq.models.hubert")
+    _mod("fairseq.models.hubert.hubert", HubertConfig=hubert_ref.HubertRefConfig, HubertModel=hubert_ref.HubertModelRef)
+    _mod("fairseq.models.wav2vec")
+    _mod("fairseq.models.wav2vec.wav2vec2", TransformerEncoder=hubert_ref.TransformerEncoderRef)
+
+    def index_put(t, idx, v):
+        t[idx] = v
+        return t
+
+    _mod("fairseq.utils", index_put=index_put)
+    s3 = _mod("s3prl")
+    s3.hub = _mod("s3prl.hub")
+    _mod("s3prl.utility")
+    _mod("s3prl.utility.download", _urls_to_filepaths=lambda url, refresh=False: "/nonexistent.pt")
+    _mod("librosa")
+    tv = _mod("torchvision")
+    tv.transforms = _mod("torchvision.transforms", Compose=_Dummy, Resize=_Dummy, ToTensor=_Dummy)
+    _mod("tqdm", tqdm=lambda x, *a, **k: x)
+    import transformers.file_utils as fu
+    if not hasattr(fu, "copy_func"):
+        fu.copy_func = lambda f: f
+    _mod("PIL", Image=types.SimpleNamespace())
+    sys.modules["PIL.Image"] = sys.modules["PIL"].Image
+    sys.path.insert(0, REF)
+
+
+def np_state(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items() if v.dtype != torch.bool}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_loss(losses_mod):
+    out = {}
+    # known-answer anchors recorded in BASELINE.md section 3
+    torch.manual_seed(0)
+    a = torch.nn.functional.normalize(torch.randn(16, 512), dim=-1)
+    b = torch.nn.functional.normalize(torch.randn(16, 512), dim=-1)
+    crit = losses_mod.MaskedContrastiveLoss()
+    ids_u = torch.arange(16)
+    ids_d = torch.tensor([0, 0, 0, 1, 1] + list(range(2, 13)))
+    l_u, l_d = crit(a, b, ids_u).item(), crit(a, b, ids_d).item()
+    print("anchors:", l_u, l_d)
+    assert abs(l_u - 2.978872299194336) < 1e-6 and abs(l_d - 2.9537737369537354) < 1e-6
+    out.update(anchor_a=a.numpy(), anchor_b=b.numpy(), anchor_ids_u=ids_u.numpy(), anchor_ids_d=ids_d.numpy(),
+               anchor_loss_u=np.float64(l_u), anchor_loss_d=np.float64(l_d))
+    # option sweep at B in {2, 16, 256}; B = 2048 with MAX_EYE patched before construction (Appendix A step 5)
+    cases = []
+    g = torch.Generator().manual_seed(5)
+    for B, E in ((2, 8), (16, 64), (256, 512), (2048, 64)):
+        losses_mod.MAX_EYE = max(256, B)
+        fa = torch.nn.functional.normalize(torch.randn(B, E, generator=g), dim=-1)
+        fb = torch.nn.functional.normalize(fa + 0.7 * torch.randn(B, E, generator=g), dim=-1)
+        ids = torch.randint(0, max(2, B // 3), (B,), generator=g)
+        for kw in (dict(), dict(margin=0.2), dict(dcl=True), dict(a2b=False), dict(b2a=False),
+                   dict(temperature=0.05, temperature_trainable=True), dict(use_ids=False)):
+            kw = dict(kw)
+            use_ids = kw.pop("use_ids", True)
+            c = losses_mod.MaskedContrastiveLoss(**kw)
+            with torch.no_grad():
+                val = c(fa.clone(), fb.clone(), ids if use_ids else None).item()
+            inv_t = c.temperature.exp().item() if kw.get("temperature_trainable") else c.temperature
+            mine = speechclip_ref.masked_contrastive_loss(fa, fb, ids if use_ids else None, inv_t, kw.get("margin", 0.0),
+                                                          kw.get("dcl", False), kw.get("a2b", True), kw.get("b2a", True)).item()
+            assert abs(val - mine) < 2e-5 * max(1, abs(val)), (B, kw, val, mine)
+            cases.append((B, E, kw.get("margin", 0.0), int(kw.get("dcl", False)), int(kw.get("a2b", True)),
+                          int(kw.get("b2a", True)), inv_t, int(use_ids), val))
+        out[f"fa_{B}"], out[f"fb_{B}"], out[f"ids_{B}"] = fa.numpy(), fb.numpy(), ids.numpy()
+    losses_mod.MAX_EYE = 256
+    out["cases"] = np.array(cases, dtype=np.float64)
+    # the documented limitation: B > 256 raises in the reference
+    try:
+        losses_mod.MaskedContrastiveLoss()(torch.randn(300, 8), torch.randn(300, 8), torch.arange(300))
+        raised = False
+    except IndexError:
+        raised = True
+    assert raised
+    save("loss.npz", **out)
+
+
+def gen_retrieval(retrieval_mod):
+    g = torch.Generator().manual_seed(11)
+    n_img, cap = 40, 5
+    img = torch.nn.functional.normalize(torch.randn(n_img, 32, generator=g), dim=-1)
+    img_ids = torch.randperm(1000, generator=g)[:n_img]
+    aud = torch.nn.functional.normalize(img.repeat_interleave(cap, 0) + 0.9 * torch.randn(n_img * cap, 32, generator=g), dim=-1)
+    aud_ids = img_ids.repeat_interleave(cap, 0)
+    perm = torch.randperm(n_img * cap, generator=g)
+    aud, aud_ids = aud[perm], aud_ids[perm]
+    score = aud @ img.t()
+    ab, ba, mean = retrieval_mod.mutualRetrieval(score, score.t().contiguous(), aud_ids, img_ids, [1, 5, 10])
+    o_ab, o_ba, o_mean = speechclip_ref.mutual_retrieval(score, score.t(), aud_ids, img_ids, [1, 5, 10])
+    for k in ab:
+        assert abs(ab[k] - o_ab[k]) < 1e-4 and abs(ba[k] - o_ba[k]) < 1e-4 and abs(mean[k] - o_mean[k]) < 1e-4
+    save("retrieval.npz", aud=aud.numpy(), img=img.numpy(), aud_ids=aud_ids.numpy(), img_ids=img_ids.numpy(),
+         recall_ab=np.array([ab[f"recall@{k}"] for k in (1, 5, 10)]),
+         recall_ba=np.array([ba[f"recall@{k}"] for k in (1, 5, 10)]),
+         recall_mean=np.array([mean[f"recall@{k}"] for k in (1, 5, 10)]))
+
+
+def gen_small_ops(ws_mod, du_mod):
+    g = torch.Generator().manual_seed(3)
+    out = {}
+    for n in (13, 25):
+        for norm in (False, True):
+            layer = ws_mod.WeightedSumLayer(n, normalize_features=norm)
+            with torch.no_grad():
+                layer.weights.copy_(torch.randn(n, generator=g))
+            hs = [torch.randn(2, 7, 16, generator=g) for _ in range(n)]
+            with torch.no_grad():
+                y = layer(hs)
+            mine = speechclip_ref.weighted_sum(hs, layer.weights.detach(), norm)
+            assert torch.allclose(y, mine, atol=1e-6)
+            out[f"ws_{n}_{int(norm)}_w"] = layer.weights.detach().numpy()
+            out[f"ws_{n}_{int(norm)}_h"] = torch.stack(hs).numpy()
+            out[f"ws_{n}_{int(norm)}_y"] = y.numpy()
+    lens = torch.tensor([1, 5, 9, 10])
+    m = du_mod.get_keypadding_mask(10, lens)
+    assert torch.equal(m, speechclip_ref.keypadding_mask(10, lens))
+    out["kpm_lens"], out["kpm_mask"] = lens.numpy(), m.numpy()
+    save("small_ops.npz", **out)
+
+
+def tiny_config(OrderedNamespace, yaml_path, d_model, n_kw=8, cascaded=False, parallel=True, branch_heads=4,
+                normalize_hiddenstates=False, temperature_trainable=False, reduce_vocab=None):
+    import yaml
+    cfg = yaml.load(open(yaml_path), Loader=yaml.FullLoader)
+    ms = cfg["model_settings"]
+    ms["cascaded_objective_weight"] = 1.0 if cascaded else 0.0
+    ms["parallel_objective_weight"] = 1.0 if parallel else 0.0
+    ms["parallel_branch"]["transformer_args"].update(d_model=d_model, nhead=branch_heads, dim_feedforward=4 * d_model)
+    ms["cascaded_branch"]["transformer_args"].update(d_model=d_model, nhead=1, dim_feedforward=4 * d_model)
+    ms["cascaded_branch"]["keyword"]["number"] = n_kw
+    cfg["audio_encoder"]["normalize_hiddenstates"] = normalize_hiddenstates
+    cfg["cl_loss"]["args"]["temperature_trainable"] = temperature_trainable
+    cfg["clip"]["reduce_subword_embbedding"] = reduce_vocab
+    return OrderedNamespace(cfg)
+
+
+def gen_end_to_end(kwclip_mod, OrderedNamespace, tag, hubert_cfg, clip_cfg, cascaded, parallel, lens, normalize_hiddenstates,
+                   reduce_vocab_ids=None):
+    STATE["hubert_cfg"], STATE["clip_cfg"] = hubert_cfg, clip_cfg
+    vocab_path = None
+    if reduce_vocab_ids is not None:
+        vocab_path = os.path.join("/tmp", f"vocab_{tag}.npy")
+        np.save(vocab_path, np.stack([reduce_vocab_ids, np.arange(len(reduce_vocab_ids))[::-1] + 1], axis=1))
+    # the reference tokenizer stub reports 49406/49407; map them to the tiny vocab's last two ids
+    import clip.simple_tokenizer as st
+    st_enc = {"<|startoftext|>": clip_cfg.vocab_size - 2, "<|endoftext|>": clip_cfg.vocab_size - 1}
+    st.SimpleTokenizer.__init__ = lambda self: setattr(self, "encoder", st_enc)
+    d = hubert_cfg.encoder_embed_dim
+    cfg = tiny_config(OrderedNamespace, f"{REF}/config/speechCLIP/model_base/spchclp_{'c' if cascaded else 'p'}.yaml",
+                      d_model=d, cascaded=cascaded, parallel=parallel, branch_heads=4,
+                      normalize_hiddenstates=normalize_hiddenstates, reduce_vocab=vocab_path)
+    torch.manual_seed(2024)
+    model = kwclip_mod.KWClip_GeneralTransformer(cfg).eval()
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        model.audio_encoder.weightedsum_layer.weights.copy_(0.5 * torch.randn(hubert_cfg.encoder_layers + 1, generator=g))
+    B, lmax = len(lens), max(lens)
+    wav = torch.zeros(B, lmax)
+    for i, l in enumerate(lens):
+        wav[i, :l] = 0.3 * torch.randn(l, generator=g)
+    res = clip_cfg.image_resolution
+    batch = {"wav": wav, "wav_len": torch.tensor(lens), "image": torch.randn(B, 3, res, res, generator=g),
+             "id": torch.tensor([7, 7, 3, 9, 11, 3][:B])}
+    with torch.no_grad():
+        losses, log_metrics, others = model.forward(batch)
+        loss = model.compute_loss(losses)
+        feat, feat_len, hidden = model.forward_audio(batch["wav"], batch["wav_len"], return_hidden_states=True)
+    # standalone oracle on the same weights must agree
+    sc = speechclip_ref.SpeechClipRef(hubert_cfg, clip_cfg, parallel=parallel, cascaded=cascaded, branch_heads=4,
+                                      normalize_hiddenstates=normalize_hiddenstates,
+                                      reduced_vocab=torch.tensor(reduce_vocab_ids) if reduce_vocab_ids is not None else None).eval()
+    sd = model.state_dict()
+    sc.encoder.load_state_dict({k[len("audio_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("audio_encoder.encoder.")})
+    sc.clip.load_state_dict({k[len("clip.model."):]: v for k, v in sd.items() if k.startswith("clip.model.")})
+    with torch.no_grad():
+        sc.ws_weights.copy_(sd["audio_encoder.weightedsum_layer.weights"])
+    if parallel:
+        sc.parallel_branch.load_state_dict({k[len("parallel_branch."):]: v for k, v in sd.items() if k.startswith("parallel_branch.")})
+    if cascaded:
+        sc.cascaded_branch.load_state_dict({k[len("cascaded_branch."):]: v for k, v in sd.items()
+                                            if k.startswith("cascaded_branch.") and not k.startswith("cascaded_branch.clip.")
+                                            and "vector_quantizer" not in k})
+    o = sc(batch)
+    assert torch.equal(o["audio_len"], feat_len), (o["audio_len"], feat_len)
+    assert torch.allclose(o["audio_feat"], feat, atol=2e-5), (o["audio_feat"] - feat).abs().max()
+    assert torch.allclose(o["image_feat"], losses["image_feat"], atol=1e-5)
+    arrays = {"wav": wav.numpy(), "wav_len": np.array(lens), "image": batch["image"].numpy(), "id": batch["id"].numpy(),
+              "audio_feat": feat.numpy(), "feat_len": feat_len.numpy(), "image_feat": losses["image_feat"].numpy(),
+              "hidden_last": hidden[-1].numpy(), "hidden_0": hidden[0].numpy(), "loss": np.float64(loss["loss"].item())}
+    if parallel:
+        assert torch.allclose(o["parallel_audio_feat"], losses["parallel_audio_feat"], atol=1e-5)
+        arrays["parallel_audio_feat"] = losses["parallel_audio_feat"].numpy()
+    if cascaded:
+        assert torch.allclose(o["cascaded_audio_feat"], losses["cascaded_audio_feat"], atol=1e-5), \
+            (o["cascaded_audio_feat"] - losses["cascaded_audio_feat"]).abs().max()
+        assert torch.equal(o["vq_results"]["targets"], others["vq_results"]["targets"])
+        arrays["cascaded_audio_feat"] = losses["cascaded_audio_feat"].numpy()
+        arrays["vq_targets"] = others["vq_results"]["targets"].numpy()
+        arrays["vq_ent_per_t"] = others["vq_results"]["ent_per_t"].numpy()
+        arrays["keywords"] = others["keywords"].numpy()
+    my_loss = sc.compute_loss(o, w_par=1.0 if parallel else 0.0, w_casc=1.0 if cascaded else 0.0)["loss"].item()
+    assert abs(my_loss - loss["loss"].item()) < 1e-5
+    for k, v in np_state(sd).items():
+        if k.startswith("criterion.") or k.startswith("cascaded_branch.clip."):
+            continue
+        arrays["sd/" + k] = v
+    save(f"e2e_{tag}.npz", **arrays)
+
+
+def gen_feat_len_table(kwclip_mod, OrderedNamespace):
+    """feat_len (round-half-even of len/320, clamp T) and the HuBERT-internal frame mask for mixed batches."""
+    STATE["hubert_cfg"], STATE["clip_cfg"] = hubert_ref.HubertRefConfig.tiny(), clip_ref.ClipRefConfig.tiny()
+    from avssl.module.speech_encoder_plus import FairseqSpeechEncoder_Hubert
+    enc = FairseqSpeechEncoder_Hubert("hubert", pretrained=True, feat_select_idx="weighted_sum").eval()
+    rows = []
+    for lens in ([400, 480, 16000], [800, 1120, 1440, 1760, 8160, 15840, 16000], [80000, 102400, 159999, 160000],
+                 [480, 480], [4000, 12345, 33333, 40000]):
+        wav = torch.zeros(len(lens), max(lens))
+        with torch.no_grad():
+            feat, flen = enc(wav, torch.tensor(lens))
+            padded, mask = enc.preprocess_input([wav[i, :l] for i, l in enumerate(lens)])
+            T = feat.shape[1]
+            fm = enc.encoder.forward_padding_mask(torch.zeros(len(lens), T, 1), mask)
+        for i, l in enumerate(lens):
+            rows.append((max(lens), l, T, int(flen[i]), int((~fm[i]).sum())))
+    save("feat_len.npz", table=np.array(rows, dtype=np.int64))
+
+
+def main():
+    install_stubs()
+    import avssl.module.losses as losses_mod
+    import avssl.module.retrieval as retrieval_mod
+    import avssl.module.weighted_sum as ws_mod
+    import avssl.util.data_utils as du_mod
+    from avssl.base import OrderedNamespace
+    import avssl.model.kwClip as kwclip_mod
+
+    gen_loss(losses_mod)
+    gen_retrieval(retrieval_mod)
+    gen_small_ops(ws_mod, du_mod)
+    gen_feat_len_table(kwclip_mod, OrderedNamespace)
+    tiny_b = hubert_ref.HubertRefConfig.tiny()
+    tiny_l = hubert_ref.HubertRefConfig.tiny(layer_norm_first=True, extractor_mode="layer_norm", conv_bias=True)
+    tiny_clip = clip_ref.ClipRefConfig.tiny()
+    gen_end_to_end(kwclip_mod, OrderedNamespace, "tiny_base_p", tiny_b, tiny_clip, cascaded=False, parallel=True,
+                   lens=[8000, 5000, 6777, 1200], normalize_hiddenstates=False)
+    gen_end_to_end(kwclip_mod, OrderedNamespace, "tiny_large_p", tiny_l, tiny_clip, cascaded=False, parallel=True,
+                   lens=[6400, 8000, 3999], normalize_hiddenstates=True)
+    vocab = np.array([0, 320, 510, 511] + list(range(5, 300, 3)))
+    gen_end_to_end(kwclip_mod, OrderedNamespace, "tiny_base_c", tiny_b, tiny_clip, cascaded=True, parallel=False,
+                   lens=[8000, 5000, 6777, 1200], normalize_hiddenstates=False, reduce_vocab_ids=vocab)
+
+
+if __name__ == "__main__":
+    main()
