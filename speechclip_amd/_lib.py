@@ -1,0 +1,84 @@
+"""ctypes loader for libspeechclip_hip.so (the C-ABI product library).
+
+There is deliberately NO fallback: if the shared object is missing or a call fails the product
+raises.  PyTorch is used only for device memory and streams (tensor.data_ptr(), current stream).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspeechclip_hip.so")
+
+ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
+GEMM_OUT_F32 = 0x10
+
+_lib = None
+
+
+class SpeechClipHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SpeechClipHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C speechclip_amd/csrc).  There is no CPU/PyTorch fallback for the hot path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.sc_last_error.restype = c_char_p
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    P, I, L64, F = c_void_p, c_int, c_int64, c_float
+    sigs = {
+        "sc_abi_version": [],
+        "sc_gemm_bf16": [P, L64, P, L64, P, L64, P, P, L64, L64, I, I, I, P],
+        "sc_gemm_bf16_batched": [P, L64, L64, P, L64, L64, I, P, L64, L64, P, L64, I, I, I, I, P],
+        "sc_layernorm": [P, P, P, P, P, L64, I, F, I, P],
+        "sc_attention_fwd": [P, P, P, P, P, I, I, I, I, I, L64, L64, F, P],
+        "sc_cls_attention_fwd": [P, P, P, P, P, P, P, I, I, I, I, L64, L64, F, P],
+        "sc_conv0_stats": [P, P, I, L64, L64, P],
+        "sc_conv0_gn_gelu_fwd": [P, P, P, P, P, P, P, I, L64, L64, L64, L64, I, F, P],
+        "sc_wave_layernorm": [P, P, P, I, L64, F, P],
+        "sc_posconv_pack": [P, P, P, I, I, I, I, I, P],
+        "sc_posconv_finish": [P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
+        "sc_weighted_sum_fwd": [P, P, P, I, L64, I, I, F, P],
+        "sc_vit_patchify": [P, P, I, I, I, P],
+        "sc_vit_embed": [P, P, P, P, I, I, I, P],
+        "sc_l2norm_fwd": [P, P, L64, I, I, P],
+        "sc_infonce_fwd": [P, P, P, P, P, I, I, F, F, I, I, I, P],
+        "sc_rows_gather": [P, P, L64, L64, I, I, P],
+    }
+    for name, args in sigs.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = c_int
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SpeechClipHipError(f"{what} failed (rc={rc}): {lib().sc_last_error().decode()}")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def exported_symbols():
+    """Names declared in include/speechclip_hip.h (parsed), for the CPU-side ABI test."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "speechclip_hip.h")
+    text = open(hdr).read()
+    return sorted(set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", text)))

@@ -1,0 +1,72 @@
+// Shared device helpers for the SpeechCLIP hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef unsigned short bf16_t;  // raw storage type used in signatures
+
+#define SC_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;  // RNE; lowers to v_cvt_pk_bf16_f32 on gfx950
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) {
+    bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float lo2f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi2f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp + a handful of FMAs.
+__device__ __forceinline__ float fast_erf(float x) {
+    float ax = fabsf(x);
+    float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float poly = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
+    float r = 1.0f - poly * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+// exact-form GELU (erf), as torch.nn.functional.gelu / fairseq "gelu".
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+// CLIP QuickGELU: x * sigmoid(1.702 x)
+__device__ __forceinline__ float quick_gelu(float x) { return x * __frcp_rn(1.0f + __expf(-1.702f * x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// error plumbing (host)
+void sc_set_error(const char* fmt, ...);
+#define SC_CHECK_ARG(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            sc_set_error(__VA_ARGS__);     \
+            return -1;                     \
+        }                                  \
+    } while (0)
+#define SC_CHECK_LAUNCH()                                                   \
+    do {                                                                    \
+        hipError_t e_ = hipGetLastError();                                  \
+        if (e_ != hipSuccess) {                                             \
+            sc_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return -2;                                                      \
+        }                                                                   \
+    } while (0)

@@ -1,0 +1,59 @@
+"""GPU parity: sc_gemm_bf16 against a torch fp32 reference on the same bf16-rounded operands."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(a, w, bias, act, residual):
+    y = a.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias
+    if act == 1:
+        y = torch.nn.functional.gelu(y)
+    elif act == 2:
+        y = y * torch.sigmoid(1.702 * y)
+    if residual is not None:
+        y = y + residual.float()
+    return y
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 768, 768), (499, 2304, 768), (1000, 48, 6144), (130, 512, 1536),
+                                   (37, 132, 128)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_matches_fp32(M, N, K, act):
+    from speechclip_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N + K + act)
+    a = (torch.randn(M, K, generator=g) * 0.5).to("cuda", torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16)  # asymmetric, non-identity
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to("cuda", torch.bfloat16)
+    for use_bias, use_res, f32 in ((True, True, False), (False, False, False), (True, True, True)):
+        r = res.float() if f32 else res
+        y = ops.gemm(a, w, bias if use_bias else None, act, r if use_res else None, out_f32=f32)
+        ref = _ref(a, w, bias if use_bias else None, act, r if use_res else None)
+        tol = 2e-3 if f32 else 2e-2
+        torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)
+
+
+def test_gemm_overlapping_rows_is_conv1d():
+    """lda < K: channels-last conv1d (k=3, s=2) as a GEMM over overlapping rows."""
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(3)
+    T, C, k, s = 257, 64, 3, 2
+    x = (torch.randn(T, C, generator=g)).to("cuda", torch.bfloat16)
+    w = (torch.randn(128, C, k, generator=g) * 0.1).to("cuda", torch.bfloat16)     # [out, in, k]
+    w_g = w.permute(0, 2, 1).reshape(128, k * C).contiguous()                       # [out, k*in]
+    t_out = (T - k) // s + 1
+    y = ops.gemm(x, w_g, M=t_out, K=k * C, lda=s * C)
+    ref = torch.nn.functional.conv1d(x.float().t()[None], w.float(), stride=s)[0].t()
+    torch.testing.assert_close(y.float(), ref, atol=2e-2, rtol=2e-2)
+
+
+def test_gemm_transpose_detecting():
+    """A = I with an asymmetric W: catches a swapped C-write."""
+    from speechclip_amd import ops
+    a = torch.eye(128, device="cuda", dtype=torch.bfloat16)
+    w = (torch.arange(128 * 128, device="cuda").reshape(128, 128) % 251).to(torch.bfloat16)
+    y = ops.gemm(a, w)
+    torch.testing.assert_close(y.float(), w.float().t())
