@@ -57,6 +57,82 @@ int sc_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void
                          int64_t strideW, int w_mod, void* C, int64_t ldc, int64_t strideC,
                          const float* bias, int64_t M, int N, int K, int batch, int flags, void* stream);
 
+/* ---- LayerNorm (wave-per-row, D <= 1024) -----------------------------------------------------
+ * out[r,:] = [gelu]( (x[r,:] - mean) * rstd * gamma + beta ), gamma/beta may be NULL (no affine).
+ * Replaces every nn.LayerNorm on the path: fairseq layer_norm / self_attn_layer_norm /
+ * final_layer_norm / encoder.layer_norm (speech_encoder_plus.py:39-40,:52,:78), the conv-stack
+ * channel LayerNorm+GELU of the `layer_norm` extractor mode (large), CLIP ln_1/ln_2/ln_post
+ * (clip_official.py:209), branch norm1/norm2/final norm (TransformerModels.py:64-75,:117).
+ */
+#define SC_LN_IN_F32 0x1
+#define SC_LN_OUT_F32 0x2
+#define SC_LN_GELU 0x4
+int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, const float* beta, void* out, int64_t ld_out,
+                 int64_t rows, int D, float eps, int flags, void* stream);
+
+/* ---- Weighted sum of hidden states -- avssl/module/weighted_sum.py:26-45 ----------------------
+ * out[m,:] (bf16) = sum_i softmax(weights)_i * h_i[m,:]; h_i = hidden + i*layer_stride (elements),
+ * rows contiguous [rows, D].  SC_WS_NORMALIZE applies F.layer_norm(h_i, (D,)) (no affine) first. */
+#define SC_WS_NORMALIZE 0x1
+#define SC_WS_IN_F32 0x2
+int sc_weighted_sum_fwd(const void* hidden, int64_t layer_stride, const float* weights, void* out, int n_layers,
+                        int64_t rows, int D, int flags, float eps, void* stream);
+
+/* ---- L2 normalise -- avssl/model/kwClip.py:1436,:1444-1454 (x / ||x||, no eps), f32 out ------- */
+int sc_l2norm_fwd(const void* x, int64_t ld_in, float* out, int64_t rows, int D, int in_f32, void* stream);
+
+/* ---- Per-utterance wave layer-norm -- speech_encoder_plus.py:507-508 (task.cfg.normalize) -----
+ * out[b,:len_b] = layer_norm(wav[b,:len_b]); out[b,len_b:] = 0.  wav/out are [B, ld] f32. */
+int sc_wave_layernorm(const float* wav, float* out, const int32_t* lens, int B, int64_t ld, float eps, void* stream);
+
+/* ---- Attention ---------------------------------------------------------------------------------
+ * Flash-style forward, head_dim 64, per-utterance key lengths (klens[b] keys valid; NULL = T).
+ * q/k/v point at the first head's columns of row 0; rows are (b*T + t) with stride ld_qkv; head h
+ * is at column offset h*64.  Replaces fairseq MultiheadAttention (key_padding_mask -> -inf) inside
+ * TransformerSentenceEncoderLayer (speech_encoder_plus.py:52) and CLIP's nn.MultiheadAttention
+ * in ResidualAttentionBlock (clip_official.py:209).  out: bf16 [B*T, H*64] rows of stride ld_out. */
+int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H,
+                     int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, void* stream);
+
+/* CLS-rows-only attention of the pooling heads (kwClip.py:1089-1099 parallel, :869-881 cascaded):
+ * NQ learned query tokens attend to [NQ CLS tokens ; frames t < lens[b]].  cls_qkv: bf16 [NQ, 3*D]
+ * (q|k|v of the CLS tokens); kv_x: bf16 rows (b*T+t) = [k | v] of the frames, stride ld_kv;
+ * out: bf16 [B, NQ, D], D = H*head_dim. */
+int sc_cls_attention_fwd(const void* cls_qkv, const void* kv_x, int64_t ld_kv, const int32_t* lens, void* out, int B, int T,
+                         int NQ, int H, int head_dim, float scale, void* stream);
+
+/* ---- HuBERT conv layer 0 -- fairseq ConvFeatureExtractionModel block 0 (speech_encoder_plus.py:75)
+ * wav f32 [B, ld] (zero padded, L valid columns), w f32 [C,10], out bf16 channels-last [B, P, C]
+ * (P >= T0 rows per utterance; rows >= T0 are written as zeros).
+ * sc_conv0_gn_coef: per-(b,c) GroupNorm scale/shift from the 10x10 sample autocorrelation
+ * (fp64) -- the statistics are over all T0 frames of the padded batch, as in the reference.
+ * sc_conv0_fwd mode 0: conv -> GroupNorm(coef) -> GELU; mode 1: conv + bias (no norm, no act). */
+int64_t sc_conv0_stats_workspace_bytes(int B);
+int sc_conv0_gn_coef(const float* wav, int64_t ld, const float* w, const float* gamma, const float* beta, void* workspace,
+                     float* coef, int B, int C, int T0, float eps, void* stream);
+int sc_conv0_fwd(const float* wav, int64_t ld, int64_t L, const float* w, const float* bias, const float* coef, void* out, int B,
+                 int C, int T0, int P, int mode, void* stream);
+
+/* ---- HuBERT positional conv -- speech_encoder_plus.py:32-40 ------------------------------------
+ * pack: zero padded frames (t >= valid[b]) and regroup x bf16 [B*Tp, D] into xg bf16
+ * [B][G][Tp+Kw][D/G] (Kw/2 zero rows each side) so that group g is an overlapping-row GEMM
+ * (lda = D/G, K = Kw*D/G) via sc_gemm_bf16_batched -> conv bf16 [B*G][Tp][D/G].
+ * finish: out = [LayerNorm]( mask(x) + gelu(conv + bias) ); gamma NULL = no LN (layer_norm_first). */
+int sc_posconv_pack(const void* x, const int32_t* valid, void* xg, int B, int Tp, int D, int G, int Kw, void* stream);
+int sc_posconv_finish(const void* x, const int32_t* valid, const void* conv, const float* bias, const float* gamma, const float* beta,
+                      void* out, int B, int Tp, int D, int G, int out_f32, float eps, void* stream);
+
+/* ---- CLIP ViT stem -- openai VisionTransformer.forward up to ln_pre (clip_official.py:209) ----- */
+int sc_vit_patchify(const float* img, void* cols, int B, int R, int p, int Kpad, void* stream);
+int sc_vit_embed(const void* patch, const float* cls, const float* pos, const float* gamma, const float* beta, float* out, int B,
+                 int ntok, int D, float eps, void* stream);
+
+/* ---- Masked InfoNCE -- avssl/module/losses.py:185-245 (any global batch size) ------------------
+ * feat_a/feat_b f32 [Bg,E] (unit norm), ids int64 [Bg] or NULL, out3 = {loss, a2b term, b2a term}. */
+int64_t sc_infonce_workspace_bytes(int Bg);
+int sc_infonce_fwd(const float* feat_a, const float* feat_b, const int64_t* ids, void* workspace, float* out3, int Bg, int E,
+                   float inv_temperature, float margin, int dcl, int a2b, int b2a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

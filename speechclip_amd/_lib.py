@@ -38,29 +38,29 @@ def lib():
 def _declare(L):
     P, I, L64, F = c_void_p, c_int, c_int64, c_float
     sigs = {
-        "sc_abi_version": [],
-        "sc_gemm_bf16": [P, L64, P, L64, P, L64, P, P, L64, L64, I, I, I, P],
-        "sc_gemm_bf16_batched": [P, L64, L64, P, L64, L64, I, P, L64, L64, P, L64, I, I, I, I, P],
-        "sc_layernorm": [P, P, P, P, P, L64, I, F, I, P],
-        "sc_attention_fwd": [P, P, P, P, P, I, I, I, I, I, L64, L64, F, P],
-        "sc_cls_attention_fwd": [P, P, P, P, P, P, P, I, I, I, I, L64, L64, F, P],
-        "sc_conv0_stats": [P, P, I, L64, L64, P],
-        "sc_conv0_gn_gelu_fwd": [P, P, P, P, P, P, P, I, L64, L64, L64, L64, I, F, P],
-        "sc_wave_layernorm": [P, P, P, I, L64, F, P],
-        "sc_posconv_pack": [P, P, P, I, I, I, I, I, P],
-        "sc_posconv_finish": [P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
-        "sc_weighted_sum_fwd": [P, P, P, I, L64, I, I, F, P],
-        "sc_vit_patchify": [P, P, I, I, I, P],
-        "sc_vit_embed": [P, P, P, P, I, I, I, P],
-        "sc_l2norm_fwd": [P, P, L64, I, I, P],
-        "sc_infonce_fwd": [P, P, P, P, P, I, I, F, F, I, I, I, P],
-        "sc_rows_gather": [P, P, L64, L64, I, I, P],
+        "sc_abi_version": ([], c_int),
+        "sc_gemm_bf16": ([P, L64, P, L64, P, L64, P, P, L64, L64, I, I, I, P], c_int),
+        "sc_gemm_bf16_batched": ([P, L64, L64, P, L64, L64, I, P, L64, L64, P, L64, I, I, I, I, P], c_int),
+        "sc_layernorm": ([P, L64, P, P, P, L64, L64, I, F, I, P], c_int),
+        "sc_weighted_sum_fwd": ([P, L64, P, P, I, L64, I, I, F, P], c_int),
+        "sc_l2norm_fwd": ([P, L64, P, L64, I, I, P], c_int),
+        "sc_wave_layernorm": ([P, P, P, I, L64, F, P], c_int),
+        "sc_attention_fwd": ([P, P, P, P, P, I, I, I, I, L64, L64, F, P], c_int),
+        "sc_cls_attention_fwd": ([P, P, L64, P, P, I, I, I, I, I, F, P], c_int),
+        "sc_conv0_stats_workspace_bytes": ([I], c_int64),
+        "sc_conv0_gn_coef": ([P, L64, P, P, P, P, P, I, I, I, F, P], c_int),
+        "sc_conv0_fwd": ([P, L64, L64, P, P, P, P, I, I, I, I, I, P], c_int),
+        "sc_posconv_pack": ([P, P, P, I, I, I, I, I, P], c_int),
+        "sc_posconv_finish": ([P, P, P, P, P, P, P, I, I, I, I, I, F, P], c_int),
+        "sc_vit_patchify": ([P, P, I, I, I, I, P], c_int),
+        "sc_vit_embed": ([P, P, P, P, P, P, I, I, I, F, P], c_int),
+        "sc_infonce_workspace_bytes": ([I], c_int64),
+        "sc_infonce_fwd": ([P, P, P, P, P, I, I, F, F, I, I, I, P], c_int),
     }
-    for name, args in sigs.items():
-        if hasattr(L, name):
-            fn = getattr(L, name)
-            fn.argtypes = args
-            fn.restype = c_int
+    for name, (args, res) in sigs.items():
+        fn = getattr(L, name)   # AttributeError here = header/library mismatch: fail loudly
+        fn.argtypes = args
+        fn.restype = res
 
 
 def check(rc, what):

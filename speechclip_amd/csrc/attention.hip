@@ -1,0 +1,305 @@
+// Scaled-dot-product attention kernels for gfx950.
+//  (1) attn_fwd_kernel: flash-style forward for head_dim 64 with per-utterance key lengths
+//      (HuBERT layers: fairseq MultiheadAttention with key_padding_mask; CLIP ViT blocks: no mask).
+//      One wave owns 32 query rows.  S^T = K.Q^T is computed with the operands swapped
+//      (mfma(K, Q)) so a lane holds 16 keys of ONE query: the row max/sum is in-lane plus one
+//      cross-half shuffle, and the exponentiated registers are already in B-operand order for the
+//      O^T += V^T.P^T MFMA (the key->k-slot permutation is chosen to match, so no permlane).
+//      K tiles arrive by LDS-DMA into an XOR-swizzled image; V tiles are transposed through
+//      registers into a padded V^T image (conflict-free ds_read_b64).  Double-buffered, one
+//      barrier per 64-key tile; tiles past the utterance's key length are skipped entirely.
+//  (2) cls_attn_kernel: the CLS-rows-only attention of the parallel / cascaded heads: NQ <= 8 learned
+//      query tokens against [CLS tokens ; valid frames] for any head_dim <= 1024 (VALU, HBM-bound).
+#include "common.h"
+#include "../../include/speechclip_hip.h"
+
+namespace {
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int KV = 64;          // keys per tile
+constexpr int VT_STRIDE = 136;  // bytes per V^T row (64 keys * 2 B + 8 B pad)
+constexpr int K_TILE_BYTES = KV * 128;
+constexpr int VT_TILE_BYTES = 64 * VT_STRIDE;
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                       const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
+                                                       const int32_t* __restrict__ klens, int T, int64_t ld_qkv,
+                                                       int64_t ld_out, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kbuf = smem;                       // 2 x 8 KiB
+    char* Vbuf = smem + 2 * K_TILE_BYTES;    // 2 x 8.5 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int g = lane >> 5, ql = lane & 31;
+    const int64_t row_base = (int64_t)b * T;
+    const int hoff = h * 64;
+
+    int klen = klens ? klens[b] : T;
+    klen = klen < 0 ? 0 : (klen > T ? T : klen);
+    const int nkv = (klen + KV - 1) / KV;
+
+    const int qrow = blockIdx.x * 128 + wave * 32 + ql;
+    const int qrow_c = qrow < T ? qrow : T - 1;
+
+    // Q fragments: B operand of S^T (col = query, k-slots = 8 dims)
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        qf[c] = *(const bf16x8_t*)(q + (row_base + qrow_c) * ld_qkv + hoff + c * 16 + g * 8);
+
+    // staging helpers
+    const int vj = tid >> 3, vdc = tid & 7;  // V: key pair, d-chunk
+    auto stage_k = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int cid = i * 256 + tid;
+            int key = cid >> 3, pos = cid & 7;
+            int kr = tile * KV + key;
+            kr = kr < T ? kr : T - 1;
+            glds16(k + (row_base + kr) * ld_qkv + hoff + ((pos ^ (key & 7)) << 3), Kbuf + buf * K_TILE_BYTES + (i * 256 + wave * 64) * 16);
+        }
+    };
+    uint4 v0, v1;
+    auto load_v = [&](int tile) {
+        int k0 = tile * KV + 2 * vj, k1 = k0 + 1;
+        k0 = k0 < T ? k0 : T - 1;
+        k1 = k1 < T ? k1 : T - 1;
+        v0 = *(const uint4*)(v + (row_base + k0) * ld_qkv + hoff + vdc * 8);
+        v1 = *(const uint4*)(v + (row_base + k1) * ld_qkv + hoff + vdc * 8);
+    };
+    auto write_v = [&](int buf) {
+        char* base = Vbuf + buf * VT_TILE_BYTES + (vdc * 8) * VT_STRIDE + vj * 4;
+        const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w};
+        const uint32_t c[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(uint32_t*)(base + (2 * i) * VT_STRIDE) = (a[i] & 0xffffu) | (c[i] << 16);
+            *(uint32_t*)(base + (2 * i + 1) * VT_STRIDE) = (a[i] >> 16) | (c[i] & 0xffff0000u);
+        }
+    };
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    if (nkv > 0) {
+        stage_k(0, 0);
+        load_v(0);
+        write_v(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int j = 0; j < nkv; ++j) {
+        const int cur = j & 1;
+        const bool more = (j + 1 < nkv);
+        if (more) {
+            stage_k(j + 1, cur ^ 1);
+            load_v(j + 1);
+        }
+        const char* kb_ = Kbuf + cur * K_TILE_BYTES;
+        const char* vb_ = Vbuf + cur * VT_TILE_BYTES;
+        // ---- S^T = K . Q^T
+        f32x16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+            const int key = kb * 32 + ql;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bf16x8_t kf = *(const bf16x8_t*)(kb_ + key * 128 + (((2 * c + g) ^ (key & 7)) << 4));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], s[kb], 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax (log2 domain)
+        float mx = -INFINITY;
+        const int kv0 = j * KV;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                float t = s[kb][r] * scale_log2e;
+                t = key < klen ? t : -INFINITY;
+                s[kb][r] = t;
+                mx = fmaxf(mx, t);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(s[kb][r] - m_new);
+                s[kb][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int kb = c4 >> 1, hb = c4 & 1;
+            bf16x8_t pf;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)s[kb][hb * 8 + jj];
+            const int kofs = (kb * 32 + hb * 16 + 4 * g) * 2;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const char* vr = vb_ + (db * 32 + ql) * VT_STRIDE + kofs;
+                const uint2 lo = *(const uint2*)vr;
+                const uint2 hi = *(const uint2*)(vr + 16);
+                uint4 u = {lo.x, lo.y, hi.x, hi.y};
+                bf16x8_t vf = __builtin_bit_cast(bf16x8_t, u);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+            }
+        }
+        if (more) write_v(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qrow < T) {
+        bf16_t* orow = out + (row_base + qrow) * ld_out + hoff;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                uint2 p;
+                p.x = pack2bf(o[db][rq * 4 + 0] * inv, o[db][rq * 4 + 1] * inv);
+                p.y = pack2bf(o[db][rq * 4 + 2] * inv, o[db][rq * 4 + 3] * inv);
+                *(uint2*)(orow + db * 32 + rq * 8 + g * 4) = p;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CLS-rows-only attention.  Keys/values: first the NQ CLS tokens (batch independent, rows of
+// cls_qkv = [q | k | v] each D wide), then frames t < lens[b] of kv_x ([k | v], row stride ld_kv).
+__global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict__ cls_qkv, const bf16_t* __restrict__ kv_x, int64_t ld_kv,
+                                                       const int32_t* __restrict__ lens, bf16_t* __restrict__ out, int T, int NQ, int H,
+                                                       int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = H * hd;
+    float* qs = (float*)smem;               // [NQ][hd]
+    float* sc = qs + NQ * hd;               // [NQ][NQ + T]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int len = lens ? lens[b] : T;
+    len = len < 0 ? 0 : (len > T ? T : len);
+    const int nkeys = NQ + len;
+    const int skeys = NQ + T;
+
+    for (int i = tid; i < NQ * hd; i += 256) {
+        int qi = i / hd, d = i - qi * hd;
+        qs[i] = bf2f(cls_qkv[(int64_t)qi * 3 * D + h * hd + d]) * scale;
+    }
+    __syncthreads();
+    // scores: one wave per key
+    for (int kk = wave; kk < nkeys; kk += 4) {
+        const bf16_t* kr = kk < NQ ? cls_qkv + (int64_t)kk * 3 * D + D + h * hd
+                                   : kv_x + ((int64_t)b * T + (kk - NQ)) * ld_kv + h * hd;
+        float part[8];
+#pragma unroll
+        for (int qi = 0; qi < 8; ++qi) part[qi] = 0.f;
+        for (int e = lane * 4; e < hd; e += 256) {
+            const uint2 u = *(const uint2*)(kr + e);
+            const float k0 = lo2f(u.x), k1 = hi2f(u.x), k2 = lo2f(u.y), k3 = hi2f(u.y);
+#pragma unroll
+            for (int qi = 0; qi < 8; ++qi)
+                if (qi < NQ) {
+                    const float* qq = qs + qi * hd + e;
+                    part[qi] += qq[0] * k0 + qq[1] * k1 + qq[2] * k2 + qq[3] * k3;
+                }
+        }
+#pragma unroll
+        for (int qi = 0; qi < 8; ++qi)
+            if (qi < NQ) {
+                float t = wave_sum(part[qi]);
+                if (lane == 0) sc[qi * skeys + kk] = t;
+            }
+    }
+    __syncthreads();
+    // softmax: wave w handles queries w, w+4
+    for (int qi = wave; qi < NQ; qi += 4) {
+        float* row = sc + qi * skeys;
+        float mx = -INFINITY;
+        for (int kk = lane; kk < nkeys; kk += 64) mx = fmaxf(mx, row[kk]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int kk = lane; kk < nkeys; kk += 64) { float e = __expf(row[kk] - mx); row[kk] = e; sum += e; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int kk = lane; kk < nkeys; kk += 64) row[kk] *= inv;
+    }
+    __syncthreads();
+    // out[q][d] = sum_k p[q][k] V[k][d]; thread handles 2 adjacent d
+    for (int d = tid * 2; d < hd; d += 512) {
+        float acc0[8], acc1[8];
+#pragma unroll
+        for (int qi = 0; qi < 8; ++qi) { acc0[qi] = 0.f; acc1[qi] = 0.f; }
+        for (int kk = 0; kk < nkeys; ++kk) {
+            const bf16_t* vr = kk < NQ ? cls_qkv + (int64_t)kk * 3 * D + 2 * D + h * hd
+                                       : kv_x + ((int64_t)b * T + (kk - NQ)) * ld_kv + D + h * hd;
+            const uint32_t u = *(const uint32_t*)(vr + d);
+            const float x0 = lo2f(u), x1 = hi2f(u);
+#pragma unroll
+            for (int qi = 0; qi < 8; ++qi)
+                if (qi < NQ) {
+                    const float pw = sc[qi * skeys + kk];
+                    acc0[qi] += pw * x0;
+                    acc1[qi] += pw * x1;
+                }
+        }
+#pragma unroll
+        for (int qi = 0; qi < 8; ++qi)
+            if (qi < NQ) *(uint32_t*)(out + ((int64_t)b * NQ + qi) * D + h * hd + d) = pack2bf(acc0[qi], acc1[qi]);
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H,
+                                int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, void* stream) {
+    SC_CHECK_ARG(head_dim == 64, "sc_attention_fwd: head_dim=%d unsupported (64 only; use sc_cls_attention_fwd for pooling heads)", head_dim);
+    SC_CHECK_ARG(ld_qkv % 8 == 0 && ld_out % 4 == 0, "sc_attention_fwd: ld_qkv must be a multiple of 8, ld_out of 4");
+    SC_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "sc_attention_fwd: misaligned pointers");
+    SC_CHECK_ARG(H <= 65535 && B <= 65535, "sc_attention_fwd: H/B exceed grid limits");
+    if (B <= 0 || T <= 0) return 0;
+    static bool attr = false;
+    constexpr int lds = 2 * K_TILE_BYTES + 2 * VT_TILE_BYTES;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    dim3 grid((T + 127) / 128, H, B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_cls_attention_fwd(const void* cls_qkv, const void* kv_x, int64_t ld_kv, const int32_t* lens, void* out, int B, int T,
+                                    int NQ, int H, int head_dim, float scale, void* stream) {
+    SC_CHECK_ARG(NQ >= 1 && NQ <= 8, "sc_cls_attention_fwd: NQ=%d must be in [1,8]", NQ);
+    SC_CHECK_ARG(head_dim % 4 == 0 && head_dim <= 1024, "sc_cls_attention_fwd: head_dim=%d must be a multiple of 4, <= 1024", head_dim);
+    SC_CHECK_ARG(ld_kv % 4 == 0, "sc_cls_attention_fwd: ld_kv must be a multiple of 4");
+    if (B <= 0) return 0;
+    const int lds = (NQ * head_dim + NQ * (NQ + T)) * 4;
+    SC_CHECK_ARG(lds <= 160 * 1024, "sc_cls_attention_fwd: T=%d too long for the LDS score buffer", T);
+    (void)hipFuncSetAttribute((const void*)cls_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(cls_attn_kernel, dim3(H, B), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)cls_qkv, (const bf16_t*)kv_x, ld_kv,
+                       lens, (bf16_t*)out, T, NQ, H, head_dim, scale);
+    SC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,325 @@
+// Front-end kernels of the two towers (HBM-bound segments):
+//   * HuBERT conv layer 0 (Conv1d 1->C, k=10, s=5) fused with GroupNorm(C groups)+GELU.  The GroupNorm
+//     statistics over the whole time axis are obtained WITHOUT a first conv pass: with
+//     y[c,t] = sum_j w[c,j] x[5t+j],  sum_t y = w_c . s  and  sum_t y^2 = w_c^T R w_c  where
+//     s[j] = sum_t x[5t+j], R[j,j'] = sum_t x[5t+j] x[5t+j'] (10 + 55 numbers per utterance, fp64).
+//   * positional grouped conv (k=128, 16 groups): pack into a group-major zero-padded layout so each
+//     group becomes an overlapping-row GEMM, and the finishing gather + bias + GELU + residual (+LayerNorm).
+//   * CLIP ViT stem: patchify (im2col for the stride=patch conv) and class/positional embedding + ln_pre.
+#include "common.h"
+#include "../../include/speechclip_hip.h"
+
+namespace {
+
+constexpr int CK = 10, CS = 5;        // conv0 kernel / stride
+constexpr int NSTAT = CK + CK * (CK + 1) / 2;  // 65
+constexpr int NSPLIT = 8;
+
+__global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restrict__ wav, int64_t ld, int T0, double* __restrict__ partial) {
+    __shared__ double red[4][NSTAT];
+    const int b = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* x = wav + (int64_t)b * ld;
+    const int per = (T0 + NSPLIT - 1) / NSPLIT;
+    const int t_lo = sp * per, t_hi = min(T0, t_lo + per);
+    double acc[NSTAT];
+#pragma unroll
+    for (int i = 0; i < NSTAT; ++i) acc[i] = 0.0;
+    for (int t = t_lo + tid; t < t_hi; t += 256) {
+        double xv[CK];
+#pragma unroll
+        for (int j = 0; j < CK; ++j) xv[j] = (double)x[(int64_t)CS * t + j];
+        int idx = CK;
+#pragma unroll
+        for (int j = 0; j < CK; ++j) {
+            acc[j] += xv[j];
+#pragma unroll
+            for (int k = j; k < CK; ++k) acc[idx++] += xv[j] * xv[k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NSTAT; ++i) {
+        double r = wave_sum_d(acc[i]);
+        if (lane == 0) red[wv][i] = r;
+    }
+    __syncthreads();
+    if (tid < NSTAT) partial[((int64_t)b * NSPLIT + sp) * NSTAT + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// coef[b][c] = (scale, shift) so that GroupNorm(conv)[c,t] = conv[c,t]*scale + shift
+__global__ __launch_bounds__(256) void conv0_coef_kernel(const double* __restrict__ partial, const float* __restrict__ w, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float2* __restrict__ coef, int C, int T0, float eps) {
+    __shared__ double st[NSTAT];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < NSTAT) {
+        double t = 0;
+        for (int sp = 0; sp < NSPLIT; ++sp) t += partial[((int64_t)b * NSPLIT + sp) * NSTAT + tid];
+        st[tid] = t;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        double wv[CK];
+        for (int j = 0; j < CK; ++j) wv[j] = (double)w[c * CK + j];
+        double sum = 0, sq = 0;
+        int idx = CK;
+        for (int j = 0; j < CK; ++j) {
+            sum += wv[j] * st[j];
+            for (int k = j; k < CK; ++k) sq += (j == k ? 1.0 : 2.0) * wv[j] * wv[k] * st[idx++];
+        }
+        const double mean = sum / T0;
+        double var = sq / T0 - mean * mean;
+        var = var > 0 ? var : 0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double sc = (double)gamma[c] * rstd;
+        coef[(int64_t)b * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
+    }
+}
+
+// out[b][t][c] (channels-last bf16, P rows per utterance).  mode 0: GroupNorm coefficients + GELU; mode 1: raw conv + bias.
+constexpr int TT = 64;
+__global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ wav, int64_t ld, int64_t L, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float2* __restrict__ coef, bf16_t* __restrict__ out,
+                                                        int C, int T0, int P, int mode) {
+    __shared__ float xs[TT * CS + CK];
+    const int b = blockIdx.y, t0 = blockIdx.x * TT, tid = threadIdx.x;
+    const float* x = wav + (int64_t)b * ld;
+    for (int i = tid; i < TT * CS + CK; i += 256) {
+        int64_t si = (int64_t)t0 * CS + i;
+        xs[i] = si < L ? x[si] : 0.f;
+    }
+    const int cpairs = C >> 1;
+    const int cp = tid % cpairs, fs = tid / cpairs, fpar = 256 / cpairs;
+    const int c0 = cp * 2;
+    float w0[CK], w1[CK];
+#pragma unroll
+    for (int j = 0; j < CK; ++j) { w0[j] = w[c0 * CK + j]; w1[j] = w[(c0 + 1) * CK + j]; }
+    float sc0 = 1.f, sh0 = 0.f, sc1 = 1.f, sh1 = 0.f;
+    if (mode == 0) {
+        const float2 a = coef[(int64_t)b * C + c0], d = coef[(int64_t)b * C + c0 + 1];
+        sc0 = a.x; sh0 = a.y; sc1 = d.x; sh1 = d.y;
+    } else if (bias) {
+        sh0 = bias[c0]; sh1 = bias[c0 + 1];
+    }
+    __syncthreads();
+    for (int f = fs; f < TT; f += fpar) {
+        const int t = t0 + f;
+        if (t >= P) break;
+        uint32_t o = 0;
+        if (t < T0) {
+            float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < CK; ++j) {
+                const float xv = xs[f * CS + j];
+                y0 = fmaf(w0[j], xv, y0);
+                y1 = fmaf(w1[j], xv, y1);
+            }
+            y0 = fmaf(y0, sc0, sh0);
+            y1 = fmaf(y1, sc1, sh1);
+            if (mode == 0) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); }
+            o = pack2bf(y0, y1);
+        }
+        *(uint32_t*)(out + ((int64_t)b * P + t) * C + c0) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- pos-conv
+// xg[b][g][Kw/2 + t][c] = t < valid[b] ? x[b][t][g*cg + c] : 0, rows [0,Kw/2) and [Kw/2+Tp, Tp+Kw) zero.
+__global__ __launch_bounds__(256) void posconv_pack_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ valid, bf16_t* __restrict__ xg,
+                                                           int Tp, int D, int G, int Kw) {
+    const int cg = D / G;
+    const int rows = Tp + Kw;
+    const int b = blockIdx.z, g = blockIdx.y;
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 4);  // 16 rows per block, 16 threads per row
+    if (r >= rows) return;
+    const int t = r - Kw / 2;
+    const bool live = t >= 0 && t < Tp && t < valid[b];
+    bf16_t* dst = xg + (((int64_t)b * G + g) * rows + r) * cg;
+    const bf16_t* src = x + ((int64_t)b * Tp + (live ? t : 0)) * D + g * cg;
+    for (int c = (threadIdx.x & 15) * 4; c < cg; c += 64) {
+        uint2 v = make_uint2(0u, 0u);
+        if (live) v = *(const uint2*)(src + c);
+        *(uint2*)(dst + c) = v;
+    }
+}
+
+// out[b,t,:] = [LN]( mask(x)[b,t,:] + gelu(cg_out[b,g,t,c] + bias) )
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void posconv_finish_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ valid, const bf16_t* __restrict__ conv,
+                                                             const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             void* __restrict__ out, int B, int Tp, int D, int G, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * Tp) return;
+    const int b = (int)(row / Tp), t = (int)(row - (int64_t)b * Tp);
+    const int cg = D / G;
+    const bool live = t < valid[b];
+    float v[4][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int e = c * 256 + lane * 4;
+        v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+        if (e < D) {
+            const int g = e / cg, ci = e - g * cg;  // cg % 4 == 0 so the 4 elements stay in one group
+            const uint2 cv = *(const uint2*)(conv + (((int64_t)b * G + g) * Tp + t) * cg + ci);
+            float xv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (live) {
+                const uint2 xx = *(const uint2*)(x + row * D + e);
+                xv[0] = lo2f(xx.x); xv[1] = hi2f(xx.x); xv[2] = lo2f(xx.y); xv[3] = hi2f(xx.y);
+            }
+            v[c][0] = xv[0] + gelu_erf(lo2f(cv.x) + bias[e]);
+            v[c][1] = xv[1] + gelu_erf(hi2f(cv.x) + bias[e + 1]);
+            v[c][2] = xv[2] + gelu_erf(lo2f(cv.y) + bias[e + 2]);
+            v[c][3] = xv[3] + gelu_erf(hi2f(cv.y) + bias[e + 3]);
+            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (gamma) {
+        mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int e = c * 256 + lane * 4;
+            if (e < D) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { float d = v[c][i] - mean; q += d * d; }
+            }
+        }
+        rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int e = c * 256 + lane * 4;
+        if (e < D) {
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = gamma ? (v[c][i] - mean) * rstd * gamma[e + i] + beta[e + i] : v[c][i];
+            if (OUT_F32) *(f32x4_t*)((float*)out + row * D + e) = (f32x4_t){o[0], o[1], o[2], o[3]};
+            else { uint2 p; p.x = pack2bf(o[0], o[1]); p.y = pack2bf(o[2], o[3]); *(uint2*)((bf16_t*)out + row * D + e) = p; }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------- ViT stem
+// cols[b*np + gy*g + gx][c*p*p + py*p + px] = img[b][c][gy*p+py][gx*p+px]; columns [3*p*p, Kpad) zero.
+__global__ __launch_bounds__(256) void vit_patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ cols, int R, int p, int Kpad) {
+    const int g = R / p, np = g * g;
+    const int row = blockIdx.x, b = row / np, pi = row - b * np, gy = pi / g, gx = pi - gy * g;
+    const int K = 3 * p * p;
+    for (int k = threadIdx.x; k < Kpad; k += 256) {
+        float val = 0.f;
+        if (k < K) {
+            const int c = k / (p * p), rem = k - c * p * p, py = rem / p, px = rem - py * p;
+            val = img[(((int64_t)b * 3 + c) * R + gy * p + py) * R + gx * p + px];
+        }
+        cols[(int64_t)row * Kpad + k] = f2bf(val);
+    }
+}
+
+// x0[b][tk][:] = ln_pre( (tk == 0 ? class_emb : patch[b*np + tk - 1]) + pos[tk] )   (f32 residual stream)
+__global__ __launch_bounds__(256) void vit_embed_kernel(const bf16_t* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out,
+                                                        int64_t rows, int ntok, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t b = row / ntok;
+    const int tk = (int)(row - b * ntok);
+    float v[4][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int e = c * 256 + lane * 4;
+        v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+        if (e < D) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float base = tk == 0 ? cls[e + i] : bf2f(patch[(b * (ntok - 1) + tk - 1) * D + e + i]);
+                v[c][i] = base + pos[(int64_t)tk * D + e + i];
+            }
+            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int e = c * 256 + lane * 4;
+        if (e < D) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { float d = v[c][i] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int e = c * 256 + lane * 4;
+        if (e < D)
+            *(f32x4_t*)(out + row * D + e) = (f32x4_t){(v[c][0] - mean) * rstd * gamma[e] + beta[e], (v[c][1] - mean) * rstd * gamma[e + 1] + beta[e + 1],
+                                                        (v[c][2] - mean) * rstd * gamma[e + 2] + beta[e + 2], (v[c][3] - mean) * rstd * gamma[e + 3] + beta[e + 3]};
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t sc_conv0_stats_workspace_bytes(int B) { return (int64_t)B * NSPLIT * NSTAT * 8; }
+
+extern "C" int sc_conv0_gn_coef(const float* wav, int64_t ld, const float* w, const float* gamma, const float* beta, void* workspace,
+                                float* coef, int B, int C, int T0, float eps, void* stream) {
+    SC_CHECK_ARG(B > 0 && C > 0 && T0 > 0, "sc_conv0_gn_coef: bad sizes B=%d C=%d T0=%d", B, C, T0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv0_stats_kernel, dim3(B, NSPLIT), dim3(256), 0, s, wav, ld, T0, (double*)workspace);
+    SC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(conv0_coef_kernel, dim3(B), dim3(256), 0, s, (const double*)workspace, w, gamma, beta, (float2*)coef, C, T0, eps);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_conv0_fwd(const float* wav, int64_t ld, int64_t L, const float* w, const float* bias, const float* coef, void* out, int B,
+                            int C, int T0, int P, int mode, void* stream) {
+    SC_CHECK_ARG(C >= 2 && C <= 512 && 512 % C == 0, "sc_conv0_fwd: C=%d must divide 512", C);
+    SC_CHECK_ARG(mode == 1 || coef != nullptr, "sc_conv0_fwd: GroupNorm mode needs coef");
+    SC_CHECK_ARG(P >= T0 && B > 0 && B <= 65535, "sc_conv0_fwd: need P >= T0 and 0 < B <= 65535");
+    hipLaunchKernelGGL(conv0_fwd_kernel, dim3((P + TT - 1) / TT, B), dim3(256), 0, (hipStream_t)stream, wav, ld, L, w, bias, (const float2*)coef,
+                       (bf16_t*)out, C, T0, P, mode);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_posconv_pack(const void* x, const int32_t* valid, void* xg, int B, int Tp, int D, int G, int Kw, void* stream) {
+    SC_CHECK_ARG(D % G == 0 && (D / G) % 4 == 0, "sc_posconv_pack: D/G must be a multiple of 4");
+    SC_CHECK_ARG(B <= 65535 && G <= 65535, "sc_posconv_pack: grid limits");
+    hipLaunchKernelGGL(posconv_pack_kernel, dim3((Tp + Kw + 15) / 16, G, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, valid, (bf16_t*)xg, Tp,
+                       D, G, Kw);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_posconv_finish(const void* x, const int32_t* valid, const void* conv, const float* bias, const float* gamma, const float* beta,
+                                 void* out, int B, int Tp, int D, int G, int out_f32, float eps, void* stream) {
+    SC_CHECK_ARG(D <= 1024 && D % G == 0 && (D / G) % 4 == 0, "sc_posconv_finish: D<=1024 and D/G multiple of 4 required");
+    const int64_t rows = (int64_t)B * Tp;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (out_f32) hipLaunchKernelGGL((posconv_finish_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, valid, (const bf16_t*)conv, bias, gamma, beta, out, B, Tp, D, G, eps);
+    else hipLaunchKernelGGL((posconv_finish_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, valid, (const bf16_t*)conv, bias, gamma, beta, out, B, Tp, D, G, eps);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_vit_patchify(const float* img, void* cols, int B, int R, int p, int Kpad, void* stream) {
+    SC_CHECK_ARG(R % p == 0 && Kpad >= 3 * p * p && Kpad % 64 == 0, "sc_vit_patchify: R%%p==0 and Kpad>=3p^2, Kpad%%64==0 required");
+    const int np = (R / p) * (R / p);
+    hipLaunchKernelGGL(vit_patchify_kernel, dim3(B * np), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)cols, R, p, Kpad);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_vit_embed(const void* patch, const float* cls, const float* pos, const float* gamma, const float* beta, float* out, int B,
+                            int ntok, int D, float eps, void* stream) {
+    SC_CHECK_ARG(D <= 1024 && D % 4 == 0, "sc_vit_embed: D=%d must be a multiple of 4, <= 1024", D);
+    const int64_t rows = (int64_t)B * ntok;
+    hipLaunchKernelGGL(vit_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)patch, cls, pos, gamma, beta,
+                       out, rows, ntok, D, eps);
+    SC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,220 @@
+// Row-wise HBM-bound kernels: LayerNorm (+GELU), weighted layer sum, L2 normalise, wave layer-norm.
+// One 64-lane wave owns one row (D <= 1024); reductions are wave shuffles, loads are 8/16 B per lane.
+#include "common.h"
+#include "../../include/speechclip_hip.h"
+
+namespace {
+
+constexpr int MAXC = 4;  // D <= 1024: up to 4 chunks of 256 elements, 4 elements per lane per chunk
+
+template <bool IN_F32>
+__device__ __forceinline__ void load_row(const void* base, int64_t off, int D, int lane, float (&v)[MAXC][4]) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        int e = c * 256 + lane * 4;
+        if (e < D) {
+            if (IN_F32) {
+                f32x4_t t = *(const f32x4_t*)((const float*)base + off + e);
+                v[c][0] = t[0]; v[c][1] = t[1]; v[c][2] = t[2]; v[c][3] = t[3];
+            } else {
+                uint2 t = *(const uint2*)((const bf16_t*)base + off + e);
+                v[c][0] = lo2f(t.x); v[c][1] = hi2f(t.x); v[c][2] = lo2f(t.y); v[c][3] = hi2f(t.y);
+            }
+        } else {
+            v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void row_stats(const float (&v)[MAXC][4], int D, int lane, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        int e = c * 256 + lane * 4;
+        if (e < D) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { float d = v[c][i] - mean; q += d * d; }
+        }
+    }
+    rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+}
+
+// out = [gelu]( (x - mean) * rstd * gamma + beta )
+template <bool IN_F32, bool OUT_F32>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, int64_t ld_in, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, void* __restrict__ out, int64_t ld_out,
+                                                        int64_t rows, int D, float eps, int gelu) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[MAXC][4];
+    load_row<IN_F32>(x, row * ld_in, D, lane, v);
+    float mean, rstd;
+    row_stats(v, D, lane, eps, mean, rstd);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        int e = c * 256 + lane * 4;
+        if (e < D) {
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float y = (v[c][i] - mean) * rstd;
+                if (gamma) y = y * gamma[e + i] + beta[e + i];
+                o[i] = gelu ? gelu_erf(y) : y;
+            }
+            if (OUT_F32) {
+                *(f32x4_t*)((float*)out + row * ld_out + e) = (f32x4_t){o[0], o[1], o[2], o[3]};
+            } else {
+                uint2 p; p.x = pack2bf(o[0], o[1]); p.y = pack2bf(o[2], o[3]);
+                *(uint2*)((bf16_t*)out + row * ld_out + e) = p;
+            }
+        }
+    }
+}
+
+// out[m,:] = sum_i softmax(w)_i * (normalize ? LN_noaffine(h_i[m,:]) : h_i[m,:])
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void weighted_sum_kernel(const void* __restrict__ hidden, int64_t layer_stride, const float* __restrict__ w,
+                                                           void* __restrict__ out, int n, int64_t rows, int D, int normalize,
+                                                           float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float mx = -INFINITY;
+    for (int i = 0; i < n; ++i) mx = fmaxf(mx, w[i]);
+    float den = 0.f;
+    for (int i = 0; i < n; ++i) den += __expf(w[i] - mx);
+    float acc[MAXC][4];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float wi = __expf(w[i] - mx) / den;
+        float v[MAXC][4];
+        load_row<IN_F32>(hidden, (int64_t)i * layer_stride + row * D, D, lane, v);
+        if (normalize) {
+            float mean, rstd;
+            row_stats(v, D, lane, eps, mean, rstd);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[c][k] += wi * ((v[c][k] - mean) * rstd);
+        } else {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[c][k] += wi * v[c][k];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        int e = c * 256 + lane * 4;
+        if (e < D) {
+            uint2 p; p.x = pack2bf(acc[c][0], acc[c][1]); p.y = pack2bf(acc[c][2], acc[c][3]);
+            *(uint2*)((bf16_t*)out + row * D + e) = p;
+        }
+    }
+}
+
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void l2norm_kernel(const void* __restrict__ x, int64_t ld_in, float* __restrict__ out, int64_t rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[MAXC][4];
+    load_row<IN_F32>(x, row * ld_in, D, lane, v);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q += v[c][i] * v[c][i];
+    const float inv = 1.0f / sqrtf(wave_sum(q));  // no eps: kwClip.py:1436 divides by the plain norm
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        int e = c * 256 + lane * 4;
+        if (e < D) *(f32x4_t*)(out + row * D + e) = (f32x4_t){v[c][0] * inv, v[c][1] * inv, v[c][2] * inv, v[c][3] * inv};
+    }
+}
+
+// per-utterance F.layer_norm(wav[:len], (len,)) in place over the unpadded samples (eps 1e-5); pad stays 0.
+__global__ __launch_bounds__(1024) void wave_layernorm_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ lens,
+                                                              int64_t ld, float eps) {
+    __shared__ double red[2][16];
+    __shared__ float stat[2];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int len = lens[b];
+    const float* x = in + (int64_t)b * ld;
+    float* y = out + (int64_t)b * ld;
+    double s = 0.0;
+    for (int i = tid; i < len; i += 1024) s += (double)x[i];
+    s = wave_sum_d(s);
+    if (lane == 0) red[0][wv] = s;
+    __syncthreads();
+    if (tid == 0) { double t = 0; for (int i = 0; i < 16; ++i) t += red[0][i]; stat[0] = (float)(t / len); }
+    __syncthreads();
+    const float mean = stat[0];
+    double q = 0.0;
+    for (int i = tid; i < len; i += 1024) { double d = (double)x[i] - (double)mean; q += d * d; }
+    q = wave_sum_d(q);
+    if (lane == 0) red[1][wv] = q;
+    __syncthreads();
+    if (tid == 0) { double t = 0; for (int i = 0; i < 16; ++i) t += red[1][i]; stat[1] = rsqrtf((float)(t / len) + eps); }
+    __syncthreads();
+    const float rstd = stat[1];
+    for (int i = tid; i < ld; i += 1024) y[i] = i < len ? (x[i] - mean) * rstd : 0.f;
+}
+
+}  // namespace
+
+extern "C" int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, const float* beta, void* out, int64_t ld_out,
+                            int64_t rows, int D, float eps, int flags, void* stream) {
+    SC_CHECK_ARG(D > 0 && D <= 1024 && D % 4 == 0, "sc_layernorm: D=%d must be a multiple of 4, <= 1024", D);
+    SC_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "sc_layernorm: gamma and beta must both be given or both null");
+    SC_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0, "sc_layernorm: leading dims must be multiples of 4");
+    if (rows <= 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int gelu = (flags & SC_LN_GELU) ? 1 : 0;
+    const bool in32 = flags & SC_LN_IN_F32, out32 = flags & SC_LN_OUT_F32;
+    if (in32 && out32) hipLaunchKernelGGL((layernorm_kernel<true, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
+    else if (in32) hipLaunchKernelGGL((layernorm_kernel<true, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
+    else if (out32) hipLaunchKernelGGL((layernorm_kernel<false, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
+    else hipLaunchKernelGGL((layernorm_kernel<false, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_weighted_sum_fwd(const void* hidden, int64_t layer_stride, const float* weights, void* out, int n_layers,
+                                   int64_t rows, int D, int flags, float eps, void* stream) {
+    SC_CHECK_ARG(D > 0 && D <= 1024 && D % 4 == 0, "sc_weighted_sum: D=%d must be a multiple of 4, <= 1024", D);
+    SC_CHECK_ARG(n_layers > 0 && n_layers <= 64, "sc_weighted_sum: n_layers=%d out of range", n_layers);
+    if (rows <= 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int normalize = (flags & SC_WS_NORMALIZE) ? 1 : 0;
+    if (flags & SC_WS_IN_F32)
+        hipLaunchKernelGGL((weighted_sum_kernel<true>), grid, block, 0, (hipStream_t)stream, hidden, layer_stride, weights, out, n_layers, rows, D, normalize, eps);
+    else
+        hipLaunchKernelGGL((weighted_sum_kernel<false>), grid, block, 0, (hipStream_t)stream, hidden, layer_stride, weights, out, n_layers, rows, D, normalize, eps);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_l2norm_fwd(const void* x, int64_t ld_in, float* out, int64_t rows, int D, int in_f32, void* stream) {
+    SC_CHECK_ARG(D > 0 && D <= 1024 && D % 4 == 0, "sc_l2norm: D=%d must be a multiple of 4, <= 1024", D);
+    if (rows <= 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (in_f32) hipLaunchKernelGGL((l2norm_kernel<true>), grid, block, 0, (hipStream_t)stream, x, ld_in, out, rows, D);
+    else hipLaunchKernelGGL((l2norm_kernel<false>), grid, block, 0, (hipStream_t)stream, x, ld_in, out, rows, D);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_wave_layernorm(const float* wav, float* out, const int32_t* lens, int B, int64_t ld, float eps, void* stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(wave_layernorm_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, wav, out, lens, ld, eps);
+    SC_CHECK_LAUNCH();
+    return 0;
+}

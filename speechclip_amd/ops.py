@@ -40,3 +40,148 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     check(lib().sc_gemm_bf16(ptr(a), lda, ptr(w), w.stride(0), ptr(out), out.stride(-2), ptr(bias), ptr(residual),
                              residual.stride(-2) if residual is not None else 0, M, N, K, flags, stream()), "sc_gemm_bf16")
     return out
+
+
+def gemm_batched(a, lda, stride_a, w, stride_w, w_mod, out, ldc, stride_c, bias, M, N, K, batch, act=ACT_NONE):
+    _need_cuda(a, w, out)
+    check(lib().sc_gemm_bf16_batched(ptr(a), lda, stride_a, ptr(w), K, stride_w, w_mod, ptr(out), ldc, stride_c, ptr(bias),
+                                     M, N, K, batch, act, stream()), "sc_gemm_bf16_batched")
+    return out
+
+
+LN_IN_F32, LN_OUT_F32, LN_GELU = 1, 2, 4
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None, out_f32=False, gelu=False, rows=None, D=None, ld_in=None):
+    """Row LayerNorm.  x: [..., D] (bf16 or f32, last dim contiguous); optional strided-row view via rows/D/ld_in."""
+    _need_cuda(x)
+    if rows is None:
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D) if x.is_contiguous() else x
+        assert x2.dim() == 2 and x2.stride(1) == 1
+        rows, ld_in = x2.shape[0], x2.stride(0)
+        shape = x.shape
+    else:
+        shape = (rows, D)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32 if out_f32 else bf16)
+    flags = (LN_IN_F32 if x.dtype == torch.float32 else 0) | (LN_OUT_F32 if out.dtype == torch.float32 else 0) | (LN_GELU if gelu else 0)
+    assert x.dtype in (bf16, torch.float32)
+    check(lib().sc_layernorm(ptr(x), ld_in, ptr(gamma), ptr(beta), ptr(out), D, rows, D, eps, flags, stream()), "sc_layernorm")
+    return out
+
+
+def weighted_sum(hidden, weights, normalize=False, eps=1e-5):
+    """hidden: [n, rows, D] contiguous (bf16 or f32); weights f32 [n] (pre-softmax).  Returns bf16 [rows, D]."""
+    _need_cuda(hidden, weights)
+    n, rows, D = hidden.shape
+    assert hidden.is_contiguous() and weights.dtype == torch.float32
+    out = torch.empty(rows, D, device=hidden.device, dtype=bf16)
+    flags = (1 if normalize else 0) | (2 if hidden.dtype == torch.float32 else 0)
+    check(lib().sc_weighted_sum_fwd(ptr(hidden), rows * D, ptr(weights), ptr(out), n, rows, D, flags, eps, stream()), "sc_weighted_sum_fwd")
+    return out
+
+
+def l2norm(x):
+    _need_cuda(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(lib().sc_l2norm_fwd(ptr(x), x.stride(0), ptr(out), x.shape[0], x.shape[1], int(x.dtype == torch.float32), stream()), "sc_l2norm_fwd")
+    return out
+
+
+def wave_layernorm(wav, lens_i32, eps=1e-5):
+    _need_cuda(wav, lens_i32)
+    assert wav.dtype == torch.float32 and wav.is_contiguous() and lens_i32.dtype == torch.int32
+    out = torch.empty_like(wav)
+    check(lib().sc_wave_layernorm(ptr(wav), ptr(out), ptr(lens_i32), wav.shape[0], wav.shape[1], eps, stream()), "sc_wave_layernorm")
+    return out
+
+
+def attention(qkv, B, T, H, klens_i32=None, out=None, scale=None):
+    """qkv: bf16 [B*T, 3*H*64] packed (q|k|v); returns bf16 [B*T, H*64]."""
+    _need_cuda(qkv)
+    D = H * 64
+    assert qkv.dtype == bf16 and qkv.shape == (B * T, 3 * D) and qkv.is_contiguous()
+    if out is None:
+        out = torch.empty(B * T, D, device=qkv.device, dtype=bf16)
+    esz = 2
+    check(lib().sc_attention_fwd(qkv.data_ptr(), qkv.data_ptr() + D * esz, qkv.data_ptr() + 2 * D * esz, ptr(out), ptr(klens_i32),
+                                 B, H, T, 64, 3 * D, D, 0.125 if scale is None else scale, stream()), "sc_attention_fwd")
+    return out
+
+
+def cls_attention(cls_qkv, kv_x, lens_i32, B, T, NQ, H, hd):
+    """cls_qkv bf16 [NQ, 3D]; kv_x bf16 [B*T, 2D]; returns bf16 [B, NQ, D]."""
+    _need_cuda(cls_qkv, kv_x)
+    D = H * hd
+    assert cls_qkv.shape == (NQ, 3 * D) and kv_x.shape == (B * T, 2 * D) and cls_qkv.is_contiguous() and kv_x.is_contiguous()
+    out = torch.empty(B, NQ, D, device=kv_x.device, dtype=bf16)
+    check(lib().sc_cls_attention_fwd(ptr(cls_qkv), ptr(kv_x), 2 * D, ptr(lens_i32), ptr(out), B, T, NQ, H, hd, hd ** -0.5, stream()),
+          "sc_cls_attention_fwd")
+    return out
+
+
+def conv0(wav, w, T0, P, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5):
+    """HuBERT conv layer 0.  wav f32 [B, L]; w f32 [C, 10].  GroupNorm+GELU if gn_gamma given, else raw conv + bias.
+    Returns channels-last bf16 [B, P, C] (+ (k-s) slack rows so the next conv-as-GEMM may over-read)."""
+    _need_cuda(wav, w)
+    B, L = wav.shape
+    C = w.shape[0]
+    assert wav.dtype == torch.float32 and wav.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
+    buf = torch.zeros(B * P + 8, C, device=wav.device, dtype=bf16)
+    if gn_gamma is not None:
+        ws = torch.empty(lib().sc_conv0_stats_workspace_bytes(B), device=wav.device, dtype=torch.uint8)
+        coef = torch.empty(B, C, 2, device=wav.device, dtype=torch.float32)
+        check(lib().sc_conv0_gn_coef(ptr(wav), L, ptr(w), ptr(gn_gamma), ptr(gn_beta), ptr(ws), ptr(coef), B, C, T0, eps, stream()), "sc_conv0_gn_coef")
+        check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), None, ptr(coef), ptr(buf), B, C, T0, P, 0, stream()), "sc_conv0_fwd")
+    else:
+        check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), ptr(bias), None, ptr(buf), B, C, T0, P, 1, stream()), "sc_conv0_fwd")
+    return buf
+
+
+def posconv(x, valid_i32, wg, bias, gamma, beta, B, Tp, D, G, Kw, out=None, out_f32=False, eps=1e-5):
+    """x bf16 [B*Tp, D]; wg bf16 [G, D/G, Kw*D/G] (folded weight-norm, K index = tap*cg + c_in)."""
+    _need_cuda(x, wg)
+    cg = D // G
+    xg = torch.empty(B * G * (Tp + Kw) * cg + 64, device=x.device, dtype=bf16)
+    check(lib().sc_posconv_pack(ptr(x), ptr(valid_i32), ptr(xg), B, Tp, D, G, Kw, stream()), "sc_posconv_pack")
+    conv = torch.empty(B * G * Tp * cg, device=x.device, dtype=bf16)
+    gemm_batched(xg, cg, (Tp + Kw) * cg, wg, cg * Kw * cg, G, conv, cg, Tp * cg, None, Tp, cg, Kw * cg, B * G)
+    if out is None:
+        out = torch.empty(B * Tp, D, device=x.device, dtype=torch.float32 if out_f32 else bf16)
+    check(lib().sc_posconv_finish(ptr(x), ptr(valid_i32), ptr(conv), ptr(bias), ptr(gamma), ptr(beta), ptr(out), B, Tp, D, G,
+                                  int(out.dtype == torch.float32), eps, stream()), "sc_posconv_finish")
+    return out
+
+
+def vit_patchify(img, p, Kpad):
+    _need_cuda(img)
+    B, C, R, _ = img.shape
+    assert C == 3 and img.dtype == torch.float32 and img.is_contiguous()
+    npatch = (R // p) ** 2
+    cols = torch.empty(B * npatch, Kpad, device=img.device, dtype=bf16)
+    check(lib().sc_vit_patchify(ptr(img), ptr(cols), B, R, p, Kpad, stream()), "sc_vit_patchify")
+    return cols
+
+
+def vit_embed(patch, cls, pos, gamma, beta, B, ntok, D, eps=1e-5):
+    out = torch.empty(B * ntok, D, device=patch.device, dtype=torch.float32)
+    check(lib().sc_vit_embed(ptr(patch), ptr(cls), ptr(pos), ptr(gamma), ptr(beta), ptr(out), B, ntok, D, eps, stream()), "sc_vit_embed")
+    return out
+
+
+def infonce(feat_a, feat_b, ids=None, inv_temperature=1.0 / 0.07, margin=0.0, dcl=False, a2b=True, b2a=True):
+    """Returns f32[3] device tensor: (loss, a2b term, b2a term)."""
+    _need_cuda(feat_a, feat_b)
+    assert feat_a.shape == feat_b.shape and feat_a.dtype == torch.float32 and feat_b.dtype == torch.float32
+    feat_a, feat_b = feat_a.contiguous(), feat_b.contiguous()
+    Bg, E = feat_a.shape
+    if ids is not None:
+        assert ids.dtype == torch.int64 and ids.shape[0] == Bg
+        ids = ids.contiguous()
+    ws = torch.empty(lib().sc_infonce_workspace_bytes(Bg), device=feat_a.device, dtype=torch.uint8)
+    out = torch.empty(3, device=feat_a.device, dtype=torch.float32)
+    check(lib().sc_infonce_fwd(ptr(feat_a), ptr(feat_b), ptr(ids), ptr(ws), ptr(out), Bg, E, inv_temperature, margin, int(dcl), int(a2b),
+                               int(b2a), stream()), "sc_infonce_fwd")
+    return out

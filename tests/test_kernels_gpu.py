@@ -1,0 +1,219 @@
+"""GPU parity of the individual HIP kernels against plain torch fp32 references on the same inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("D", [64, 512, 768, 1024])
+@pytest.mark.parametrize("in_f32,out_f32,gelu,affine", [(False, False, False, True), (True, False, False, True),
+                                                        (False, True, True, True), (True, True, False, False)])
+def test_layernorm(D, in_f32, out_f32, gelu, affine):
+    from speechclip_amd import ops
+    g = _g(D)
+    x = (torch.randn(37, D, generator=g) * 2 + 0.5)
+    x = x.cuda() if in_f32 else x.to("cuda", BF)
+    gamma = (1 + 0.3 * torch.randn(D, generator=g)).cuda() if affine else None
+    beta = (0.3 * torch.randn(D, generator=g)).cuda() if affine else None
+    y = ops.layernorm(x, gamma, beta, out_f32=out_f32, gelu=gelu)
+    ref = F.layer_norm(x.float(), (D,), gamma, beta, 1e-5)
+    if gelu:
+        ref = F.gelu(ref)
+    tol = 1e-4 if out_f32 else 2e-2
+    torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)
+
+
+def test_layernorm_strided_rows():
+    from speechclip_amd import ops
+    x = torch.randn(6, 5, 768, generator=_g(1)).cuda()
+    gamma, beta = torch.ones(768).cuda(), torch.zeros(768).cuda()
+    y = ops.layernorm(x, gamma, beta, out_f32=True, rows=6, D=768, ld_in=5 * 768)  # token 0 of each sequence
+    torch.testing.assert_close(y, F.layer_norm(x[:, 0], (768,)), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("n,normalize,f32", [(13, False, False), (25, True, False), (25, True, True)])
+def test_weighted_sum(n, normalize, f32):
+    from speechclip_amd import ops
+    g = _g(n)
+    h = torch.randn(n, 50, 768, generator=g)
+    h = h.cuda() if f32 else h.to("cuda", BF)
+    w = torch.randn(n, generator=g).cuda()
+    y = ops.weighted_sum(h, w, normalize)
+    hf = h.float()
+    if normalize:
+        hf = F.layer_norm(hf, (768,))
+    ref = (torch.softmax(w, 0).view(-1, 1, 1) * hf).sum(0)
+    torch.testing.assert_close(y.float(), ref, atol=1e-2, rtol=1e-2)
+
+
+def test_l2norm_and_wave_layernorm():
+    from speechclip_amd import ops
+    x = torch.randn(33, 512, generator=_g(2)).cuda()
+    torch.testing.assert_close(ops.l2norm(x), x / x.norm(dim=-1, keepdim=True), atol=1e-6, rtol=1e-5)
+    xb = x.to(BF)
+    torch.testing.assert_close(ops.l2norm(xb), xb.float() / xb.float().norm(dim=-1, keepdim=True), atol=1e-6, rtol=1e-5)
+    wav = torch.randn(3, 5000, generator=_g(3)) * 0.1 + 0.02
+    lens = torch.tensor([5000, 1234, 1], dtype=torch.int32)
+    for i, l in enumerate(lens):
+        wav[i, l:] = 0
+    y = ops.wave_layernorm(wav.cuda(), lens.cuda())
+    for i, l in enumerate(lens.tolist()):
+        ref = F.layer_norm(wav[i, :l], (l,))
+        torch.testing.assert_close(y[i, :l].cpu(), ref, atol=2e-5, rtol=1e-4)
+        assert torch.all(y[i, l:] == 0)
+
+
+def _attn_ref(qkv, B, T, H, klens):
+    D = H * 64
+    q, k, v = (qkv.float().view(B, T, 3, H, 64)[:, :, i].transpose(1, 2) for i in range(3))
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if klens is not None:
+        mask = torch.arange(T, device=qkv.device)[None, :] >= klens[:, None]
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * T, D)
+
+
+@pytest.mark.parametrize("B,T,H,lens", [(2, 50, 12, None), (3, 500, 12, [500, 499, 37]), (2, 129, 2, [1, 64]),
+                                        (1, 64, 1, [64]), (2, 319, 16, [319, 65])])
+def test_flash_attention(B, T, H, lens):
+    from speechclip_amd import ops
+    g = _g(T + H)
+    qkv = (torch.randn(B * T, 3 * H * 64, generator=g)).to("cuda", BF)
+    klens = torch.tensor(lens, dtype=torch.int32, device="cuda") if lens is not None else None
+    y = ops.attention(qkv, B, T, H, klens)
+    ref = _attn_ref(qkv, B, T, H, klens)
+    torch.testing.assert_close(y.float(), ref, atol=2e-2, rtol=2e-2)
+
+
+def test_flash_attention_online_softmax_rescale():
+    """Force a late, much larger score so the running max jumps at the last tile (rule 26)."""
+    from speechclip_amd import ops
+    B, T, H = 1, 256, 1
+    g = _g(9)
+    qkv = (torch.randn(B * T, 192, generator=g) * 0.5)
+    qkv[:, 0:64][5] = 4.0                 # query 5
+    qkv[:, 64:128][250] = 4.0             # key 250 -> q.k * 0.125 = 128 >> others
+    qkv = qkv.to("cuda", BF)
+    y = ops.attention(qkv, B, T, H, None)
+    torch.testing.assert_close(y.float(), _attn_ref(qkv, B, T, H, None), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("NQ,H,hd,T", [(1, 8, 96, 499), (8, 1, 768, 499), (1, 4, 16, 24), (8, 1, 64, 24)])
+def test_cls_attention(NQ, H, hd, T):
+    from speechclip_amd import ops
+    B, D = 3, H * hd
+    g = _g(NQ + hd)
+    cls_qkv = torch.randn(NQ, 3 * D, generator=g).to("cuda", BF)
+    kv = torch.randn(B * T, 2 * D, generator=g).to("cuda", BF)
+    lens = torch.tensor([T, 1, T // 2], dtype=torch.int32, device="cuda")
+    y = ops.cls_attention(cls_qkv, kv, lens, B, T, NQ, H, hd)
+    cq = cls_qkv.float()
+    ref = torch.zeros(B, NQ, D, device="cuda")
+    for b in range(B):
+        L = int(lens[b])
+        k = torch.cat([cq[:, D:2 * D], kv[b * T:b * T + L, :D].float()], 0).view(-1, H, hd)
+        v = torch.cat([cq[:, 2 * D:], kv[b * T:b * T + L, D:].float()], 0).view(-1, H, hd)
+        q = cq[:, :D].view(NQ, H, hd)
+        s = torch.einsum("qhd,khd->hqk", q, k) * hd ** -0.5
+        ref[b] = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), v).reshape(NQ, D)
+    torch.testing.assert_close(y.float(), ref, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("C,L", [(512, 16000), (32, 8000), (512, 4000)])
+def test_conv0_groupnorm_gelu(C, L):
+    from speechclip_amd import ops
+    g = _g(C + L)
+    B = 3
+    wav = torch.randn(B, L, generator=g) * 0.2 + 0.01
+    wav[1, L // 2:] = 0
+    w = torch.randn(C, 10, generator=g) * 0.4
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    T0 = (L - 10) // 5 + 1
+    P = (T0 + 63) // 64 * 64
+    y = ops.conv0(wav.cuda(), w.cuda(), T0, P, gamma.cuda(), beta.cuda())[: B * P].view(B, P, C)
+    ref = F.gelu(F.group_norm(F.conv1d(wav[:, None], w[:, None], stride=5), C, gamma, beta, 1e-5)).transpose(1, 2)
+    torch.testing.assert_close(y[:, :T0].float().cpu(), ref, atol=2e-2, rtol=2e-2)
+    assert torch.all(y[:, T0:] == 0)
+
+
+def test_conv0_raw_bias():
+    from speechclip_amd import ops
+    g = _g(5)
+    B, L, C = 2, 6000, 32
+    wav, w, bias = torch.randn(B, L, generator=g), torch.randn(C, 10, generator=g) * 0.3, torch.randn(C, generator=g)
+    T0 = (L - 10) // 5 + 1
+    P = (T0 + 63) // 64 * 64
+    y = ops.conv0(wav.cuda(), w.cuda(), T0, P, bias=bias.cuda())[: B * P].view(B, P, C)
+    ref = F.conv1d(wav[:, None], w[:, None], bias, stride=5).transpose(1, 2)
+    torch.testing.assert_close(y[:, :T0].float().cpu(), ref, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("D,G,Kw,Tp,ln", [(768, 16, 128, 500, True), (64, 4, 16, 30, True), (1024, 16, 128, 70, False)])
+def test_posconv(D, G, Kw, Tp, ln):
+    from speechclip_amd import ops
+    g = _g(D + Tp)
+    B, cg = 2, D // G
+    x = torch.randn(B, Tp, D, generator=g).to(BF)
+    valid = torch.tensor([Tp - 1, max(1, Tp // 3)], dtype=torch.int32)
+    w = (torch.randn(D, cg, Kw, generator=g) * math.sqrt(4.0 / (Kw * D)) * 3).to(BF)   # [out, in/groups, k]
+    bias = torch.randn(D, generator=g) * 0.1
+    gamma, beta = (1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)) if ln else (None, None)
+    wg = w.float().view(G, cg, cg, Kw).permute(0, 1, 3, 2).reshape(G, cg, Kw * cg).contiguous().to("cuda", BF)
+    y = ops.posconv(x.cuda().view(B * Tp, D), valid.cuda(), wg, bias.cuda(), gamma.cuda() if ln else None,
+                    beta.cuda() if ln else None, B, Tp, D, G, Kw, out_f32=not ln)
+    xm = x.float().clone()
+    for b in range(B):
+        xm[b, valid[b]:] = 0
+    conv = F.conv1d(xm.transpose(1, 2), w.float(), bias, padding=Kw // 2, groups=G)[:, :, :Tp].transpose(1, 2)
+    ref = xm + F.gelu(conv)
+    if ln:
+        ref = F.layer_norm(ref, (D,), gamma, beta, 1e-5)
+    torch.testing.assert_close(y.float().cpu().view(B, Tp, D), ref, atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("R,p,W", [(224, 32, 768), (64, 16, 128), (224, 14, 1024)])
+def test_vit_stem(R, p, W):
+    from speechclip_amd import ops
+    g = _g(R + p)
+    B = 2
+    img = torch.randn(B, 3, R, R, generator=g)
+    wc = (torch.randn(W, 3, p, p, generator=g) * (3 * p * p) ** -0.5).to(BF)
+    cls, pos = torch.randn(W, generator=g) * 0.1, torch.randn((R // p) ** 2 + 1, W, generator=g) * 0.1
+    gamma, beta = 1 + 0.1 * torch.randn(W, generator=g), 0.1 * torch.randn(W, generator=g)
+    K = 3 * p * p
+    Kpad = (K + 63) // 64 * 64
+    cols = ops.vit_patchify(img.cuda(), p, Kpad)
+    w2 = torch.zeros(W, Kpad, dtype=BF)
+    w2[:, :K] = wc.view(W, K)
+    patch = ops.gemm(cols, w2.cuda())
+    ntok = (R // p) ** 2 + 1
+    y = ops.vit_embed(patch, cls.cuda(), pos.cuda(), gamma.cuda(), beta.cuda(), B, ntok, W)
+    conv = F.conv2d(img.to(BF).float(), wc.float(), stride=p).reshape(B, W, -1).permute(0, 2, 1)
+    tok = torch.cat([cls.expand(B, 1, W), conv], 1) + pos
+    ref = F.layer_norm(tok, (W,), gamma, beta, 1e-5)
+    torch.testing.assert_close(y.cpu().view(B, ntok, W), ref, atol=3e-2, rtol=3e-2)
+
+
+def test_infonce_golden():
+    """C-ABI loss against the reference's own MaskedContrastiveLoss outputs (tests/golden/loss.npz)."""
+    import os
+    from speechclip_amd import ops
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss.npz"))
+    a, b = torch.from_numpy(gold["anchor_a"]).cuda(), torch.from_numpy(gold["anchor_b"]).cuda()
+    lu = ops.infonce(a, b, torch.from_numpy(gold["anchor_ids_u"]).cuda())[0].item()
+    ld = ops.infonce(a, b, torch.from_numpy(gold["anchor_ids_d"]).cuda())[0].item()
+    assert abs(lu - 2.978872299194336) < 1e-4 and abs(ld - 2.9537737369537354) < 1e-4
+    for B, E, margin, dcl, a2b, b2a, inv_t, use_ids, val in gold["cases"]:
+        B = int(B)
+        fa, fb, ids = (torch.from_numpy(gold[f"{k}_{B}"]).cuda() for k in ("fa", "fb", "ids"))
+        mine = ops.infonce(fa, fb, ids if use_ids else None, inv_t, margin, bool(dcl), bool(a2b), bool(b2a))[0].item()
+        assert abs(mine - val) < 1e-4 * max(1.0, abs(val)), (B, margin, dcl, a2b, b2a, val, mine)
