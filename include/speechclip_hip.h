@@ -90,9 +90,10 @@ int sc_wave_layernorm(const float* wav, float* out, const int32_t* lens, int B, 
  * q/k/v point at the first head's columns of row 0; rows are (b*T + t) with stride ld_qkv; head h
  * is at column offset h*64.  Replaces fairseq MultiheadAttention (key_padding_mask -> -inf) inside
  * TransformerSentenceEncoderLayer (speech_encoder_plus.py:52) and CLIP's nn.MultiheadAttention
- * in ResidualAttentionBlock (clip_official.py:209).  out: bf16 [B*T, H*64] rows of stride ld_out. */
+ * in ResidualAttentionBlock (clip_official.py:209; causal != 0 adds the text tower's build_attention_mask,
+ * clip_official.py:249-262).  out: bf16 [B*T, H*64] rows of stride ld_out. */
 int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H,
-                     int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, void* stream);
+                     int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, int causal, void* stream);
 
 /* CLS-rows-only attention of the pooling heads (kwClip.py:1089-1099 parallel, :869-881 cascaded):
  * NQ learned query tokens attend to [NQ CLS tokens ; frames t < lens[b]].  cls_qkv: bf16 [NQ, 3*D]
@@ -132,6 +133,21 @@ int sc_vit_embed(const void* patch, const float* cls, const float* pos, const fl
 int64_t sc_infonce_workspace_bytes(int Bg);
 int sc_infonce_fwd(const float* feat_a, const float* feat_b, const int64_t* ids, void* workspace, float* out3, int Bg, int E,
                    float inv_temperature, float margin, int dcl, int a2b, int b2a, void* stream);
+
+/* ---- Cascaded-branch extras (fp32) -- avssl/model/kwClip.py:883-909 -------------------------------
+ * sc_kw_affine: eval-mode Kw_BatchNorm (kw_bn.py:122-131) as out[r,d] = x[r,d]*scale[r%K,d] + shift[r%K,d].
+ * sc_cosine_scores: F.cosine_similarity of every keyword against every sub-word embedding (kwClip.py:889-898):
+ *   out[r,v] = a_r . e_v / (max(|a_r|,eps) max(|e_v|,eps)), a f32 [R,E], emb f32 [V,E], out f32 [R,V].
+ * sc_vq_fwd: SimpleVectorQuantizer eval path (my_vector_quantizer.py:64-165): ids in host_mask_ids get -inf,
+ *   targets[r] = arg-max, stats2 = {code_perplexity, prob_perplexity}, ent_per_t[k] (K keywords; rows r = b*K + k).
+ * sc_gather_rows: out[r,:] = src[idx[r],:]  (one-hot @ E, kwClip.py:909). */
+int sc_kw_affine(const float* x, const float* scale, const float* shift, float* out, int64_t rows, int K, int D, void* stream);
+int64_t sc_cosine_workspace_bytes(int R, int V);
+int sc_cosine_scores(const float* a, const float* emb, void* workspace, float* out, int R, int V, int E, float eps, void* stream);
+int64_t sc_vq_workspace_bytes(int R, int V);
+int sc_vq_fwd(const float* scores, int64_t* targets, float* stats2, float* ent_per_t, void* workspace, int R, int K, int V,
+              const int32_t* host_mask_ids, int n_mask, void* stream);
+int sc_gather_rows(const float* src, const int64_t* idx, float* out, int R, int E, void* stream);
 
 #ifdef __cplusplus
 }

@@ -52,10 +52,11 @@ class HubertRefConfig:
 
     @staticmethod
     def tiny(layer_norm_first=False, extractor_mode="default", conv_bias=False):
+        # smallest shape the MI355X kernels accept: head_dim 64, conv K = k*C a multiple of 64
         return HubertRefConfig(extractor_mode=extractor_mode, conv_bias=conv_bias,
-                               conv_layers=[(32, 10, 5)] + [(32, 3, 2)] * 4 + [(32, 2, 2)] * 2,
-                               encoder_layers=2, encoder_embed_dim=64, encoder_ffn_embed_dim=128,
-                               encoder_attention_heads=4, layer_norm_first=layer_norm_first,
+                               conv_layers=[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)] * 2,
+                               encoder_layers=2, encoder_embed_dim=128, encoder_ffn_embed_dim=256,
+                               encoder_attention_heads=2, layer_norm_first=layer_norm_first,
                                conv_pos=16, conv_pos_groups=4, normalize=layer_norm_first)
 
 

@@ -45,7 +45,7 @@ def _declare(L):
         "sc_weighted_sum_fwd": ([P, L64, P, P, I, L64, I, I, F, P], c_int),
         "sc_l2norm_fwd": ([P, L64, P, L64, I, I, P], c_int),
         "sc_wave_layernorm": ([P, P, P, I, L64, F, P], c_int),
-        "sc_attention_fwd": ([P, P, P, P, P, I, I, I, I, L64, L64, F, P], c_int),
+        "sc_attention_fwd": ([P, P, P, P, P, I, I, I, I, L64, L64, F, I, P], c_int),
         "sc_cls_attention_fwd": ([P, P, L64, P, P, I, I, I, I, I, F, P], c_int),
         "sc_conv0_stats_workspace_bytes": ([I], c_int64),
         "sc_conv0_gn_coef": ([P, L64, P, P, P, P, P, I, I, I, F, P], c_int),
@@ -56,6 +56,12 @@ def _declare(L):
         "sc_vit_embed": ([P, P, P, P, P, P, I, I, I, F, P], c_int),
         "sc_infonce_workspace_bytes": ([I], c_int64),
         "sc_infonce_fwd": ([P, P, P, P, P, I, I, F, F, I, I, I, P], c_int),
+        "sc_kw_affine": ([P, P, P, P, L64, I, I, P], c_int),
+        "sc_cosine_workspace_bytes": ([I, I], c_int64),
+        "sc_cosine_scores": ([P, P, P, P, I, I, I, F, P], c_int),
+        "sc_vq_workspace_bytes": ([I, I], c_int64),
+        "sc_vq_fwd": ([P, P, P, P, P, I, I, I, P, I, P], c_int),
+        "sc_gather_rows": ([P, P, P, I, I, P], c_int),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(L, name)   # AttributeError here = header/library mismatch: fail loudly

@@ -28,7 +28,7 @@ constexpr int VT_TILE_BYTES = 64 * VT_STRIDE;
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
                                                        const int32_t* __restrict__ klens, int T, int64_t ld_qkv,
-                                                       int64_t ld_out, float scale_log2e) {
+                                                       int64_t ld_out, float scale_log2e, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kbuf = smem;                       // 2 x 8 KiB
     char* Vbuf = smem + 2 * K_TILE_BYTES;    // 2 x 8.5 KiB
@@ -42,7 +42,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
     int klen = klens ? klens[b] : T;
     klen = klen < 0 ? 0 : (klen > T ? T : klen);
-    const int nkv = (klen + KV - 1) / KV;
+    int nkv = (klen + KV - 1) / KV;
+    if (causal) {  // keys beyond the block's last query are never needed
+        const int last_q = min(T, (int)blockIdx.x * 128 + 128);
+        nkv = min(nkv, (last_q + KV - 1) / KV);
+    }
 
     const int qrow = blockIdx.x * 128 + wave * 32 + ql;
     const int qrow_c = qrow < T ? qrow : T - 1;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                 float t = s[kb][r] * scale_log2e;
-                t = key < klen ? t : -INFINITY;
+                t = (key < klen && (!causal || key <= qrow)) ? t : -INFINITY;
                 s[kb][r] = t;
                 mx = fmaxf(mx, t);
             }
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict_
 }  // namespace
 
 extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H,
-                                int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, void* stream) {
+                                int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, int causal, void* stream) {
     SC_CHECK_ARG(head_dim == 64, "sc_attention_fwd: head_dim=%d unsupported (64 only; use sc_cls_attention_fwd for pooling heads)", head_dim);
     SC_CHECK_ARG(ld_qkv % 8 == 0 && ld_out % 4 == 0, "sc_attention_fwd: ld_qkv must be a multiple of 8, ld_out of 4");
     SC_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "sc_attention_fwd: misaligned pointers");
@@ -284,7 +288,7 @@ extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, voi
     if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
     dim3 grid((T + 127) / 128, H, B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f);
+                       (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal);
     SC_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,334 @@
+"""SpeechCLIP model layer on MI355X -- the `avssl.model` plugin surface.
+
+Mirrors the reference's class names, constructor (`config: OrderedNamespace`), hook protocol and output tuple layout
+(avssl/model/kwClip.py:49-1497, avssl/model/base_model.py:10-26) so that task code written against the reference
+(`run_task.py`, `example.py`, Lightning's training/validation hooks) runs unchanged, while every tensor op of
+the forward / contrastive path executes in libspeechclip_hip.so.
+
+Multi-GPU: the reference runs single-process `nn.DataParallel` and computes the loss on device 0 after DP's gather
+(`training_step_end`, kwClip.py:147-191).  Here there is one process per GPU; `*_step_end` all-gathers the per-rank
+feature dicts over RCCL (speechclip_amd/parallel.py) in rank-major order (= DP's dim-0 concat order) and every rank
+evaluates the loss on the global batch.
+"""
+import logging
+from typing import List, Tuple, Union
+
+import torch
+from torch import nn
+
+from .. import ops, parallel
+from ..base import OrderedNamespace
+from ..module import ClipModel, FairseqSpeechEncoder_Hubert, MLPLayers, S3prlSpeechEncoderPlus, losses, mutualRetrieval
+from ..module.kw_modules import TransformerModels
+from ..module.speechclip_c_modules import vector_quantizers
+from ..module.speechclip_c_modules.kw_bn import Kw_BatchNorm
+from ..optim import get_scheduler
+from ..util import get_keypadding_mask  # noqa: F401  (re-exported name used by downstream code)
+from .base_model import BaseLightningModel
+
+logger = logging.getLogger(__name__)
+__all__ = ["KWClip_GeneralTransformer"]
+
+# reduction applied to each logged metric gathered from the replicas (kwClip.py:41-46)
+METRIC_REDUCEFN_MAPPING = {torch.Tensor: lambda x: torch.mean(x), float: lambda x: x, int: lambda x: x, str: lambda x: x}
+
+
+class KWClipBase(BaseLightningModel):
+    def __init__(self, config: OrderedNamespace):
+        super().__init__(config)
+        self.audio_encoder_type = config.audio_encoder.type
+        if self.audio_encoder_type == "s3prl_plus":
+            self.audio_encoder = S3prlSpeechEncoderPlus(**config.audio_encoder)
+        elif self.audio_encoder_type == "FairseqHubert":
+            self.audio_encoder = FairseqSpeechEncoder_Hubert(**config.audio_encoder)
+        elif self.audio_encoder_type == "s3prl":
+            raise DeprecationWarning("Please use s3prl_plus")
+        else:
+            logger.warning("No audio encoder loaded")
+        self.clip = ClipModel(**config.clip)
+        if hasattr(self, "audio_encoder"):
+            self.audio_embd_dim = self.audio_encoder.out_dim
+        self.subword_embd_dim = self.clip.model.token_embedding.weight.size(-1)
+        self.recall_at = config.retrieval.recall_at
+        self.criterion = getattr(losses, config.cl_loss.type)(**config.cl_loss.args)
+        self.log_detokenize_results = config.log_setting.get("log_detokenize_results", True)
+        self.keyword_num = self.config.model_settings.cascaded_branch.keyword.number
+
+    # ---- encoders -------------------------------------------------------------------------------------
+    def forward_audio(self, wav, wav_len=[], return_hidden_states: bool = False):
+        if self.audio_encoder_type in ["s3prl_plus", "FairseqHubert"]:
+            return self.audio_encoder(wav, wav_len, return_hidden_states=return_hidden_states)
+        raise NotImplementedError("Unknown type:{}".format(self.audio_encoder_type))
+
+    def forward_image(self, images: Union[list, torch.Tensor]) -> torch.Tensor:
+        if isinstance(images, list):
+            raise NotImplementedError("image files -> tensors is data-layer work (avssl/data, out of scope); pass a [B,3,H,W] tensor")
+        if not isinstance(images, torch.Tensor):
+            raise TypeError(f"Unknown image type {type(images)}")
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"Incorrect image tensor shape {images.shape}")
+        return self.clip.encode_image(images)
+
+    def forward(self, batch: dict) -> tuple:
+        raise NotImplementedError()
+
+    def compute_loss(self, input_feats):
+        raise NotImplementedError()
+
+    # ---- Lightning hook protocol --------------------------------------------------------------------------
+    def training_step(self, batch: dict, batch_idx: int = 0) -> dict:
+        loss_feats, log_metrics = self.forward(batch)[:2]
+        return {"loss_feats": loss_feats, "log_metrics": log_metrics}
+
+    def _reduce_metrics(self, prefix, losses_, log_metrics):
+        out = {f"{prefix}_{k}": losses_[k] for k in losses_}
+        out.update({f"{prefix}_{k}": METRIC_REDUCEFN_MAPPING[type(log_metrics[k])](log_metrics[k]) for k in log_metrics})
+        return out
+
+    def training_step_end(self, outputs: dict) -> dict:
+        if not isinstance(outputs, dict):
+            raise NotImplementedError()
+        if "loss" in outputs:
+            return {"loss": torch.mean(outputs["loss"])}
+        if "loss_feats" in outputs and "log_metrics" in outputs:
+            losses_ = self.compute_loss(parallel.gather_loss_feats(outputs["loss_feats"]))
+            self.log_dict(self._reduce_metrics("train", losses_, outputs["log_metrics"]), on_step=True, on_epoch=True,
+                          prog_bar=True, logger=True, sync_dist=True)
+            return {"loss": losses_["loss"]}
+        raise NotImplementedError()
+
+    def validation_step(self, batch: dict, batch_idx: int = 0) -> dict:
+        loss_feats, log_metrics, others = self.forward(batch)
+        audio_feat = others["cascaded_audio_feat"] if self.config.retrieval.audio_feat_src == "cascaded" else others["parallel_audio_feat"]
+        ret = {"id": others["id"], "audio_feat": audio_feat}
+        if others.get("image_feat") is not None:
+            ret["image_feat"] = others["image_feat"]
+        if others.get("text_feat") is not None:
+            ret["text_feat"] = others["text_feat"]
+        if others.get("keywords") is not None:
+            ret["keywords"] = others["keywords"]
+            ret["gold_text"] = batch.get("text")
+        return {"loss_feats": loss_feats, "log_metrics": log_metrics, "others": ret}
+
+    def validation_step_end(self, outputs: dict) -> dict:
+        assert isinstance(outputs, dict)
+        losses_ = self.compute_loss(parallel.gather_loss_feats(outputs["loss_feats"]))
+        self.log_dict(self._reduce_metrics("val", losses_, outputs["log_metrics"]), on_step=True, on_epoch=True, prog_bar=True,
+                      logger=True, sync_dist=True)
+        others = outputs["others"]
+        for k in others:
+            if isinstance(others[k], torch.Tensor):
+                others[k] = others[k].detach().cpu()
+        return others
+
+    def validation_epoch_end(self, outputs: list):
+        """Retrieval half of kwClip.py:468-502 (keyword de-tokenisation logging :277-466 is analysis-only, out of scope)."""
+        all_ids = torch.cat([x["id"] for x in outputs], dim=0)
+        all_imgs = torch.cat([x["image_feat"] for x in outputs], dim=0)
+        first = {}
+        for i, _id in enumerate(all_ids.tolist()):       # last occurrence wins, first-seen order (dict semantics)
+            first[_id] = i
+        img_ids = torch.tensor(list(first.keys()), dtype=torch.long)
+        img_feats = all_imgs[torch.tensor(list(first.values()), dtype=torch.long)]
+        aud_feats = torch.cat([x["audio_feat"] for x in outputs], dim=0)
+        print("Total #{} images, #{} audio".format(len(img_feats), len(aud_feats)))
+        dev = self.device
+        score = torch.matmul(aud_feats.float().to(dev), img_feats.float().T.to(dev))
+        return self.reportRetrieval(score_per_A=score, score_per_B=score.T, AB_answers=all_ids, BA_answers=img_ids)
+
+    def reportRetrieval(self, score_per_A, score_per_B, AB_answers, BA_answers,
+                        metadata={"modality_A_title": "audio", "modality_B_title": "image", "modality_A_logAbbr": "A",
+                                  "modality_B_logAbbr": "I"}):
+        for k in ("modality_A_title", "modality_B_title", "modality_A_logAbbr", "modality_B_logAbbr"):
+            assert k in metadata
+        r_ab, r_ba, r_mean = mutualRetrieval(score_per_A=score_per_A, score_per_B=score_per_B, AB_answers=AB_answers,
+                                             BA_answers=BA_answers, recall_at=self.recall_at,
+                                             modality_A_title=metadata["modality_A_title"], modality_B_title=metadata["modality_B_title"])
+        ab, ba = metadata["modality_A_logAbbr"] + metadata["modality_B_logAbbr"], metadata["modality_B_logAbbr"] + metadata["modality_A_logAbbr"]
+        print(f"val_recall_{ab}", r_ab)
+        print(f"val_recall_{ba}", r_ba)
+        print("val_recall_mean", r_mean)
+        if getattr(self, "logger", None) is not None:
+            self.log("val_recall_mean_10", r_mean.get("recall@10", 0.0), sync_dist=True)
+        return r_ab, r_ba, r_mean
+
+    def processWavs(self, wav):
+        wav_len = [len(x) for x in wav]
+        return wav, wav_len
+
+    def feature_extractor_s3prl(self, wav):
+        raise NotImplementedError()
+
+    def getTrainableParams(self) -> list:
+        params = []
+        if hasattr(self, "audio_encoder"):
+            params += self.audio_encoder.trainable_params()
+            params += list(self.criterion.parameters())
+        params += self.clip.trainable_params()
+        return params
+
+    def configure_optimizers(self) -> Tuple[list, list]:
+        params = self.getTrainableParams()
+        opt = getattr(torch.optim, self.config.audio_encoder.optim.name)(params, **self.config.audio_encoder.optim.args)
+        sched = get_scheduler(optimizer=opt, **self.config.audio_encoder.scheduler)
+        return [opt], [{"scheduler": sched, "interval": "step"}]
+
+
+class KW_ParallelBranch(nn.Module):
+    """kwClip.py:1004-1108: learned [CLS] + 1 post-LN encoder layer + final LN, CLS row, Linear(d -> E)."""
+
+    def __init__(self, config: OrderedNamespace, audio_dim: int, out_dim: int) -> None:
+        super().__init__()
+        self.config, self.audio_dim, self.out_dim = config, audio_dim, out_dim
+        pb = config.model_settings.parallel_branch
+        self.need_projection = pb.get("need_projection", True)
+        assert hasattr(TransformerModels, pb.transformer_type)
+        self.self_att = getattr(TransformerModels, pb.transformer_type)(**pb.transformer_args)
+        self.cls = torch.nn.Parameter(torch.randn([1, 1, pb.transformer_args.d_model]))
+        if self.need_projection:
+            self.linear_proj = nn.Linear(self.audio_dim, self.out_dim)
+
+    def extract_hidden_states(self, audio_feat, audio_len):
+        raise NotImplementedError("analysis-only path (feature_extractor_s3prl); SURVEY.md section 8f")
+
+    def forward(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> torch.Tensor:
+        out = self.self_att.forward_cls(self.cls, audio_feat, audio_len)            # bf16 [B, d]
+        if hasattr(self, "linear_proj"):
+            out = ops.gemm(out, self.linear_proj.weight.detach().to(torch.bfloat16).contiguous(),
+                           self.linear_proj.bias.detach().float().contiguous(), out_f32=True)
+        return out
+
+
+class KW_CascadedBranch(nn.Module):
+    """kwClip.py:697-916: K learned [CLS] keywords -> LN(MHA+x) -> Linear -> BatchNorm -> cosine vs sub-word embeddings ->
+    VQ -> CLIP text encoder."""
+
+    def __init__(self, config: OrderedNamespace, audio_dim: int, text_dim: int, clip: ClipModel) -> None:
+        super().__init__()
+        self.audio_dim, self.text_dim, self.clip, self.config = audio_dim, text_dim, clip, config
+        cb = config.model_settings.cascaded_branch
+        if cb.keyword.get("kw_projection", None) is not None:
+            raise NotImplementedError("kw_projection MLP is not used by any shipped config")
+        self.keyword_num = cb.keyword.number
+        self.cls = torch.nn.Parameter(torch.randn([1, self.keyword_num, cb.transformer_args.d_model]))
+        assert hasattr(TransformerModels, cb.transformer_type), "transformer structure '{}' not supported".format(cb.transformer_type)
+        self.self_att = getattr(TransformerModels, cb.transformer_type)(**cb.transformer_args)
+        self.linear_proj = nn.Linear(cb.transformer_args.d_model, self.text_dim)
+        self.vq_type = cb.vq.type
+        if not hasattr(vector_quantizers, self.vq_type):
+            raise NotImplementedError("Vq ({}) not implemented".format(self.vq_type))
+        self.vector_quantizer = getattr(vector_quantizers, self.vq_type)(**cb.vq.args)
+        if hasattr(cb.keyword, "batchnorms"):
+            bn = cb.keyword.batchnorms
+            emb = self.clip.model.token_embedding.weight
+            self.bn_layer = Kw_BatchNorm(kw_num=self.keyword_num, kw_dim=self.text_dim, batchnorm_type=bn.type,
+                                         init_bias=torch.mean(emb, dim=0), init_scale=torch.std(emb, dim=0), std_scale=bn.std_scale,
+                                         learnable=bn.learnable if hasattr(bn, "learnable") else True,
+                                         parallel=bn.parallel if hasattr(bn, "parallel") else False)
+
+    def forward(self, audio_feat: torch.Tensor, audio_len: torch.Tensor):
+        B, K = audio_feat.shape[0], self.keyword_num
+        kw = self.self_att.forward_cls(self.cls, audio_feat, audio_len)                       # bf16 [B, K, d]
+        kw = ops.gemm(kw.view(B * K, -1), self.linear_proj.weight.detach().to(torch.bfloat16).contiguous(),
+                      self.linear_proj.bias.detach().float().contiguous(), out_f32=True).view(B, K, self.text_dim)
+        if hasattr(self, "bn_layer"):
+            kw = self.bn_layer(kw)
+        emb = self.clip.model.token_embedding.weight
+        cos = ops.cosine_scores(kw.reshape(B * K, self.text_dim), emb).view(B, K, emb.shape[0])   # fp32, exact arg-max
+        vq_results = self.vector_quantizer(x=cos)
+        assert emb.requires_grad is False
+        keywords = self.vector_quantizer.embed(vq_results, emb)
+        feat = self.clip.encode_keywords(keywords, K)
+        return feat, vq_results, keywords
+
+
+class KWClip_GeneralTransformer(KWClipBase):
+    def __init__(self, config: OrderedNamespace) -> None:
+        super().__init__(config)
+        ms = self.config.model_settings
+        self.cascaded_branch = None
+        self.parallel_branch = None
+        if ms.cascaded_objective_weight > 0:
+            if ms.cascaded_branch.type != "KW_CascadedBranch":
+                raise NotImplementedError()
+            self.cascaded_branch = KW_CascadedBranch(config=self.config, audio_dim=self.audio_embd_dim,
+                                                     text_dim=self.subword_embd_dim, clip=self.clip)
+        if ms.parallel_objective_weight > 0:
+            self.parallel_branch = KW_ParallelBranch(config=self.config, audio_dim=self.audio_embd_dim, out_dim=self.subword_embd_dim)
+        self.img_enc_proj_net = self.p_branch_proj_net = self.c_branch_proj_net = None
+        if ms.get("image_encoder_projection", None) is not None:
+            p = ms.image_encoder_projection
+            self.img_enc_proj_net = MLPLayers(units=p.dimensions, dropout=p.dropout)
+        if ms.get("parallel_branch_projection", None) is not None:
+            p = ms.parallel_branch_projection
+            self.p_branch_proj_net = MLPLayers(units=p.dimensions, dropout=p.dropout)
+            if ms.get("cascaded_branch_projection", None) is not None:   # the reference gates this on the parallel key (kwClip.py:1178)
+                p = ms.cascaded_branch_projection
+                self.c_branch_proj_net = MLPLayers(units=p.dimensions, dropout=p.dropout)
+
+    def getTrainableParams(self) -> list:
+        params = super().getTrainableParams()
+        for m in (self.cascaded_branch, self.parallel_branch, self.img_enc_proj_net, self.p_branch_proj_net):
+            if m is not None:
+                params += [p for p in m.parameters() if p.requires_grad]
+        return params
+
+    def compute_loss(self, input_feats: dict):
+        assert isinstance(input_feats, dict) and "id" in input_feats and "image_feat" in input_feats
+        assert "cascaded_audio_feat" in input_feats or "parallel_audio_feat" in input_feats
+        ms = self.config.model_settings
+        image_feat, ids = input_feats["image_feat"].float(), input_feats["id"]
+        out = {"loss": 0}
+        if ms.cascaded_objective_weight > 0:
+            out["c_cl_loss"] = self.criterion(feat_A=input_feats["cascaded_audio_feat"].float(), feat_B=image_feat, index=ids)
+            out["loss"] = out["loss"] + ms.cascaded_objective_weight * out["c_cl_loss"]
+        if ms.parallel_objective_weight > 0:
+            out["p_cl_loss"] = self.criterion(feat_A=input_feats["parallel_audio_feat"].float(), feat_B=image_feat, index=ids)
+            out["loss"] = out["loss"] + ms.parallel_objective_weight * out["p_cl_loss"]
+        return out
+
+    def _branches(self, audio_feat, audio_len):
+        c_feat = p_feat = vq = kw = None
+        if self.cascaded_branch is not None:
+            c_feat, vq, kw = self.cascaded_branch(audio_feat=audio_feat, audio_len=audio_len)
+            c_feat = ops.l2norm(c_feat)
+        if self.parallel_branch is not None:
+            p_feat = self.parallel_branch(audio_feat=audio_feat, audio_len=audio_len)
+            if self.p_branch_proj_net is not None:
+                p_feat = self.p_branch_proj_net(p_feat)
+            p_feat = ops.l2norm(p_feat)
+        return c_feat, p_feat, vq, kw
+
+    def encode_speech(self, wav) -> dict:
+        wav, wav_len = self.processWavs(wav)
+        audio_feat, audio_len = self.forward_audio(wav, wav_len)
+        c_feat, p_feat, vq, kw = self._branches(audio_feat, audio_len)
+        return {"cascaded_audio_feat": c_feat, "parallel_audio_feat": p_feat, "vq_results": vq, "keywords": kw}
+
+    def feature_extractor_s3prl(self, wav):
+        wav, wav_len = self.processWavs(wav)
+        audio_feat, audio_len, hidden_states = self.forward_audio(wav, wav_len, return_hidden_states=True)
+        assert isinstance(hidden_states, tuple)
+        return hidden_states[-1], hidden_states
+
+    def forward(self, batch) -> tuple:
+        wav, wav_len, image, ids = batch["wav"], batch["wav_len"], batch["image"], batch["id"]
+        self.clip.update_device(self.device)
+        audio_feat, audio_len = self.forward_audio(wav, wav_len)
+        image_feat = self.forward_image(image)
+        if self.img_enc_proj_net is not None:
+            image_feat = self.img_enc_proj_net(image_feat)
+        c_feat, p_feat, vq, kw = self._branches(audio_feat, audio_len)
+        image_feat = ops.l2norm(image_feat)
+        loss_feats = {"id": ids, "image_feat": image_feat}
+        log_metrics = {}
+        if c_feat is not None:
+            loss_feats["cascaded_audio_feat"] = c_feat
+        if p_feat is not None:
+            loss_feats["parallel_audio_feat"] = p_feat
+        if self.config.model_settings.cascaded_objective_weight > 0:
+            log_metrics["softmax_temp"] = vq["temp"]
+        log_metrics["cl_temp"] = self.criterion.current_temperature
+        others = {"cascaded_audio_feat": c_feat, "parallel_audio_feat": p_feat, "image_feat": image_feat, "id": ids,
+                  "vq_results": vq, "keywords": kw}
+        return loss_feats, log_metrics, others

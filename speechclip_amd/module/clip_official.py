@@ -1,0 +1,102 @@
+"""ClipModel -- the reference's CLIP wrapper (avssl/module/clip_official.py:26-294) over the MI355X CLIP engine.
+
+Same constructor arguments and attributes (`model`, `out_dim`, `tokenizer`, `device`, reduced sub-word vocabulary,
+`encode_image`, `encode_text`, `encode_keywords`, `update_device`, `trainable_params`).  openai `clip` is not
+required: `self.model` is a parameter tree with openai's key names (clip_model.CLIP) whose towers run on HIP kernels.
+No network: weights are loaded only from a local state_dict ($SPEECHCLIP_CLIP_CKPT), else random init.
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .clip_model import CLIP, ClipConfig
+
+logger = logging.getLogger(__name__)
+_clip_models = {"RN50", "RN101", "RN50x4", "RN50x16", "RN50x64", "ViT-B/32", "ViT-B/16", "ViT-L/14"}
+SOT_ID, EOT_ID = 49406, 49407
+
+
+class _TokenizerIds:
+    """The two ids of openai's SimpleTokenizer that the hot path needs (clip_official.py:95-101,235-240)."""
+
+    def __init__(self, vocab_size=49408):
+        self.encoder = {"<|startoftext|>": vocab_size - 2, "<|endoftext|>": vocab_size - 1}
+
+
+class ClipModel(nn.Module):
+    def __init__(self, name: str, device: str = "cpu", image_encoder_trainable: bool = False, text_encoder_trainable: bool = False,
+                 reduce_subword_embbedding: str = None, clip_config: ClipConfig = None, **kwargs):
+        super().__init__()
+        assert name in _clip_models
+        if image_encoder_trainable or text_encoder_trainable:
+            raise NotImplementedError("CLIP towers are frozen in every shipped config; fine-tuning needs backward kernels")
+        self.name, self.device = name, device
+        if clip_config is not None and not isinstance(clip_config, ClipConfig):
+            clip_config = ClipConfig(**dict(clip_config.to_dict() if hasattr(clip_config, "to_dict") else clip_config))
+        cfg = clip_config if clip_config is not None else ClipConfig.from_name(name)
+        self.model = CLIP(cfg)
+        ckpt = os.environ.get("SPEECHCLIP_CLIP_CKPT", "")
+        if ckpt and os.path.isfile(ckpt):
+            self.model.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=False)
+        self.image_encoder_trainable, self.text_encoder_trainable = image_encoder_trainable, text_encoder_trainable
+        self.out_dim = self.model.transformer.width
+        self.tokenizer = _TokenizerIds(cfg.vocab_size)
+        for p in self.model.parameters():
+            p.requires_grad = False
+        self.selected_text_emb_ids = None
+        if reduce_subword_embbedding is not None:
+            if not os.path.exists(reduce_subword_embbedding):
+                raise FileNotFoundError(reduce_subword_embbedding)
+            data = np.load(reduce_subword_embbedding)
+            self.selected_text_emb_ids = data[:, 0]
+            dist = data[:, 1]
+            self.selected_text_emb_ids_dist = torch.from_numpy(dist / np.sum(dist))
+            self.original_text_emb_weight = self.model.token_embedding.weight
+            reduced = self.model.token_embedding.weight[torch.as_tensor(self.selected_text_emb_ids, dtype=torch.long)]
+            self.model.token_embedding = nn.Embedding.from_pretrained(reduced.detach().clone())
+            self.model.token_embedding.weight.requires_grad = False
+            self.original2Reduced = {int(o): n for n, o in enumerate(self.selected_text_emb_ids)}
+            self.reducedl2Original = {n: int(o) for n, o in enumerate(self.selected_text_emb_ids)}
+            self.startOfTxt_reduced = self.original2Reduced[self.tokenizer.encoder["<|startoftext|>"]]
+            self.endOfTxt_reduced = self.original2Reduced[self.tokenizer.encoder["<|endoftext|>"]]
+
+    def trainable_params(self) -> list:
+        return []
+
+    def update_device(self, device):
+        self.device = device
+
+    def to(self, *args, **kwargs):
+        super().to(*args, **kwargs)
+        self.device = self.model.token_embedding.weight.device
+        return self
+
+    def encode_image(self, image: torch.Tensor) -> torch.Tensor:
+        return self.model.encode_image(image)
+
+    def _special_ids(self):
+        if self.selected_text_emb_ids is None:
+            return self.tokenizer.encoder["<|startoftext|>"], self.tokenizer.encoder["<|endoftext|>"]
+        return self.startOfTxt_reduced, self.endOfTxt_reduced
+
+    def encode_text(self, text: torch.Tensor) -> torch.Tensor:
+        """text: [B, 77] token ids (reduced ids if the vocabulary is reduced).  EOT = arg-max id position."""
+        emb = self.model.token_embedding(text)
+        return self.model.encode_text_embeddings(emb, text.argmax(dim=-1))
+
+    def encode_keywords(self, keywords: torch.Tensor, keyword_num: int) -> torch.Tensor:
+        """clip_official.py:220-264: [SOT, kw_1..kw_K, EOT, pad...] through the text tower, feature at position K+1.
+        The causal mask makes positions > K+1 irrelevant, so only K+2 positions are evaluated."""
+        if not isinstance(keywords, torch.Tensor):
+            raise TypeError(f"Unknown keywords type {type(keywords)}")
+        B, dev = keywords.size(0), keywords.device
+        sot, eot = self._special_ids()
+        tok = self.model.token_embedding.weight
+        emb = torch.empty(B, keyword_num + 2, tok.shape[1], device=dev, dtype=torch.float32)
+        emb[:, 0] = tok[sot]
+        emb[:, 1:1 + keyword_num] = keywords
+        emb[:, 1 + keyword_num] = tok[eot]
+        return self.model.encode_text_embeddings(emb, torch.full((B,), keyword_num + 1, device=dev, dtype=torch.long))

@@ -1,0 +1,307 @@
+"""HuBERT speech encoder on MI355X: parameter container with fairseq checkpoint key names + the
+HIP execution engine (conv stack as overlapping-row GEMMs, grouped positional conv, transformer
+layers with varlen flash attention).
+
+Replaces what the reference obtains from fairseq (`HubertModel`, not vendored) and drives through
+`customFunc_hubert_forward` / `custom_FairseqTransformerEncoder_extract_features`
+(avssl/module/speech_encoder_plus.py:29-107).  Parameter names follow fairseq so the reference's
+checkpoints (`audio_encoder.encoder.*`) load by key name.
+
+Layout notes (DESIGN.md has the full picture):
+  * activations are channels-last bf16 [B, P_l, C]; P_0 = ceil(T_0/64)*64 and P_{l+1} = P_l / 2, so all
+    utterances of the batch flatten into ONE GEMM per conv layer (row m = b*P_l + t, lda = stride*C, K = k*C);
+    rows t >= T_l are finite don't-care rows that never reach a valid output.
+  * the transformer runs on T_p = P_0/64 >= T rows per utterance; rows >= T are treated exactly like
+    padded frames (zeroed before the positional conv, masked as keys).
+"""
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import ACT_GELU, ACT_NONE
+
+CONV_LAYERS = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2
+
+
+@dataclass
+class HubertConfig:
+    extractor_mode: str = "default"      # "default": GroupNorm on conv layer 0 (base); "layer_norm": LN on every layer (large)
+    conv_bias: bool = False
+    conv_layers: List[Tuple[int, int, int]] = field(default_factory=lambda: list(CONV_LAYERS))
+    encoder_layers: int = 12
+    encoder_embed_dim: int = 768
+    encoder_ffn_embed_dim: int = 3072
+    encoder_attention_heads: int = 12
+    layer_norm_first: bool = False
+    conv_pos: int = 128
+    conv_pos_groups: int = 16
+    normalize: bool = False              # fairseq task.cfg.normalize (per-utterance wave layer-norm)
+
+    @staticmethod
+    def from_name(name: str) -> "HubertConfig":
+        if name in ("hubert", "hubert_base"):
+            return HubertConfig()
+        if name == "hubert_large_ll60k":
+            return HubertConfig(extractor_mode="layer_norm", conv_bias=True, encoder_layers=24, encoder_embed_dim=1024,
+                                encoder_ffn_embed_dim=4096, encoder_attention_heads=16, layer_norm_first=True, normalize=True)
+        raise KeyError(name)
+
+
+class _Holder(nn.Module):
+    """Parameter holder whose children are registered under explicit (numeric) names."""
+
+
+def _conv_block(cfg: HubertConfig, i: int, in_d: int, dim: int, k: int) -> nn.Module:
+    blk = _Holder()
+    conv = _Holder()
+    conv.weight = nn.Parameter(torch.empty(dim, in_d, k))
+    nn.init.kaiming_normal_(conv.weight)
+    if cfg.conv_bias:
+        conv.bias = nn.Parameter(torch.zeros(dim))
+    blk.add_module("0", conv)
+    if cfg.extractor_mode == "layer_norm":
+        wrap = _Holder()
+        wrap.add_module("1", nn.LayerNorm(dim))
+        blk.add_module("2", wrap)
+    elif i == 0:
+        blk.add_module("2", nn.GroupNorm(dim, dim))
+    return blk
+
+
+class _Attn(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj, self.v_proj, self.q_proj, self.out_proj = (nn.Linear(d, d) for _ in range(4))
+
+
+class _EncLayer(nn.Module):
+    def __init__(self, cfg: HubertConfig):
+        super().__init__()
+        d = cfg.encoder_embed_dim
+        self.self_attn = _Attn(d)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, cfg.encoder_ffn_embed_dim)
+        self.fc2 = nn.Linear(cfg.encoder_ffn_embed_dim, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg: HubertConfig):
+        super().__init__()
+        d, k, g = cfg.encoder_embed_dim, cfg.conv_pos, cfg.conv_pos_groups
+        pc = _Holder()
+        v = torch.empty(d, d // g, k)
+        nn.init.normal_(v, 0.0, math.sqrt(4.0 / (k * d)))
+        pc.weight_v = nn.Parameter(v)
+        pc.weight_g = nn.Parameter(v.detach().pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+        pc.bias = nn.Parameter(torch.zeros(d))
+        self.pos_conv = _Holder()
+        self.pos_conv.add_module("0", pc)
+        self.layers = nn.ModuleList([_EncLayer(cfg) for _ in range(cfg.encoder_layers)])
+        self.layer_norm = nn.LayerNorm(d)
+        self.layerdrop = 0.0
+        self.layer_norm_first = cfg.layer_norm_first
+
+
+def conv_lengths(L: int, conv_layers) -> List[int]:
+    out = []
+    for _, k, s in conv_layers:
+        L = (L - k) // s + 1
+        out.append(L)
+    return out
+
+
+class HubertModel(nn.Module):
+    """fairseq-compatible parameter tree; `extract_all_layers` is the HIP forward."""
+
+    def __init__(self, cfg: HubertConfig):
+        super().__init__()
+        self.cfg = cfg
+        fe = _Holder()
+        fe.conv_layers = nn.ModuleList()
+        in_d = 1
+        for i, (dim, k, s) in enumerate(cfg.conv_layers):
+            fe.conv_layers.append(_conv_block(cfg, i, in_d, dim, k))
+            in_d = dim
+        self.feature_extractor = fe
+        d = cfg.encoder_embed_dim
+        self.post_extract_proj = nn.Linear(in_d, d)
+        self.mask_emb = nn.Parameter(torch.empty(d).uniform_())
+        self.encoder = _Encoder(cfg)
+        self.layer_norm = nn.LayerNorm(in_d)
+        self.feature_grad_mult = 1.0
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0.0, 0.02)
+                nn.init.zeros_(m.bias)
+        self._packed = None
+        self._ws = {}
+        self.register_load_state_dict_post_hook(lambda module, keys: module.invalidate_packed())
+
+    # ------------------------------------------------------------------ weight packing (load time, not hot path)
+    def invalidate_packed(self):
+        self._packed = None
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        self._ws = {}
+        return super()._apply(fn, *a, **k)
+
+    def _pack(self, dev):
+        cfg = self.cfg
+        bf, f32 = torch.bfloat16, torch.float32
+        P = {}
+
+        def w16(t):
+            return t.detach().to(dev, bf).contiguous()
+
+        def w32(t):
+            return None if t is None else t.detach().to(dev, f32).contiguous()
+
+        convs = self.feature_extractor.conv_layers
+        c0 = getattr(convs[0], "0")
+        P["conv0_w"] = w32(c0.weight.reshape(c0.weight.shape[0], -1))
+        P["conv0_b"] = w32(getattr(c0, "bias", None))
+        P["conv_ln"] = []
+        if cfg.extractor_mode == "layer_norm":
+            for blk in convs:
+                ln = getattr(getattr(blk, "2"), "1")
+                P["conv_ln"].append((w32(ln.weight), w32(ln.bias)))
+        else:
+            gn = getattr(convs[0], "2")
+            P["gn"] = (w32(gn.weight), w32(gn.bias))
+        P["conv_w"], P["conv_b"] = [], []
+        for i in range(1, len(convs)):
+            c = getattr(convs[i], "0")
+            P["conv_w"].append(w16(c.weight.permute(0, 2, 1).reshape(c.weight.shape[0], -1)))   # [out, k*in], K idx = tap*C + c_in
+            P["conv_b"].append(w32(getattr(c, "bias", None)))
+        P["feat_ln"] = (w32(self.layer_norm.weight), w32(self.layer_norm.bias))
+        P["proj_w"], P["proj_b"] = w16(self.post_extract_proj.weight), w32(self.post_extract_proj.bias)
+        pc = getattr(self.encoder.pos_conv, "0")
+        v = pc.weight_v.detach().float()
+        wfold = pc.weight_g.detach().float() * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()   # weight-norm, dim=2
+        d, G, Kw = cfg.encoder_embed_dim, cfg.conv_pos_groups, cfg.conv_pos
+        cg = d // G
+        P["pos_w"] = w16(wfold.view(G, cg, cg, Kw).permute(0, 1, 3, 2).reshape(G, cg, Kw * cg))
+        P["pos_b"] = w32(pc.bias)
+        P["enc_ln"] = (w32(self.encoder.layer_norm.weight), w32(self.encoder.layer_norm.bias))
+        P["layers"] = []
+        for lyr in self.encoder.layers:
+            a = lyr.self_attn
+            P["layers"].append(dict(
+                wqkv=w16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)),
+                bqkv=w32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)),
+                wo=w16(a.out_proj.weight), bo=w32(a.out_proj.bias),
+                ln1=(w32(lyr.self_attn_layer_norm.weight), w32(lyr.self_attn_layer_norm.bias)),
+                w1=w16(lyr.fc1.weight), b1=w32(lyr.fc1.bias), w2=w16(lyr.fc2.weight), b2=w32(lyr.fc2.bias),
+                ln2=(w32(lyr.final_layer_norm.weight), w32(lyr.final_layer_norm.bias))))
+        return P
+
+    def _buf(self, name, shape, dtype, dev, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None or t.device != dev:
+            t = (torch.zeros if zero else torch.empty)(shape, device=dev, dtype=dtype)
+            self._ws[key] = t
+        return t
+
+    # ------------------------------------------------------------------ geometry helpers (host ints)
+    def frame_geometry(self, lmax: int):
+        cl = self.cfg.conv_layers
+        lens = conv_lengths(lmax, cl)
+        T0, T = lens[0], lens[-1]
+        ds = 1
+        for _, _, s in cl[1:]:
+            ds *= s
+        P0 = (T0 + ds - 1) // ds * ds
+        return T0, T, P0, P0 // ds
+
+    @staticmethod
+    def valid_frames(lens: Sequence[int], lmax: int, T: int) -> List[int]:
+        """fairseq forward_padding_mask rule: trim lmax % T samples, chunk = remaining / T, a frame is padding iff
+        ALL its samples are padding  =>  valid = ceil(len / chunk), clamped to T."""
+        chunk = (lmax - lmax % T) // T
+        return [min(T, -(-int(l) // chunk)) for l in lens]
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int]):
+        """wav: f32 [B, Lmax] device tensor (right zero-padded); lens: host ints.
+        Returns (hidden [n_layers+1, B, Tp, d] (bf16 for post-LN, f32 for pre-LN), T, Tp, valid_frames)."""
+        cfg = self.cfg
+        dev = wav.device
+        if self._packed is None:
+            self._packed = self._pack(dev)
+        P = self._packed
+        B, lmax = wav.shape
+        T0, T, P0, Tp = self.frame_geometry(lmax)
+        assert T >= 1, "waveform too short for the conv stack"
+        C = cfg.conv_layers[0][0]
+        bf = torch.bfloat16
+        lens_i32 = torch.tensor([int(l) for l in lens], dtype=torch.int32, device=dev)
+        if cfg.normalize:
+            wav = ops.wave_layernorm(wav.contiguous(), lens_i32)
+        ln_mode = cfg.extractor_mode == "layer_norm"
+        # ---- conv layer 0
+        x = self._buf("conv0", (B * P0 + 8, C), bf, dev, zero=True)
+        if ln_mode:
+            ops.conv0(wav, P["conv0_w"], T0, P0, bias=P["conv0_b"], out=x)
+            ops.layernorm(x[: B * P0], *P["conv_ln"][0], gelu=True, out=x[: B * P0])
+        else:
+            ops.conv0(wav, P["conv0_w"], T0, P0, gn_gamma=P["gn"][0], gn_beta=P["gn"][1], out=x)
+        # ---- conv layers 1.. as overlapping-row GEMMs
+        rows = P0
+        for i, (dim, k, s) in enumerate(cfg.conv_layers[1:]):
+            rows //= s
+            y = self._buf(f"conv{i + 1}", (B * rows + 8, dim), bf, dev, zero=True)
+            ops.gemm(x, P["conv_w"][i], P["conv_b"][i], ACT_NONE if ln_mode else ACT_GELU, out=y[: B * rows],
+                     M=B * rows, K=k * C, lda=s * C)
+            if ln_mode:
+                ops.layernorm(y[: B * rows], *P["conv_ln"][i + 1], gelu=True, out=y[: B * rows])
+            x, C = y, dim
+        assert rows == Tp
+        M = B * Tp
+        d = cfg.encoder_embed_dim
+        # ---- feature LayerNorm + projection
+        feats = ops.layernorm(x[:M], *P["feat_ln"], out=self._buf("feat_ln", (M, C), bf, dev))
+        xp = ops.gemm(feats, P["proj_w"], P["proj_b"], out=self._buf("proj", (M, d), bf, dev))
+        # ---- frame mask, positional conv (+ LN for post-LN models)
+        valid = self.valid_frames(lens, lmax, T)
+        valid_i32 = torch.tensor(valid, dtype=torch.int32, device=dev)
+        nl = cfg.encoder_layers
+        pre_ln = cfg.layer_norm_first
+        hid_dtype = torch.float32 if pre_ln else bf
+        hidden = self._buf("hidden", (nl + 1, M, d), hid_dtype, dev)
+        g, bta = (None, None) if pre_ln else P["enc_ln"]
+        ops.posconv(xp, valid_i32, P["pos_w"], P["pos_b"], g, bta, B, Tp, d, cfg.conv_pos_groups, cfg.conv_pos, out=hidden[0])
+        # ---- transformer layers
+        H = cfg.encoder_attention_heads
+        qkv = self._buf("qkv", (M, 3 * d), bf, dev)
+        att = self._buf("att", (M, d), bf, dev)
+        ffn = self._buf("ffn", (M, cfg.encoder_ffn_embed_dim), bf, dev)
+        tmp = self._buf("tmp", (M, d), bf, dev)
+        tmp2 = self._buf("tmp2", (M, d), bf, dev)
+        for i, L in enumerate(P["layers"]):
+            h = hidden[i]
+            if not pre_ln:
+                ops.gemm(h, L["wqkv"], L["bqkv"], out=qkv)
+                ops.attention(qkv, B, Tp, H, valid_i32, out=att)
+                ops.gemm(att, L["wo"], L["bo"], residual=h, out=tmp)
+                ops.layernorm(tmp, *L["ln1"], out=tmp2)
+                ops.gemm(tmp2, L["w1"], L["b1"], ACT_GELU, out=ffn)
+                ops.gemm(ffn, L["w2"], L["b2"], residual=tmp2, out=tmp)
+                ops.layernorm(tmp, *L["ln2"], out=hidden[i + 1])
+            else:
+                xmid = self._buf("xmid", (M, d), torch.float32, dev)
+                ops.layernorm(h, *L["ln1"], out=tmp)
+                ops.gemm(tmp, L["wqkv"], L["bqkv"], out=qkv)
+                ops.attention(qkv, B, Tp, H, valid_i32, out=att)
+                ops.gemm(att, L["wo"], L["bo"], residual=h, out=xmid, out_f32=True)
+                ops.layernorm(xmid, *L["ln2"], out=tmp)
+                ops.gemm(tmp, L["w1"], L["b1"], ACT_GELU, out=ffn)
+                ops.gemm(ffn, L["w2"], L["b2"], residual=xmid, out=hidden[i + 1], out_f32=True)
+        return hidden.view(nl + 1, B, Tp, d), T, Tp, valid

@@ -1,0 +1,113 @@
+"""CLS-pooling heads (avssl/module/kw_modules/TransformerModels.py:48-135) on the HIP kernels.
+
+`TransformerEncoder` (parallel branch: 1 post-LN encoder layer + final LayerNorm) and
+`MultiheadAttentionAndNorm` (cascaded branch: LN(MHA(x) + x)) keep the reference's constructor arguments and
+`state_dict` key names (`model.layers.0.self_attn.in_proj_weight`, `model.norm.*`,
+`multihead_attn_layer.*`, `attentionBlock_Norm.*`).  The reference evaluates every row of
+[CLS ; frames] and then keeps only the CLS rows (kwClip.py:1099, :879); here only the CLS rows are computed
+(`forward_cls`): K/V for all frames, Q / attention / FFN / LayerNorm for the NQ learned tokens only.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...ops import ACT_GELU
+
+__all__ = ["TransformerEncoder", "MultiheadAttentionAndNorm"]
+BF = torch.bfloat16
+
+
+def _frames_view(audio_feat: torch.Tensor):
+    """[B,T,D] (possibly a [:, :T] slice of a [B,Tp,D] buffer) -> (rows2d [B*Tp, D], Tp) without copying."""
+    B, T, D = audio_feat.shape
+    if audio_feat.stride(2) == 1 and audio_feat.stride(1) == D and audio_feat.stride(0) % D == 0 and audio_feat.dtype == BF:
+        Tp = audio_feat.stride(0) // D if B > 1 else T
+        need = ((B - 1) * Tp + T) * D
+        if audio_feat.untyped_storage().nbytes() // 2 - audio_feat.storage_offset() >= B * Tp * D or Tp == T:
+            return torch.as_strided(audio_feat, (B * Tp, D), (D, 1)), Tp
+        del need
+    x = audio_feat.to(BF).contiguous()
+    return x.view(B * T, D), T
+
+
+def _cls_attention_block(cls: torch.Tensor, audio_feat: torch.Tensor, audio_len: torch.Tensor, in_w, in_b, heads: int):
+    """Shared front half: q/k/v of the NQ CLS tokens, k/v of the frames, CLS-rows-only attention.
+    Returns bf16 [B*NQ, D]."""
+    B = audio_feat.shape[0]
+    NQ, D = cls.shape[-2], cls.shape[-1]
+    rows, Tp = _frames_view(audio_feat)
+    w = in_w.detach().to(BF).contiguous()
+    b = in_b.detach().float().contiguous()
+    cls_rows = cls.detach().reshape(NQ, D).to(BF).contiguous()
+    cls_qkv = ops.gemm(cls_rows, w, b)                                   # [NQ, 3D]
+    kv_x = ops.gemm(rows, w[D:], b[D:])                                   # [B*Tp, 2D]
+    lens = audio_len.to(device=rows.device, dtype=torch.int32).contiguous()
+    att = ops.cls_attention(cls_qkv, kv_x, lens, B, Tp, NQ, heads, D // heads)
+    return att.view(B * NQ, D)
+
+
+class _EncoderStack(nn.Module):
+    def __init__(self, layer_args, n_layers, d_model):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.TransformerEncoderLayer(**layer_args) for _ in range(n_layers)])
+        self.norm = nn.LayerNorm(d_model, eps=1e-5)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, n_layers: int = 1, d_model: int = 768, nhead: int = 8, dim_feedforward: int = 3072, dropout: float = 0.1,
+                 activation: str = "gelu", layer_norm_eps: float = 1e-5, batch_first: bool = True, norm_first: bool = False) -> None:
+        super().__init__()
+        if n_layers != 1 or norm_first or activation != "gelu" or not batch_first:
+            raise NotImplementedError("MI355X parallel branch supports the shipped shape: 1 post-LN GELU layer, batch_first")
+        self.nhead, self.eps = nhead, layer_norm_eps
+        self.model = _EncoderStack(dict(d_model=d_model, nhead=nhead, dim_feedforward=dim_feedforward, dropout=dropout,
+                                        activation=activation, layer_norm_eps=layer_norm_eps, batch_first=batch_first,
+                                        norm_first=norm_first), n_layers, d_model)
+
+    def forward_cls(self, cls: torch.Tensor, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> torch.Tensor:
+        """cls [1,1,D]; audio_feat bf16 [B,T,D]; audio_len [B] (valid frames, without the CLS).  -> bf16 [B, D]:
+        row 0 of norm(layer([CLS; x])) -- what kwClip.py:1097-1099 keeps."""
+        L = self.model.layers[0]
+        sa = L.self_attn
+        D = cls.shape[-1]
+        att = _cls_attention_block(cls, audio_feat, audio_len, sa.in_proj_weight, sa.in_proj_bias, self.nhead)
+        f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
+        w16 = lambda t: t.detach().to(BF).contiguous()   # noqa: E731
+        y = ops.gemm(att, w16(sa.out_proj.weight), f32(sa.out_proj.bias), residual=f32(cls).reshape(1, D).expand(att.shape[0], D),
+                     out_f32=True)                                                       # x + SA(x), CLS rows
+        x1 = ops.layernorm(y, f32(L.norm1.weight), f32(L.norm1.bias), self.eps, out_f32=True)
+        x1b = ops.layernorm(y, f32(L.norm1.weight), f32(L.norm1.bias), self.eps)
+        h = ops.gemm(x1b, w16(L.linear1.weight), f32(L.linear1.bias), ACT_GELU)
+        y2 = ops.gemm(h, w16(L.linear2.weight), f32(L.linear2.bias), residual=x1, out_f32=True)
+        x2 = ops.layernorm(y2, f32(L.norm2.weight), f32(L.norm2.bias), self.eps, out_f32=True)
+        return ops.layernorm(x2, f32(self.model.norm.weight), f32(self.model.norm.bias), 1e-5)
+
+    def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
+        raise NotImplementedError("full-row forward is off the hot path; use forward_cls (KW_ParallelBranch does)")
+
+    def extract_hidden_states(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
+        raise NotImplementedError("extract_hidden_states is analysis-only (SURVEY.md section 8f)")
+
+
+class MultiheadAttentionAndNorm(nn.Module):
+    def __init__(self, d_model: int = 768, nhead: int = 8, dropout: float = 0.1, layer_norm_eps: float = 1e-5,
+                 batch_first: bool = True, **kwargs) -> None:
+        super().__init__()
+        self.nhead, self.eps = nhead, layer_norm_eps
+        self.multihead_attn_layer = nn.MultiheadAttention(d_model, num_heads=nhead, dropout=dropout, batch_first=batch_first)
+        self.attentionBlock_Norm = nn.LayerNorm(d_model, eps=layer_norm_eps)
+
+    def forward_cls(self, cls: torch.Tensor, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> torch.Tensor:
+        """cls [1,K,D] -> bf16 [B, K, D]: rows 0..K-1 of LN(MHA([CLS;x]) + [CLS;x])  (kwClip.py:877-881)."""
+        m = self.multihead_attn_layer
+        NQ, D = cls.shape[-2], cls.shape[-1]
+        B = audio_feat.shape[0]
+        att = _cls_attention_block(cls, audio_feat, audio_len, m.in_proj_weight, m.in_proj_bias, self.nhead)
+        res = cls.detach().float().reshape(1, NQ, D).expand(B, NQ, D).reshape(B * NQ, D).contiguous()
+        y = ops.gemm(att, m.out_proj.weight.detach().to(BF).contiguous(), m.out_proj.bias.detach().float().contiguous(), residual=res,
+                     out_f32=True)
+        n = self.attentionBlock_Norm
+        return ops.layernorm(y, n.weight.detach().float(), n.bias.detach().float(), self.eps).view(B, NQ, D)
+
+    def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
+        raise NotImplementedError("full-row forward is off the hot path; use forward_cls (KW_CascadedBranch does)")

@@ -1,0 +1,31 @@
+"""mutualRetrieval -- same signature and return triple as avssl/module/retrieval.py:6-121 (recall@K in percent,
+A->B, B->A and their mean).  Implemented with a rank test instead of a full argsort + Python row loops:
+item i is a hit@K iff some candidate carrying its answer id ranks among the K best scores of row i."""
+from typing import Sequence, Tuple
+
+import torch
+
+
+def _recall_one_way(score: torch.Tensor, own_ids: torch.Tensor, cand_ids: torch.Tensor, recall_at: Sequence[int]) -> dict:
+    n, m = score.shape
+    kmax = min(max(recall_at), m)
+    top = torch.topk(score, kmax, dim=1, largest=True, sorted=True).indices          # [n, kmax]
+    hit = cand_ids.to(score.device)[top] == own_ids.to(score.device)[:, None]
+    out = {}
+    for k in recall_at:
+        kk = min(k, m)
+        if k > m:
+            print("recall@{} is not eligible for #{} samples".format(k, m))
+        out["recall@{}".format(k)] = hit[:, :kk].any(dim=1).float().mean().item() * 100
+    return out
+
+
+def mutualRetrieval(score_per_A: torch.Tensor, score_per_B: torch.Tensor, AB_answers: torch.Tensor, BA_answers: torch.Tensor,
+                    recall_at: list, modality_A_title: str = "audio", modality_B_title: str = "image") -> Tuple[dict, dict, dict]:
+    assert score_per_A.dim() == 2 and score_per_B.dim() == 2 and AB_answers.dim() == 1 and BA_answers.dim() == 1
+    assert score_per_A.shape == (len(AB_answers), len(BA_answers)), (score_per_A.shape, (len(AB_answers), len(BA_answers)))
+    assert score_per_B.shape == (len(BA_answers), len(AB_answers)), (score_per_B.shape, (len(BA_answers), len(AB_answers)))
+    ab = _recall_one_way(score_per_A, AB_answers, BA_answers, recall_at)
+    ba = _recall_one_way(score_per_B, BA_answers, AB_answers, recall_at)
+    mean = {k: (ab[k] + ba[k]) / 2.0 for k in ab}
+    return ab, ba, mean

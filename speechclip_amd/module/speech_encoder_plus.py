@@ -1,0 +1,165 @@
+"""FairseqSpeechEncoder_Hubert -- the reference's HuBERT wrapper (avssl/module/speech_encoder_plus.py:319-634)
+re-implemented over the MI355X engine in `hubert.py`.
+
+Same constructor arguments, attributes (`out_dim`, `downsample_rate`, `upstream_model_hiddenstates_len`,
+`encoder`, `weightedsum_layer`, `trainable_params()`) and `forward(wav, wav_len, feat_select_idx,
+return_hidden_states)` contract.  fairseq is not required: `self.encoder` is a parameter tree with fairseq's
+checkpoint key names (hubert.HubertModel) whose forward runs on HIP kernels.  No network: a fairseq checkpoint is
+loaded only if it is already on disk ($SPEECHCLIP_HUBERT_CKPT or ~/.cache/speechclip_amd/<file name of the URL>).
+"""
+import logging
+import os
+from typing import List, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .hubert import HubertConfig, HubertModel
+from .weighted_sum import WeightedSumLayer
+
+logger = logging.getLogger(__name__)
+FEAT_SELECT_IDX_WEIGHTED_SUM_MODE = "weighted_sum"
+
+
+def random_crop_max_length(audio: torch.Tensor, max_len: int, orig_len: int = 1000000000) -> torch.Tensor:
+    """avssl/data/audio_transforms.py:5-23 (train-mode crop applied inside the encoder forward)."""
+    n = min(len(audio), orig_len)
+    if max_len < 0 or n <= max_len:
+        return audio[:n]
+    start = np.random.randint(n - max_len)
+    return audio[start:start + max_len]
+
+
+def _find_local_ckpt(url: str):
+    cands = [os.environ.get("SPEECHCLIP_HUBERT_CKPT", ""),
+             os.path.join(os.path.expanduser("~/.cache/speechclip_amd"), os.path.basename(url))]
+    for c in cands:
+        if c and os.path.isfile(c):
+            return c
+    return None
+
+
+class FairseqSpeechEncoder_Hubert(nn.Module):
+    MODEL2URL = {
+        "hubert": "https://dl.fbaipublicfiles.com/hubert/hubert_base_ls960.pt",
+        "hubert_base": "https://dl.fbaipublicfiles.com/hubert/hubert_base_ls960.pt",
+        "hubert_large_ll60k": "https://dl.fbaipublicfiles.com/hubert/hubert_large_ll60k.pt",
+    }
+    MODEL_DOWNSAMPLE_RATE = {"hubert": 320, "hubert_base": 320, "hubert_large_ll60k": 320}
+
+    def __init__(self, name: str, pretrained: bool = False, trainable: bool = False, device: str = "cpu",
+                 feat_select_idx: Union[str, list] = "all", layer_drop: Union[str, float] = 0.0, max_audio_len: int = -1,
+                 reinit_layers: List[int] = [], unfreeze_layers: List[int] = [], normalize_hiddenstates: bool = False,
+                 normalize_type: str = "s3prl", hubert_config: HubertConfig = None, **kwargs):
+        super().__init__()
+        assert name in self.MODEL2URL, "Model name({}) should be in {}".format(name, self.MODEL2URL.keys())
+        assert normalize_type in ["s3prl", "method1", "method2"], normalize_type
+        if trainable or len(reinit_layers) > 0 or len(unfreeze_layers) > 0:
+            raise NotImplementedError("fine-tuning HuBERT needs backward kernels (SURVEY.md section 8f rank 4); "
+                                      "all shipped configs freeze it (trainable: false)")
+        if not (layer_drop == "original" or (isinstance(layer_drop, float) and 0.0 <= layer_drop <= 1.0)):
+            raise ValueError(f"layer_drop = {layer_drop} is not supported.")
+        self.name, self.pretrained, self.trainable = name, pretrained, trainable
+        self.feat_select_idx, self.max_audio_len = feat_select_idx, max_audio_len
+        self.reinit_layers, self.unfreeze_layers = reinit_layers, unfreeze_layers
+        self.normalize_hiddenstates, self.normalize_type = normalize_hiddenstates, normalize_type
+        if hubert_config is not None and not isinstance(hubert_config, HubertConfig):   # dict / OrderedNamespace from a YAML
+            hc = dict(hubert_config.to_dict() if hasattr(hubert_config, "to_dict") else hubert_config)
+            if "conv_layers" in hc:
+                hc["conv_layers"] = [tuple(c) for c in hc["conv_layers"]]
+            hubert_config = HubertConfig(**hc)
+        cfg = hubert_config if hubert_config is not None else HubertConfig.from_name(name)
+        self.encoder = HubertModel(cfg)
+        self.encoder_task = type("Task", (), {"cfg": type("Cfg", (), {"normalize": cfg.normalize})()})()
+        if pretrained:
+            ckpt = _find_local_ckpt(self.MODEL2URL[name])
+            if ckpt is None:
+                logger.warning("pretrained=True but no local HuBERT checkpoint (set SPEECHCLIP_HUBERT_CKPT); using random init")
+            else:
+                sd = torch.load(ckpt, map_location="cpu")
+                sd = sd.get("model", sd)
+                missing, unexpected = self.encoder.load_state_dict(sd, strict=False)
+                logger.info(f"Loaded {ckpt}: missing={missing} unexpected={unexpected}")
+        for p in self.encoder.parameters():
+            p.requires_grad = False
+        self.encoder.eval()
+        self.downsample_rate = self.MODEL_DOWNSAMPLE_RATE[name]
+        self.out_dim = cfg.encoder_embed_dim
+        self.upstream_model_hiddenstates_len = cfg.encoder_layers + 1
+        if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
+            self.weightedsum_layer = WeightedSumLayer(n_weights=self.upstream_model_hiddenstates_len,
+                                                      normalize_features=self.normalize_hiddenstates and self.normalize_type == "s3prl")
+
+    def trainable_params(self) -> list:
+        if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
+            return list(self.weightedsum_layer.parameters())
+        return []
+
+    @staticmethod
+    def _to_list(wav, wav_len):
+        if isinstance(wav, torch.Tensor):
+            if wav.dim() == 2:
+                if len(wav_len) > 0:
+                    return [wav[b, : int(wav_len[b])] for b in range(len(wav))]
+                return [wav[b] for b in range(len(wav))]
+            if wav.dim() == 1:
+                return [wav]
+        return list(wav)
+
+    def forward(self, wav: Union[torch.Tensor, list], wav_len: Union[torch.Tensor, list] = [],
+                feat_select_idx: Union[str, list] = None, return_hidden_states: bool = False) -> Tuple:
+        dev = next(self.encoder.parameters()).device
+        # fast path: a padded [B, Lmax] device tensor in eval mode needs no per-utterance slicing
+        if isinstance(wav, torch.Tensor) and wav.dim() == 2 and len(wav_len) > 0 and not self.training:
+            lens = [int(l) for l in (wav_len.tolist() if torch.is_tensor(wav_len) else wav_len)]
+            lmax = max(lens)
+            padded = wav[:, :lmax].to(dev, torch.float32)
+            # the reference rebuilds the batch from wav[b, :len] with zero right-padding: enforce the zeros
+            if any(l < lmax for l in lens):
+                keep = torch.arange(lmax, device=dev)[None, :] < torch.tensor(lens, device=dev)[:, None]
+                padded = padded * keep
+            padded = padded.contiguous()
+        else:
+            wavs = self._to_list(wav, wav_len)
+            if self.training:
+                wavs = [random_crop_max_length(w, self.max_audio_len, len(w)) for w in wavs]
+            lens = [len(w) for w in wavs]
+            padded = torch.zeros(len(wavs), max(lens), device=dev, dtype=torch.float32)
+            for i, w in enumerate(wavs):
+                padded[i, : lens[i]] = w.to(dev, torch.float32)
+        hidden, T, Tp, _valid = self.encoder.extract_all_layers(padded, lens)      # [n, B, Tp, d]
+        if self.normalize_hiddenstates and self.normalize_type.startswith("method"):
+            raise NotImplementedError("normalize_type method1/method2 are not used by any shipped config")
+        # speech_encoder_plus.py:604-611: Python round() (banker's) of len / 320, clamped to T
+        feat_len = torch.clamp_max(torch.tensor([round(l / self.downsample_rate) for l in lens], dtype=torch.long), T).to(dev)
+        if feat_select_idx is None:
+            feat_select_idx = self.feat_select_idx
+        layers = lambda: tuple(hidden[i, :, :T] for i in range(hidden.shape[0]))  # noqa: E731
+        out = []
+        if feat_select_idx == "all":
+            hs = layers()
+            out.extend([{"last_hidden_state": hs[-1], "hidden_states": hs}, feat_len])
+        elif feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
+            out.extend([self.weightedsum_layer(hidden)[:, :T], feat_len])
+        elif isinstance(feat_select_idx, list):
+            hs = layers()
+            out.extend([[hs[i] for i in feat_select_idx], feat_len])
+        elif feat_select_idx == "last_hidden_state":
+            out.extend([hidden[-1, :, :T], feat_len])
+        elif feat_select_idx == "hidden_states":
+            out.extend([layers(), feat_len])
+        else:
+            raise KeyError(feat_select_idx)
+        if return_hidden_states:
+            out.append(layers())
+        return tuple(out)
+
+
+class S3prlSpeechEncoderPlus(nn.Module):
+    """Alternative loader via the s3prl hub (avssl/module/speech_encoder_plus.py:110-316).  No shipped config uses it
+    (all have `type: FairseqHubert`) and s3prl is a network download; kept as an importable name only."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("S3prlSpeechEncoderPlus is out of scope on MI355X; use audio_encoder.type: FairseqHubert")

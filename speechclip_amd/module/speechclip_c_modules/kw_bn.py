@@ -1,0 +1,35 @@
+"""Kw_BatchNorm (avssl/module/speechclip_c_modules/kw_bn.py:8-164), shipped mode: `eachKw` + `parallel` = one
+BatchNorm1d over the flattened (dim, keyword) features, initialised from the CLIP token-embedding mean/std.
+Eval mode (running statistics) is an affine map executed by sc_kw_affine; train-mode batch statistics are
+per-rank (not synced), as under the reference's DataParallel."""
+import torch
+from torch import nn
+
+from ... import ops
+
+
+class Kw_BatchNorm(nn.Module):
+    def __init__(self, kw_num: int, kw_dim: int, batchnorm_type: str, init_bias: torch.Tensor, init_scale: torch.Tensor,
+                 std_scale: float = 1, learnable: bool = True, parallel: bool = False) -> None:
+        super().__init__()
+        if batchnorm_type != "eachKw" or not parallel:
+            raise NotImplementedError("MI355X path supports the shipped batchnorm mode: type eachKw, parallel true")
+        self.batchnorm_type, self.kw_num, self.kw_dim, self.learnable, self.parallel = batchnorm_type, kw_num, kw_dim, learnable, parallel
+        self.std_scale = std_scale if isinstance(std_scale, list) else [std_scale] * kw_num
+        self.bn_layer = nn.BatchNorm1d(kw_dim * kw_num)
+        with torch.no_grad():
+            self.bn_layer.weight.copy_((init_scale * self.std_scale[0]).repeat(kw_num))
+            self.bn_layer.bias.copy_(init_bias.repeat(kw_num))
+        self.bn_layer.weight.requires_grad = learnable
+        self.bn_layer.bias.requires_grad = learnable
+
+    def forward(self, keywords: torch.Tensor, seq_lens: torch.Tensor = None) -> torch.Tensor:
+        assert keywords.dim() == 3 and keywords.shape[2] == self.kw_dim and keywords.shape[1] == self.kw_num
+        if self.training:
+            raise NotImplementedError("train-mode keyword BatchNorm (batch statistics + backward) is SURVEY.md section 8f rank 1")
+        bn = self.bn_layer
+        # flattened feature index of (k, d) is d*K + k  (kw_bn.py:122-131: permute(0,2,1).reshape(B,-1))
+        K, D = self.kw_num, self.kw_dim
+        scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).view(D, K).t().contiguous().float()
+        shift = (bn.bias - bn.running_mean * (bn.weight / torch.sqrt(bn.running_var + bn.eps))).view(D, K).t().contiguous().float()
+        return ops.kw_affine(keywords, scale.detach(), shift.detach())

@@ -98,7 +98,7 @@ def wave_layernorm(wav, lens_i32, eps=1e-5):
     return out
 
 
-def attention(qkv, B, T, H, klens_i32=None, out=None, scale=None):
+def attention(qkv, B, T, H, klens_i32=None, out=None, scale=None, causal=False):
     """qkv: bf16 [B*T, 3*H*64] packed (q|k|v); returns bf16 [B*T, H*64]."""
     _need_cuda(qkv)
     D = H * 64
@@ -107,7 +107,7 @@ def attention(qkv, B, T, H, klens_i32=None, out=None, scale=None):
         out = torch.empty(B * T, D, device=qkv.device, dtype=bf16)
     esz = 2
     check(lib().sc_attention_fwd(qkv.data_ptr(), qkv.data_ptr() + D * esz, qkv.data_ptr() + 2 * D * esz, ptr(out), ptr(klens_i32),
-                                 B, H, T, 64, 3 * D, D, 0.125 if scale is None else scale, stream()), "sc_attention_fwd")
+                                 B, H, T, 64, 3 * D, D, 0.125 if scale is None else scale, int(causal), stream()), "sc_attention_fwd")
     return out
 
 
@@ -122,14 +122,15 @@ def cls_attention(cls_qkv, kv_x, lens_i32, B, T, NQ, H, hd):
     return out
 
 
-def conv0(wav, w, T0, P, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5):
+def conv0(wav, w, T0, P, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5, out=None):
     """HuBERT conv layer 0.  wav f32 [B, L]; w f32 [C, 10].  GroupNorm+GELU if gn_gamma given, else raw conv + bias.
     Returns channels-last bf16 [B, P, C] (+ (k-s) slack rows so the next conv-as-GEMM may over-read)."""
     _need_cuda(wav, w)
     B, L = wav.shape
     C = w.shape[0]
     assert wav.dtype == torch.float32 and wav.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
-    buf = torch.zeros(B * P + 8, C, device=wav.device, dtype=bf16)
+    buf = out if out is not None else torch.zeros(B * P + 8, C, device=wav.device, dtype=bf16)
+    assert buf.dtype == bf16 and buf.is_contiguous() and buf.shape[0] >= B * P and buf.shape[1] == C
     if gn_gamma is not None:
         ws = torch.empty(lib().sc_conv0_stats_workspace_bytes(B), device=wav.device, dtype=torch.uint8)
         coef = torch.empty(B, C, 2, device=wav.device, dtype=torch.float32)
@@ -184,4 +185,52 @@ def infonce(feat_a, feat_b, ids=None, inv_temperature=1.0 / 0.07, margin=0.0, dc
     out = torch.empty(3, device=feat_a.device, dtype=torch.float32)
     check(lib().sc_infonce_fwd(ptr(feat_a), ptr(feat_b), ptr(ids), ptr(ws), ptr(out), Bg, E, inv_temperature, margin, int(dcl), int(a2b),
                                int(b2a), stream()), "sc_infonce_fwd")
+    return out
+
+
+def kw_affine(x, scale, shift):
+    """x f32 [B,K,D]; scale/shift f32 [K,D]."""
+    _need_cuda(x)
+    B, K, D = x.shape
+    x = x.float().contiguous()
+    out = torch.empty_like(x)
+    check(lib().sc_kw_affine(ptr(x), ptr(scale.to(x.device)), ptr(shift.to(x.device)), ptr(out), B * K, K, D, stream()), "sc_kw_affine")
+    return out
+
+
+def cosine_scores(a, emb, eps=1e-8):
+    """a f32 [R,E], emb f32 [V,E] -> f32 [R,V] cosine similarities."""
+    _need_cuda(a, emb)
+    a, emb = a.float().contiguous(), emb.detach().float().contiguous()
+    R, E = a.shape
+    V = emb.shape[0]
+    ws = torch.empty(lib().sc_cosine_workspace_bytes(R, V), device=a.device, dtype=torch.uint8)
+    out = torch.empty(R, V, device=a.device, dtype=torch.float32)
+    check(lib().sc_cosine_scores(ptr(a), ptr(emb), ptr(ws), ptr(out), R, V, E, eps, stream()), "sc_cosine_scores")
+    return out
+
+
+def vq_fwd(scores, K, mask_ids=(0, 2, 3)):
+    """scores f32 [R,V] -> (targets i64 [R], stats f32 [2] = (code_perplexity, prob_perplexity), ent_per_t f32 [K])."""
+    import ctypes
+    _need_cuda(scores)
+    scores = scores.float().contiguous()
+    R, V = scores.shape
+    dev = scores.device
+    targets = torch.empty(R, device=dev, dtype=torch.int64)
+    stats = torch.empty(2, device=dev, dtype=torch.float32)
+    ent = torch.empty(K, device=dev, dtype=torch.float32)
+    ws = torch.empty(lib().sc_vq_workspace_bytes(R, V), device=dev, dtype=torch.uint8)
+    ids = (ctypes.c_int32 * len(mask_ids))(*[int(i) for i in mask_ids])
+    check(lib().sc_vq_fwd(ptr(scores), ptr(targets), ptr(stats), ptr(ent), ptr(ws), R, K, V, ctypes.cast(ids, ctypes.c_void_p), len(mask_ids),
+                          stream()), "sc_vq_fwd")
+    return targets, stats, ent
+
+
+def gather_rows(src, idx):
+    _need_cuda(src, idx)
+    src = src.detach().float().contiguous()
+    idx = idx.to(torch.int64).contiguous()
+    out = torch.empty(idx.shape[0], src.shape[1], device=src.device, dtype=torch.float32)
+    check(lib().sc_gather_rows(ptr(src), ptr(idx), ptr(out), idx.shape[0], src.shape[1], stream()), "sc_gather_rows")
     return out
