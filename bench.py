@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- speech-image pairs/s of the Parallel SpeechCLIP base forward + InfoNCE step on MI355X.
+
+Workload (BASELINE.json configs[1] / SURVEY.md section 8d "C2"): HuBERT-base + CLIP ViT-B/32 + parallel CLS head, bf16 MFMA
+compute, per-GPU batch 256, every wave exactly 160000 samples (10 s @ 16 kHz => T = 499), 224^2 images, unique ids,
+random-init weights (no network), synthetic inputs resident in HBM before the timed region.  One "step" = the full
+forward of both towers + head + L2 norms + (N > 1: RCCL all-gather of the embeddings) + masked InfoNCE on the global batch.
+N > 1: one process per GPU (torchrun), weak scaling (256 pairs per GPU), value = all pairs / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
+  "roofline":     dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of all its launches / their HIP-event time
+  "cpu_baseline": the fp32 CPU oracle (oracle/, a port of the reference's CPU path) timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md
+
+
+def conv_lens(L):
+    out = []
+    for k, s in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
+        L = (L - k) // s + 1
+        out.append(L)
+    return out
+
+
+def algorithmic_gflop_per_pair(L=160000, d=768, ffn=3072, layers=12, vit_w=768, vit_layers=12, patch=32, res=224, E=512):
+    """SURVEY.md section 8(d) formulas (2*MACs of the dense contractions; softmax/LN/GELU excluded)."""
+    Ts = conv_lens(L)
+    T = Ts[-1]
+    cnn0 = 2 * Ts[0] * 512 * 1 * 10
+    cnn = sum(2 * Ts[i] * 512 * 512 * k for i, k in zip(range(1, 7), [3, 3, 3, 3, 2, 2]))
+    proj = 2 * T * 512 * d
+    pos = 2 * T * d * (d // 16) * 128
+    lin = layers * 2 * T * (4 * d * d + 2 * d * ffn)
+    att = layers * 4 * T * T * d
+    n = (res // patch) ** 2 + 1
+    vit_lin = 2 * (n - 1) * 3 * patch * patch * vit_w + vit_layers * 2 * n * (4 * vit_w * vit_w + 8 * vit_w * vit_w) + 2 * vit_w * E
+    vit_att = vit_layers * 4 * n * n * vit_w
+    branch_lin = 2 * (T + 1) * d * 2 * d + 2 * (d * d + d * d + 2 * d * ffn) + 2 * d * E   # K/V of all frames + CLS-row-only rest
+    branch_att = 4 * (T + 1) * d
+    gemm = cnn + proj + pos + lin + vit_lin + branch_lin
+    total = gemm + cnn0 + att + vit_att + branch_att
+    return total / 1e9, gemm / 1e9
+
+
+def build_model(seed=7122):
+    from helpers import make_config
+    from speechclip_amd.model import KWClip_GeneralTransformer
+    torch.manual_seed(seed)
+    return KWClip_GeneralTransformer(make_config()).eval()
+
+
+def cpu_baseline(model_sd, n_pairs, L):
+    """fp32 CPU oracle (port of the reference's CPU path) on n_pairs of the same workload, all host cores."""
+    from oracle.clip_ref import ClipRefConfig
+    from oracle.hubert_ref import HubertRefConfig
+    from oracle.speechclip_ref import SpeechClipRef
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ref = SpeechClipRef(HubertRefConfig.base(), ClipRefConfig.vit_b32(), parallel=True, branch_heads=8).eval()
+    ref.encoder.load_state_dict({k[len("audio_encoder.encoder."):]: v for k, v in model_sd.items() if k.startswith("audio_encoder.encoder.")})
+    ref.clip.load_state_dict({k[len("clip.model."):]: v for k, v in model_sd.items() if k.startswith("clip.model.")})
+    ref.parallel_branch.load_state_dict({k[len("parallel_branch."):]: v for k, v in model_sd.items() if k.startswith("parallel_branch.")})
+    g = torch.Generator().manual_seed(7122)
+
+    def mk(b):
+        return {"wav": 0.1 * torch.randn(b, L, generator=g), "wav_len": torch.full((b,), L), "image": torch.randn(b, 3, 224, 224, generator=g),
+                "id": torch.arange(b)}
+    with torch.no_grad():
+        ref.compute_loss(ref(mk(1)))                         # warm-up
+        t0 = time.perf_counter()
+        o = ref(mk(n_pairs))
+        loss = ref.compute_loss(o)["loss"].item()
+        dt = time.perf_counter() - t0
+    return {"value": n_pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n_pairs} pairs (10 s audio + 224^2 image) through oracle/speechclip_ref.py fp32, {dt:.1f} s, loss {loss:.4f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
+    ap.add_argument("--audio-len", type=int, default=160000)
+    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs for the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+
+    from speechclip_amd import ops, parallel
+    model = build_model()
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_pairs > 0 and world == 1) else None
+    model = model.to(dev)
+    B, L = args.batch, args.audio_len
+    g = torch.Generator(device="cpu").manual_seed(7122 + rank)
+    wav = (0.1 * torch.randn(B, L, generator=g)).to(dev)
+    batch = {"wav": wav, "wav_len": torch.full((B,), L, dtype=torch.long), "image": torch.randn(B, 3, 224, 224, generator=g).to(dev),
+             "id": (torch.arange(B) + rank * B).to(dev)}
+
+    def step():
+        with torch.no_grad():
+            lf, _, _ = model(batch)
+            return model.compute_loss(parallel.gather_loss_feats(lf))["loss"]
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    ops.PROFILE = None if args.no_roofline_events else []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    pairs_per_s = world * B * args.steps / dt
+    total_gf, gemm_gf = algorithmic_gflop_per_pair(L)
+    if rank == 0:
+        roof = None
+        if prof:
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+            launches = len(prof)
+            alg = gemm_gf * 1e9 * B * args.steps               # algorithmic GEMM FLOPs of this rank's launches
+            ach = alg / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all launches of the step)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": launches // args.steps,
+                    "avg_launch_ms": round(ms / launches, 4), "gemm_ms_per_step": round(ms / args.steps, 3),
+                    "executed_over_algorithmic": round(sum(f for _, _, f in prof) / alg, 4)}
+        out = {"metric": "speech-image pairs/sec/node (Parallel SpeechCLIP base)", "value": round(pairs_per_s, 2), "unit": "pairs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "Parallel SpeechCLIP base (HuBERT-base + ViT-B/32) forward + InfoNCE, 10 s/16 kHz audio + 224^2 images",
+                          "pairs_per_gpu": B, "global_batch": world * B, "audio_samples": L, "frames": conv_lens(L)[-1],
+                          "parallelism": f"dp{world}" if world > 1 else "single", "weights": "random-init (no network)",
+                          "algorithmic_gflop_per_pair": round(total_gf, 2)},
+               "e2e_tflops_per_gpu": round(total_gf * 1e9 * pairs_per_s / world / 1e12, 1),
+               "e2e_frac_of_bf16_peak": round(total_gf * 1e9 * pairs_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+               "loss": round(float(loss), 5), "roofline": roof, "cpu_baseline": None}
+        if sd_cpu is not None:
+            del model
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(sd_cpu, args.cpu_pairs, L)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

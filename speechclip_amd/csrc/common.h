@@ -27,7 +27,7 @@ __device__ __forceinline__ float hi2f(uint32_t u) { return __uint_as_float(u & 0
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp + a handful of FMAs.
 __device__ __forceinline__ float fast_erf(float x) {
     float ax = fabsf(x);
-    float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float poly = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
     float r = 1.0f - poly * __expf(-ax * ax);
     return copysignf(r, x);
@@ -35,7 +35,7 @@ __device__ __forceinline__ float fast_erf(float x) {
 // exact-form GELU (erf), as torch.nn.functional.gelu / fairseq "gelu".
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
 // CLIP QuickGELU: x * sigmoid(1.702 x)
-__device__ __forceinline__ float quick_gelu(float x) { return x * __frcp_rn(1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

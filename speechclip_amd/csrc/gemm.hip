@@ -9,6 +9,7 @@
 // K-tile, XCD-aware tile order (all N-tiles of an M-panel run on one XCD so the A panel is an
 // L2 hit).  The MFMA is issued with W as the "A operand" so that each lane ends up holding four
 // consecutive output columns of one row => 8-byte epilogue stores.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/speechclip_hip.h"
 
@@ -23,6 +24,7 @@ struct GemmParams {
     int64_t M; int N; int K;
     int tiles_m; int tiles_n;
     int act; int out_f32;
+    unsigned long long* trace;   // debug: per-block s_memtime stamps (sc_debug_set_gemm_trace)
 };
 
 constexpr int BK = 64;  // 128 bytes of bf16 per tile row = 8 chunks of 16 B
@@ -156,6 +158,310 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v2: 256 x 256 x 64 tiles, 8 waves (2 x 4, wave tile 128 x 64), one resident block per CU.
+//  * 128^2 tiles need ~64 B/clk/CU from L2 at full MFMA rate (more than the chip delivers); 256^2 halves that.
+//  * operands arrive by LDS-DMA in FULL 128-byte rows (BK = 64; 64-byte rows measured ~25 % slower on the load path)
+//    into a 2-slot ring (2 x 64 KiB); chunk position p of row r holds k-chunk p ^ (r & 7) (swizzle on the source
+//    address), which makes the ds_read_b128 fragment reads conflict-free.
+//  * register software pipeline at half-step (32-deep) granularity: while the 32 MFMAs of one half issue, the
+//    fragments of the next half are read ({4 MFMA, 1 ds_read} x 8), so LDS latency never gates the matrix pipe.
+//    Slot t is completely in registers once its second half starts, so it is refilled (stage t+2) from the
+//    mid-step barrier: ONE raw s_barrier per 64-deep k-step, loads stay in flight across it (counted vmcnt).
+//  * epilogue: bias/activation in registers -> bf16 -> wave-private LDS image -> full-row 16-byte stores
+//    (the direct fragment-shaped store is 32 x 8-byte stores per lane touching 16 lines each: issue-bound).
+constexpr int BK2 = 64;
+constexpr int SLOT_BYTES = 2 * 256 * BK2 * 2;  // 64 KiB: A [256][128 B] then B [256][128 B]
+constexpr int EPI_STRIDE = 144;                // bytes per row of the wave-private epilogue image (64 bf16 + 16 B pad)
+
+struct StageAddr {          // per-thread source addressing of one tile: 2 pointers + 8 32-bit row offsets
+    const bf16_t* a; const bf16_t* w;
+    int aoff[4]; int woff[4];
+};
+
+__device__ __forceinline__ StageAddr stage_addr(const bf16_t* A, int64_t lda, int64_t m0, int64_t m_max, const bf16_t* W, int64_t ldw,
+                                                int n0, int n_max, int tid) {
+    StageAddr sa;
+    const int rb = tid >> 3, pp = tid & 7;
+    const int kc = (pp ^ (rb & 7)) << 3;       // (r & 7) is the same for the 4 rows r = i*64 + rb of this thread
+    int64_t r0 = m0 + rb; r0 = r0 < m_max ? r0 : m_max;
+    int64_t c0 = n0 + rb; c0 = c0 < n_max ? c0 : n_max;
+    sa.a = A + r0 * lda + kc;
+    sa.w = W + c0 * ldw + kc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int64_t r = m0 + i * 64 + rb; r = r < m_max ? r : m_max;
+        int64_t c = n0 + i * 64 + rb; c = c < n_max ? c : n_max;
+        sa.aoff[i] = (int)((r - r0) * lda);
+        sa.woff[i] = (int)((c - c0) * ldw);
+    }
+    return sa;
+}
+
+__device__ __forceinline__ void stage256(const StageAddr& sa, int k0, char* slot, int wave) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(sa.a + sa.aoff[i] + k0, slot + (i * 512 + wave * 64) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(sa.w + sa.woff[i] + k0, slot + 256 * 128 + (i * 512 + wave * 64) * 16);
+}
+
+template <int ABL, bool TRACE>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bf16_t* A = p.A;
+    const bf16_t* W = p.W;
+    const int nk = p.K / BK2;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int off_h0 = frow * 128 + ((fk ^ (frow & 7)) << 4);
+    const int off_h1 = frow * 128 + (((4 + fk) ^ (frow & 7)) << 4);
+    const int a_base = wm * 128 * 128;
+    const int b_base = 256 * 128 + wn * 64 * 128;
+    char* img = smem + 2 * SLOT_BYTES + wave * (16 * EPI_STRIDE);   // wave-private 16-row epilogue image
+    const bool vec_ok = !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!p.residual || p.ldr % 8 == 0);
+
+    // Persistent: one block per CU walks the tile list (a new 512-thread / 144 KiB block per tile costs several us of
+    // dispatch + an exposed prologue).  XCD-aware order: block b runs on XCD b % 8 and takes a contiguous chunk of the
+    // tile space, M-panel-major, so the N-tiles of one A panel are L2 hits on the same XCD.
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int G = gridDim.x;
+    auto tile_of = [&](int it, int& tm, int& tn) -> bool {   // it-th tile of this block
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot_in_xcd = bid >> 3;
+        const int nb_xcd = (G - xcd + 7) >> 3;                  // blocks living on this XCD
+        const int q = nwg >> 3, r8 = nwg & 7;
+        const int begin = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+        const int cnt = q + (xcd < r8 ? 1 : 0);
+        const int idx = it * nb_xcd + slot_in_xcd;
+        if (idx >= cnt) return false;
+        const int v = begin + idx;
+        tm = v / p.tiles_n;
+        tn = v - tm * p.tiles_n;
+        return true;
+    };
+
+    unsigned long long t_begin = TRACE ? __builtin_readcyclecounter() : 0, t_wait = 0, t_loop = 0, t_pre = 0;
+    int tm, tn;
+    bool have = tile_of(0, tm, tn);
+    StageAddr sa{};
+    if (have) {
+        sa = stage_addr(A, p.lda, (int64_t)tm * 256, p.M - 1, W, p.ldw, tn * 256, p.N - 1, tid);
+        stage256(sa, 0, smem, wave);
+        if (nk > 1) stage256(sa, BK2, smem + SLOT_BYTES, wave);
+    }
+    for (int it = 0; have; ++it) {
+        const int64_t m0 = (int64_t)tm * 256;
+        const int n0 = tn * 256;
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        bf16x8_t bfr[4], af[8];
+        // stage 0 of this tile (issued before the previous tile's epilogue) must have landed; stage 1 may still fly on
+        // the first tile only (afterwards the previous epilogue's stores sit behind it in the queue, so drain).
+        if (it == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (TRACE) { unsigned long long t = __builtin_readcyclecounter(); t_wait += t - t_begin; t_begin = t; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8_t*)(smem + b_base + off_h0 + j * 16 * 128);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8_t*)(smem + a_base + off_h0 + i * 16 * 128);
+
+        // One half-step: 32 MFMAs on (bfr, af) while the next half's fragments are read ({4 MFMA, 1 ds_read} x 8).  The B
+        // fragments of the next half go into bn right after the first MFMA group, so no LDS wait gates the group head.
+        auto half_step = [&](const char* src, int off, bool load_next) {
+            bf16x8_t bn[4];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    else asm volatile("" :: "v"(bfr[j]), "v"(af[i]));
+                }
+                if (load_next) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    af[i] = *(const bf16x8_t*)(src + a_base + off + i * 16 * 128);
+                    if (i < 4) bn[i] = *(const bf16x8_t*)(src + b_base + off + i * 16 * 128);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (load_next) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfr[j] = bn[j];
+            }
+        };
+        auto mid_sync = [&](int kt) {
+            // slot kt is entirely in registers; stage kt+1 must have landed before anyone reads it
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk && ABL != 1)
+                stage256(sa, (kt + 2) * BK2, smem + (kt & 1) * SLOT_BYTES, wave);
+        };
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const char* slot = smem + (kt & 1) * SLOT_BYTES;
+            const char* nslot = smem + ((kt + 1) & 1) * SLOT_BYTES;
+            half_step(slot, off_h1, true);      // MFMAs of (kt, h0); read (kt, h1)
+            mid_sync(kt);
+            half_step(nslot, off_h0, true);     // MFMAs of (kt, h1); read (kt+1, h0)
+        }
+        {   // last k-step (peeled: nothing left to prefetch after its first half)
+            const int kt = nk - 1;
+            half_step(smem + (kt & 1) * SLOT_BYTES, off_h1, true);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            half_step(nullptr, 0, false);
+        }
+        // bias for this lane's 4 x 4 output columns: loaded BEFORE the next tile's LDS-DMA is issued (an ordinary load
+        // issued behind the DMA would have to drain it first: vmcnt is in-order)
+        f32x4_t bias4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n0 + wn * 64 + j * 16 + fk * 4;
+            bias4[j] = (p.bias && nn < p.N) ? *(const f32x4_t*)(p.bias + nn) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        // ---- next tile's first two stages fly during this tile's epilogue (the slots are free after this barrier:
+        //      the epilogue uses its own 18 KiB image region)
+        if (TRACE) { unsigned long long t = __builtin_readcyclecounter(); t_loop += t - t_begin; t_begin = t; }
+        int ntm, ntn;
+        const bool nhave = tile_of(it + 1, ntm, ntn);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool early = nhave && !p.residual;
+        if (nhave) sa = stage_addr(A, p.lda, (int64_t)ntm * 256, p.M - 1, W, p.ldw, ntn * 256, p.N - 1, tid);
+        if (early) {
+            stage256(sa, 0, smem, wave);
+            if (nk > 1) stage256(sa, BK2, smem + SLOT_BYTES, wave);
+        }
+
+        if (TRACE) { unsigned long long t = __builtin_readcyclecounter(); t_pre += t - t_begin; t_begin = t; }
+        // ------------------------------------------------------------------------------------------ epilogue
+        if (vec_ok) {
+            const int rr = lane >> 3, cc = (lane & 7) * 8;        // 8 lanes cover one 128-byte output row segment
+            const int n = n0 + wn * 64 + cc;
+            bf16_t* Cb = (bf16_t*)p.C;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4_t v4 = acc[i][j];
+                    v4 += bias4[j];
+                    if (p.act == SC_ACT_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v4[r] = gelu_erf(v4[r]);
+                    } else if (p.act == SC_ACT_QUICKGELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
+                    }
+                    uint2 o;
+                    o.x = pack2bf(v4[0], v4[1]);
+                    o.y = pack2bf(v4[2], v4[3]);
+                    *(uint2*)(img + frow * EPI_STRIDE + (j * 16 + fk * 4) * 2) = o;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private image: no block barrier needed
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = h * 8 + rr;
+                    const int64_t m = m0 + wm * 128 + i * 16 + row;
+                    uint4 o = *(const uint4*)(img + row * EPI_STRIDE + cc * 2);
+                    if (m < p.M && n < p.N) {
+                        if (p.residual) {
+                            const uint4 rv = *(const uint4*)((const bf16_t*)p.residual + m * p.ldr + n);
+                            o.x = pack2bf(lo2f(o.x) + lo2f(rv.x), hi2f(o.x) + hi2f(rv.x));
+                            o.y = pack2bf(lo2f(o.y) + lo2f(rv.y), hi2f(o.y) + hi2f(rv.y));
+                            o.z = pack2bf(lo2f(o.z) + lo2f(rv.z), hi2f(o.z) + hi2f(rv.z));
+                            o.w = pack2bf(lo2f(o.w) + lo2f(rv.w), hi2f(o.w) + hi2f(rv.w));
+                        }
+                        *(uint4*)(Cb + m * p.ldc + n) = o;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image rows are rewritten by the next i
+            }
+        } else {
+            char* Cb = (char*)p.C;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t m = m0 + wm * 128 + i * 16 + frow;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + j * 16 + fk * 4;
+                    if (n >= p.N) continue;
+                    f32x4_t v4 = acc[i][j];
+                    v4 += bias4[j];
+                    if (p.act == SC_ACT_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v4[r] = gelu_erf(v4[r]);
+                    } else if (p.act == SC_ACT_QUICKGELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
+                    }
+                    if (p.out_f32) {
+                        if (p.residual) v4 += *(const f32x4_t*)((const float*)p.residual + m * p.ldr + n);
+                        *(f32x4_t*)((float*)Cb + m * p.ldc + n) = v4;
+                    } else {
+                        if (p.residual) {
+                            const uint2 rr2 = *(const uint2*)((const bf16_t*)p.residual + m * p.ldr + n);
+                            v4[0] += lo2f(rr2.x); v4[1] += hi2f(rr2.x); v4[2] += lo2f(rr2.y); v4[3] += hi2f(rr2.y);
+                        }
+                        uint2 o;
+                        o.x = pack2bf(v4[0], v4[1]);
+                        o.y = pack2bf(v4[2], v4[3]);
+                        *(uint2*)((bf16_t*)Cb + m * p.ldc + n) = o;
+                    }
+                }
+            }
+        }
+        if (nhave && !early) {
+            stage256(sa, 0, smem, wave);
+            if (nk > 1) stage256(sa, BK2, smem + SLOT_BYTES, wave);
+        }
+        have = nhave;
+        tm = ntm;
+        tn = ntn;
+        if (TRACE && tid == 0) {
+            unsigned long long t = __builtin_readcyclecounter();
+            unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
+            tr[0] = t_wait; tr[1] = t_loop; tr[2] = t_pre; tr[3] += t - t_begin; tr[4] = it + 1;
+            t_begin = t;
+        }
+    }
+}
+
+int launch256(const GemmParams& p, hipStream_t s) {
+    constexpr int lds = 2 * SLOT_BYTES + 8 * 16 * EPI_STRIDE;   // 128 KiB operand ring + 18 KiB epilogue images
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    const char* abl = getenv("SC_GEMM_ABL");   // experiment switch: 1 = no LDS-DMA in the main loop, 2 = no MFMA
+    if (p.trace) hipLaunchKernelGGL((gemm256_kernel<0, true>), dim3(grid), dim3(512), lds, s, p);
+    else if (abl && abl[0] == '1') hipLaunchKernelGGL((gemm256_kernel<1, false>), dim3(grid), dim3(512), lds, s, p);
+    else if (abl && abl[0] == '2') hipLaunchKernelGGL((gemm256_kernel<2, false>), dim3(grid), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((gemm256_kernel<0, false>), dim3(grid), dim3(512), lds, s, p);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int BM, int BN>
 int launch(const GemmParams& p, int batch, hipStream_t s) {
     constexpr int lds = 2 * (BM + BN) * 128;
@@ -177,6 +483,13 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
     SC_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0 && p.ldc % 4 == 0, "sc_gemm: lda/ldw must be multiples of 8, ldc of 4");
     SC_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && ((uintptr_t)p.C & 15) == 0,
                  "sc_gemm: A/W/C must be 16-byte aligned");
+    if (batch == 1 && p.N >= 256 && p.K % 64 == 0) {
+        const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+        if (t256 >= 192 && !getenv("SC_GEMM_V1")) {
+            p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (p.N + 255) / 256;
+            return launch256(p, s);
+        }
+    }
     if (p.N <= 64) {
         p.tiles_m = (int)((p.M + 127) / 128); p.tiles_n = (p.N + 63) / 64;
         return launch<128, 64>(p, batch, s);
@@ -186,6 +499,9 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
 }
 
 }  // namespace
+
+static unsigned long long* g_gemm_trace = nullptr;
+extern "C" void sc_debug_set_gemm_trace(void* dev_buf) { g_gemm_trace = (unsigned long long*)dev_buf; }
 
 extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                             const float* bias, const void* residual, int64_t ldr, int64_t M, int N, int K,
@@ -197,6 +513,7 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     p.bias = bias; p.residual = residual; p.ldr = ldr;
     p.M = M; p.N = N; p.K = K;
     p.act = flags & SC_GEMM_ACT_MASK; p.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0;
+    p.trace = g_gemm_trace;
     return gemm_dispatch(p, 1, (hipStream_t)stream);
 }
 

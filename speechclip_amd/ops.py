@@ -12,6 +12,10 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, GEMM_OUT_F32, check, lib, p
 
 bf16 = torch.bfloat16
 
+# Optional HIP-event instrumentation of the dominant kernel (bench.py roofline leg): when PROFILE is a list, every
+# sc_gemm_bf16 launch appends (start_event, end_event, flops) recorded on the launch stream.
+PROFILE = None
+
 
 def _need_cuda(*ts):
     for t in ts:
@@ -37,15 +41,27 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if residual is not None:
         assert residual.dtype == out.dtype and residual.stride(-1) == 1
     flags = act | (GEMM_OUT_F32 if out_f32 else 0)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().sc_gemm_bf16(ptr(a), lda, ptr(w), w.stride(0), ptr(out), out.stride(-2), ptr(bias), ptr(residual),
                              residual.stride(-2) if residual is not None else 0, M, N, K, flags, stream()), "sc_gemm_bf16")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * M * N * K))
     return out
 
 
 def gemm_batched(a, lda, stride_a, w, stride_w, w_mod, out, ldc, stride_c, bias, M, N, K, batch, act=ACT_NONE):
     _need_cuda(a, w, out)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().sc_gemm_bf16_batched(ptr(a), lda, stride_a, ptr(w), K, stride_w, w_mod, ptr(out), ldc, stride_c, ptr(bias),
                                      M, N, K, batch, act, stream()), "sc_gemm_bf16_batched")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * M * N * K * batch))
     return out
 
 

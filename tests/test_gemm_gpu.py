@@ -57,3 +57,21 @@ def test_gemm_transpose_detecting():
     w = (torch.arange(128 * 128, device="cuda").reshape(128, 128) % 251).to(torch.bfloat16)
     y = ops.gemm(a, w)
     torch.testing.assert_close(y.float(), w.float().t())
+
+
+@pytest.mark.parametrize("M,N,K,lda", [(20001, 768, 768, None), (16390, 1028, 128, None), (33000, 512, 1536, 1024), (25000, 2304, 64, None)])
+@pytest.mark.parametrize("act,f32", [(0, False), (1, False), (2, True)])
+def test_gemm_256_tile_kernel(M, N, K, lda, act, f32):
+    """Shapes large enough (>= 192 256x256 tiles) to take the 4-slot-ring 256^2 kernel; M/N tails; overlapping rows."""
+    from speechclip_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    ld = lda or K
+    flat = (torch.randn(M * ld + K + 8, generator=g) * 0.5).to("cuda", torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16)
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to("cuda", torch.float32 if f32 else torch.bfloat16)
+    y = ops.gemm(flat, w, bias, act, res, out_f32=f32, M=M, K=K, lda=ld)
+    a = torch.as_strided(flat, (M, K), (ld, 1))
+    ref = _ref(a, w, bias, act, res)
+    tol = 2e-3 if f32 else 2e-2
+    torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Per-shape GEMM microbenchmark on the shapes of the P-base step (B=256): TFLOP/s from HIP events, random bf16 operands."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from speechclip_amd import ops
+
+SHAPES = [  # name, M, N, K, lda (None = K), act
+    ("qkv", 128000, 2304, 768, None, 0), ("out", 128000, 768, 768, None, 0), ("fc1", 128000, 3072, 768, None, 1),
+    ("fc2", 128000, 768, 3072, None, 0), ("proj", 128000, 768, 512, None, 0),
+    ("conv1", 4096000, 512, 1536, 1024, 1), ("conv2", 2048000, 512, 1536, 1024, 1), ("conv4", 512000, 512, 1536, 1024, 1),
+    ("conv5", 256000, 512, 1024, 1024, 1), ("vit_fc1", 12800, 3072, 768, None, 2), ("sq8k", 8192, 8192, 8192, None, 0),
+]
+
+
+def main():
+    only = sys.argv[1:] 
+    res = {}
+    for name, M, N, K, lda, act in SHAPES:
+        if only and name not in only:
+            continue
+        lda_ = lda or K
+        a = (torch.randn(M * lda_ + K + 64, device="cuda") * 0.5).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device="cuda")
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        for _ in range(2):
+            ops.gemm(a, w, bias, act, out=out, M=M, K=K, lda=lda_)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            ops.gemm(a, w, bias, act, out=out, M=M, K=K, lda=lda_)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+        res[name] = round(tf, 1)
+        print(f"{name:8s} M={M:8d} N={N:5d} K={K:5d} lda={lda_:5d}  {ms:8.3f} ms  {tf:7.1f} TF/s", flush=True)
+        del a, w, out
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
