@@ -1,0 +1,208 @@
+"""CPU tests (no GPU, no /root/reference): host-side logic of the product, the C-ABI surface, and the N > 1 exchange step
+over gloo with world_size 2."""
+import ctypes
+import os
+import pickle
+import socket
+from argparse import Namespace
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_config
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# --------------------------------------------------------------------------------------------------- C ABI
+def test_abi_library_loads_and_exports_every_declared_symbol():
+    from speechclip_amd import _lib
+    L = _lib.lib()                       # raises if the .so is missing: no fallback
+    names = _lib.exported_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/speechclip_hip.h but not exported"
+    assert L.sc_abi_version() == 1
+    assert isinstance(L.sc_last_error(), bytes)
+
+
+def test_abi_argument_errors_are_codes_not_crashes():
+    """Bad arguments return a negative code + message before any launch (no GPU needed)."""
+    from speechclip_amd import _lib
+    L = _lib.lib()
+    rc = L.sc_gemm_bf16(None, 0, None, 0, None, 0, None, None, 0, 16, 16, 48, 0, None)      # K not a multiple of 64
+    assert rc < 0 and b"K=48" in L.sc_last_error()
+    rc = L.sc_attention_fwd(None, None, None, None, None, 1, 1, 8, 96, 8, 8, ctypes.c_float(1.0), 0, None)
+    assert rc < 0 and b"head_dim" in L.sc_last_error()
+    rc = L.sc_layernorm(None, 0, None, None, None, 0, 4, 2048, ctypes.c_float(1e-5), 0, None)
+    assert rc < 0 and b"D=2048" in L.sc_last_error()
+
+
+def test_product_refuses_cpu_tensors():
+    from speechclip_amd import ops
+    from speechclip_amd._lib import SpeechClipHipError
+    with pytest.raises(SpeechClipHipError):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16))
+
+
+# --------------------------------------------------------------------------------------------------- config object
+def test_ordered_namespace_semantics():
+    """Behaviour pinned by the reference's test/test_dict.py (restated)."""
+    from speechclip_amd.base import OrderedNamespace
+    d = {"a": 1, "b": [2, {"c": 3}], "d": {"e": 4, "f": "g"}, "h": SimpleNamespace(i=5, j={"k": 6})}
+    x, y = OrderedNamespace(d), OrderedNamespace(**d)
+    assert x.a == x["a"] == 1 and x.b[0] == 2 and x.b[1].c == 3 and x.d.e == x["d"]["e"] == x.d["e"] == 4
+    assert x.h.i == 5 and x.h.j.k == 6 and x == y and len(x) == 4 and "a" in x and len(x.keys()) == 4
+    assert isinstance(x.pydict, dict) and isinstance(x.odict, OrderedDict) and x.to_dict() == x.pydict and x.keys() == x.pydict.keys()
+    assert OrderedNamespace({"a": 1, "b": 2}) == OrderedNamespace(SimpleNamespace(a=1, b=2)) == OrderedNamespace(Namespace(a=1, b=2))
+    m = OrderedNamespace([{"a": 1, "c": {"d": 3}}, Namespace(e=4, f=SimpleNamespace(g=5))])
+    assert m.a == 1 and m.c.d == 3 and m.e == 4 and m.f.g == 5 and m.f["g"] == 5
+    assert m.get("zz", 7) == 7 and not hasattr(m, "zz")
+    m.new = 3
+    assert m["new"] == 3 and dict(**m.c) == {"d": 3}
+    z = pickle.loads(pickle.dumps(x))
+    assert z == x and z.d.f == "g"
+    import avssl.base
+    assert avssl.base.OrderedNamespace is OrderedNamespace
+
+
+def test_keypadding_mask_golden():
+    from speechclip_amd.util import get_keypadding_mask
+    g = np.load(os.path.join(GOLD, "small_ops.npz"))
+    m = get_keypadding_mask(10, torch.from_numpy(g["kpm_lens"]))
+    assert m.dtype == torch.bool and np.array_equal(m.numpy(), g["kpm_mask"])
+
+
+# --------------------------------------------------------------------------------------------------- HuBERT host geometry
+def test_frame_geometry_and_masks_match_reference_table():
+    """feat_len (round-half-even, clamp T) and the fairseq chunk-`all` frame mask, against values produced by the reference glue."""
+    from speechclip_amd.module.hubert import HubertConfig, HubertModel
+    tab = np.load(os.path.join(GOLD, "feat_len.npz"))["table"]
+    m = HubertModel(HubertConfig(encoder_layers=1, encoder_embed_dim=64, encoder_ffn_embed_dim=64, encoder_attention_heads=1,
+                                 conv_layers=[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)] * 2, conv_pos=16, conv_pos_groups=4))
+    for lmax, l, T, flen, nvalid in tab.tolist():
+        T0, Tg, P0, Tp = m.frame_geometry(lmax)
+        assert Tg == T and Tp >= T and P0 % 64 == 0 and P0 >= T0 and P0 // 64 == Tp
+        assert m.valid_frames([l], lmax, T)[0] == nvalid
+        assert min(round(l / 320), T) == flen
+
+
+def test_state_dict_keys_match_fairseq_and_openai_names():
+    """Same key sets as the oracle's fairseq-/openai-named restatements => reference checkpoints load by name."""
+    import dataclasses
+    from oracle.clip_ref import ClipRef, ClipRefConfig
+    from oracle.hubert_ref import HubertModelRef, HubertRefConfig
+    from speechclip_amd.module.clip_model import CLIP, ClipConfig
+    from speechclip_amd.module.hubert import HubertConfig, HubertModel
+    for large in (False, True):
+        rc = HubertRefConfig.tiny(layer_norm_first=large, extractor_mode="layer_norm" if large else "default", conv_bias=large)
+        ours = HubertModel(HubertConfig(**dataclasses.asdict(rc))).state_dict()
+        ref = HubertModelRef(rc).state_dict()
+        assert set(ours) == set(ref)
+        assert all(ours[k].shape == ref[k].shape for k in ref)
+    cc = ClipRefConfig.tiny()
+    ours, ref = CLIP(ClipConfig(**dataclasses.asdict(cc))).state_dict(), ClipRef(cc).state_dict()
+    assert set(ours) == set(ref) and all(ours[k].shape == ref[k].shape for k in ref)
+
+
+def test_model_surface_and_checkpoint_keys():
+    from speechclip_amd.model import KWClip_GeneralTransformer
+    import dataclasses
+    from oracle.clip_ref import ClipRefConfig
+    from oracle.hubert_ref import HubertRefConfig
+    from speechclip_amd.module.clip_model import ClipConfig
+    from speechclip_amd.module.hubert import HubertConfig
+    hc = HubertConfig(**dataclasses.asdict(HubertRefConfig.tiny()))
+    cc = ClipConfig(**dataclasses.asdict(ClipRefConfig.tiny()))
+    model = KWClip_GeneralTransformer(make_config(d_model=128, branch_heads=4, hubert_config=hc, clip_config=cc, parallel=True, cascaded=True))
+    keys = set(model.state_dict())
+    for k in ("audio_encoder.encoder.feature_extractor.conv_layers.0.0.weight", "audio_encoder.encoder.feature_extractor.conv_layers.0.2.weight",
+              "audio_encoder.encoder.encoder.pos_conv.0.weight_g", "audio_encoder.encoder.encoder.layers.1.self_attn.q_proj.weight",
+              "audio_encoder.weightedsum_layer.weights", "clip.model.visual.transformer.resblocks.0.attn.in_proj_weight",
+              "clip.model.visual.proj", "criterion.eye_mat", "parallel_branch.cls", "parallel_branch.self_att.model.layers.0.self_attn.in_proj_weight",
+              "parallel_branch.self_att.model.norm.weight", "parallel_branch.linear_proj.bias", "cascaded_branch.cls",
+              "cascaded_branch.self_att.multihead_attn_layer.in_proj_weight", "cascaded_branch.self_att.attentionBlock_Norm.weight",
+              "cascaded_branch.bn_layer.bn_layer.running_mean", "cascaded_branch.vector_quantizer.curr_temp",
+              "cascaded_branch.clip.model.ln_final.weight"):
+        assert k in keys, k
+    assert model.cascaded_branch.cls.shape == (1, 8, 128) and model.parallel_branch.cls.shape == (1, 1, 128)
+    for name in ("forward", "training_step", "training_step_end", "validation_step", "validation_step_end", "validation_epoch_end",
+                 "compute_loss", "encode_speech", "feature_extractor_s3prl", "forward_audio", "forward_image", "getTrainableParams",
+                 "configure_optimizers"):
+        assert callable(getattr(model, name))
+    with pytest.raises(ValueError):
+        model.forward_image(torch.zeros(2, 4, 8, 8))
+    with pytest.raises(TypeError):
+        model.forward_image("not a tensor")
+    opt, sched = model.configure_optimizers()
+    n_train = sum(p.numel() for p in model.getTrainableParams())
+    assert len(opt) == 1 and sched[0]["interval"] == "step" and n_train > 0
+    assert all(not p.requires_grad for p in model.audio_encoder.encoder.parameters())
+
+
+def test_mutual_retrieval_golden():
+    from speechclip_amd.module import mutualRetrieval
+    g = np.load(os.path.join(GOLD, "retrieval.npz"))
+    aud, img = torch.from_numpy(g["aud"]), torch.from_numpy(g["img"])
+    s = aud @ img.t()
+    ab, ba, mean = mutualRetrieval(s, s.t().contiguous(), torch.from_numpy(g["aud_ids"]), torch.from_numpy(g["img_ids"]), [1, 5, 10])
+    for i, k in enumerate((1, 5, 10)):
+        assert abs(ab[f"recall@{k}"] - g["recall_ab"][i]) < 1e-4 and abs(ba[f"recall@{k}"] - g["recall_ba"][i]) < 1e-4
+        assert abs(mean[f"recall@{k}"] - g["recall_mean"][i]) < 1e-4
+
+
+def test_bench_flop_model_matches_baseline_md():
+    import bench
+    total, gemm = bench.algorithmic_gflop_per_pair()
+    assert abs(total - 158.1) < 0.2        # BASELINE.md section 2, Parallel base at 10 s
+    assert bench.conv_lens(160000)[-1] == 499 and bench.conv_lens(102400)[-1] == 319 and bench.conv_lens(16000)[-1] == 49
+
+
+# --------------------------------------------------------------------------------------------------- N > 1 exchange step
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.speechclip_ref import masked_contrastive_loss
+    from speechclip_amd import parallel
+    g = torch.Generator().manual_seed(100 + rank)
+    B, E = 5, 16
+    feats = {"id": torch.tensor([7, 7, 3 + rank, 2 ** 40 + rank, -1 - rank]), "image_feat": torch.randn(B, E, generator=g),
+             "parallel_audio_feat": torch.randn(B, E, generator=g)}
+    out = parallel.gather_loss_feats(feats)
+    loss = masked_contrastive_loss(torch.nn.functional.normalize(out["parallel_audio_feat"], dim=-1),
+                                   torch.nn.functional.normalize(out["image_feat"], dim=-1), out["id"]).item()
+    q.put((rank, {k: v.clone() for k, v in out.items()}, {k: v.clone() for k, v in feats.items()}, loss))
+    dist.destroy_process_group()
+
+
+def test_gather_loss_feats_gloo_world2():
+    """Rank-major concat of every feature + bit-exact int64 ids over ONE collective; every rank sees the same global batch
+    (= DataParallel's dim-0 gather order), hence the same loss."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, out0, loc0, loss0), (_, out1, loc1, loss1) = res
+    for k in ("id", "image_feat", "parallel_audio_feat"):
+        assert torch.equal(out0[k], out1[k])
+        assert torch.equal(out0[k], torch.cat([loc0[k], loc1[k]], 0))
+    assert out0["id"].dtype == torch.int64 and abs(loss0 - loss1) < 1e-7
