@@ -66,8 +66,7 @@ def cpu_baseline(model_sd, n_pairs, L):
     from oracle.clip_ref import ClipRefConfig
     from oracle.hubert_ref import HubertRefConfig
     from oracle.speechclip_ref import SpeechClipRef
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     ref = SpeechClipRef(HubertRefConfig.base(), ClipRefConfig.vit_b32(), parallel=True, branch_heads=8).eval()
     ref.encoder.load_state_dict({k[len("audio_encoder.encoder."):]: v for k, v in model_sd.items() if k.startswith("audio_encoder.encoder.")})
     ref.clip.load_state_dict({k[len("clip.model."):]: v for k, v in model_sd.items() if k.startswith("clip.model.")})
@@ -77,14 +76,28 @@ def cpu_baseline(model_sd, n_pairs, L):
     def mk(b):
         return {"wav": 0.1 * torch.randn(b, L, generator=g), "wav_len": torch.full((b,), L), "image": torch.randn(b, 3, 224, 224, generator=g),
                 "id": torch.arange(b)}
+    # torch's CPU kernels do not scale to hundreds of threads on this workload (measured on the 2 x 64-core box: 16 threads beat
+    # 128 by 3.5x): pick the best of a few thread counts on a 2-pair probe, report the count actually used as `cores`.
+    best, cores = 0.0, 1
+    with torch.no_grad():
+        for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+            torch.set_num_threads(n)
+            ref(mk(1))
+            t0 = time.perf_counter()
+            ref(mk(2))
+            r = 2 / (time.perf_counter() - t0)
+            if r > best:
+                best, cores = r, n
+    torch.set_num_threads(cores)
     with torch.no_grad():
         ref.compute_loss(ref(mk(1)))                         # warm-up
         t0 = time.perf_counter()
         o = ref(mk(n_pairs))
         loss = ref.compute_loss(o)["loss"].item()
         dt = time.perf_counter() - t0
-    return {"value": n_pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{n_pairs} pairs (10 s audio + 224^2 image) through oracle/speechclip_ref.py fp32, {dt:.1f} s, loss {loss:.4f}"}
+    return {"value": round(n_pairs / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n_pairs} pairs (10 s audio + 224^2 image) through oracle/speechclip_ref.py fp32 with {cores} threads "
+                      f"(best of 8/16/32/64 on a probe; box has {ncpu} hw threads), {dt:.1f} s, loss {loss:.4f}"}
 
 
 def main():
@@ -94,7 +107,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
     ap.add_argument("--audio-len", type=int, default=160000)
-    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs for the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=32, help="pairs for the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-events", action="store_true")
     args = ap.parse_args()
 

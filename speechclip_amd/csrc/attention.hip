@@ -28,14 +28,20 @@ constexpr int VT_TILE_BYTES = 64 * VT_STRIDE;
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
                                                        const int32_t* __restrict__ klens, int T, int64_t ld_qkv,
-                                                       int64_t ld_out, float scale_log2e, int causal) {
+                                                       int64_t ld_out, float scale_log2e, int causal, int B, int H, int nq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kbuf = smem;                       // 2 x 8 KiB
     char* Vbuf = smem + 2 * K_TILE_BYTES;    // 2 x 8.5 KiB
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, h = blockIdx.y;
+    // XCD-aware 1-D grid: blocks id, id+8, id+16.. share an XCD (and its L2); the nq query blocks of one (b, h) unit are made
+    // consecutive on ONE XCD so K/V (128 KB per unit) is fetched from HBM once instead of once per query block.
+    const int id = blockIdx.x;
+    const int unit = ((id >> 3) / nq) * 8 + (id & 7);
+    const int qblk = (id >> 3) % nq;
+    if (unit >= H * B) return;
+    const int b = unit / H, h = unit - b * H;
     const int g = lane >> 5, ql = lane & 31;
     const int64_t row_base = (int64_t)b * T;
     const int hoff = h * 64;
@@ -44,11 +50,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     klen = klen < 0 ? 0 : (klen > T ? T : klen);
     int nkv = (klen + KV - 1) / KV;
     if (causal) {  // keys beyond the block's last query are never needed
-        const int last_q = min(T, (int)blockIdx.x * 128 + 128);
+        const int last_q = min(T, qblk * 128 + 128);
         nkv = min(nkv, (last_q + KV - 1) / KV);
     }
 
-    const int qrow = blockIdx.x * 128 + wave * 32 + ql;
+    const int qrow = qblk * 128 + wave * 32 + ql;
     const int qrow_c = qrow < T ? qrow : T - 1;
 
     // Q fragments: B operand of S^T (col = query, k-slots = 8 dims)
@@ -122,35 +128,58 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], s[kb], 0, 0, 0);
             }
         }
-        // ---- mask + online softmax (log2 domain)
+        // ---- mask + online softmax (log2 domain).  Only a tile that crosses the key length (or the causal diagonal)
+        //      pays for per-element masking; full tiles take the short path.
         float mx = -INFINITY;
         const int kv0 = j * KV;
+        const bool partial = (kv0 + KV > klen) || causal;
+        if (partial) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                float t = s[kb][r] * scale_log2e;
-                t = (key < klen && (!causal || key <= qrow)) ? t : -INFINITY;
-                s[kb][r] = t;
-                mx = fmaxf(mx, t);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    float t = s[kb][r] * scale_log2e;
+                    t = (key < klen && (!causal || key <= qrow)) ? t : -INFINITY;
+                    s[kb][r] = t;
+                    mx = fmaxf(mx, t);
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+            mx *= scale_log2e;   // scale > 0: max commutes with the scaling
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
         m_run = m_new;
         float psum = 0.f;
+        if (partial) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[kb][r] - m_new);
-                s[kb][r] = pv;
-                psum += pv;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+                    s[kb][r] = pv;
+                    psum += pv;
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], scale_log2e, -m_new));
+                    s[kb][r] = pv;
+                    psum += pv;
+                }
+        }
         l_run = l_run * alpha + psum;
+        if (alpha != 1.0f) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        }
         // ---- O^T += V^T . P^T
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
@@ -281,14 +310,16 @@ extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, voi
     SC_CHECK_ARG(head_dim == 64, "sc_attention_fwd: head_dim=%d unsupported (64 only; use sc_cls_attention_fwd for pooling heads)", head_dim);
     SC_CHECK_ARG(ld_qkv % 8 == 0 && ld_out % 4 == 0, "sc_attention_fwd: ld_qkv must be a multiple of 8, ld_out of 4");
     SC_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "sc_attention_fwd: misaligned pointers");
-    SC_CHECK_ARG(H <= 65535 && B <= 65535, "sc_attention_fwd: H/B exceed grid limits");
     if (B <= 0 || T <= 0) return 0;
     static bool attr = false;
     constexpr int lds = 2 * K_TILE_BYTES + 2 * VT_TILE_BYTES;
     if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    dim3 grid((T + 127) / 128, H, B);
+    const int nq = (T + 127) / 128;
+    const int64_t units8 = ((int64_t)H * B + 7) / 8;
+    SC_CHECK_ARG(units8 * 8 * nq < 0x7fffffff, "sc_attention_fwd: grid too large");
+    dim3 grid((unsigned)(units8 * 8 * nq));
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal);
+                       (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq);
     SC_CHECK_LAUNCH();
     return 0;
 }

@@ -175,38 +175,22 @@ constexpr int BK2 = 64;
 constexpr int SLOT_BYTES = 2 * 256 * BK2 * 2;  // 64 KiB: A [256][128 B] then B [256][128 B]
 constexpr int EPI_STRIDE = 144;                // bytes per row of the wave-private epilogue image (64 bf16 + 16 B pad)
 
-struct StageAddr {          // per-thread source addressing of one tile: 2 pointers + 8 32-bit row offsets
-    const bf16_t* a; const bf16_t* w;
-    int aoff[4]; int woff[4];
-};
+// Source addressing of one tile: two WAVE-UNIFORM tile base pointers (SGPRs) + two 32-bit per-lane offsets fixed for the whole
+// kernel.  (Per-lane 64-bit pointers kept across the tile were being spilled, and a scratch reload behind freshly issued LDS-DMA
+// forces vmcnt(0): it drained the prefetch.)
+// Tiles that would cross M (or N) are shifted back so that they END at M (N): every row of a tile is then in range, the row-group
+// offsets i*64*ld are uniform (no per-lane clamp), and the epilogue skips the rows / columns that belong to the previous tile.
+// Needs M >= 256 and N >= 256, which the dispatcher guarantees for this kernel.
+struct StageAddr { const bf16_t* ta; const bf16_t* tw; };
 
-__device__ __forceinline__ StageAddr stage_addr(const bf16_t* A, int64_t lda, int64_t m0, int64_t m_max, const bf16_t* W, int64_t ldw,
-                                                int n0, int n_max, int tid) {
-    StageAddr sa;
-    const int rb = tid >> 3, pp = tid & 7;
-    const int kc = (pp ^ (rb & 7)) << 3;       // (r & 7) is the same for the 4 rows r = i*64 + rb of this thread
-    int64_t r0 = m0 + rb; r0 = r0 < m_max ? r0 : m_max;
-    int64_t c0 = n0 + rb; c0 = c0 < n_max ? c0 : n_max;
-    sa.a = A + r0 * lda + kc;
-    sa.w = W + c0 * ldw + kc;
+__device__ __forceinline__ void stage256(const StageAddr& sa, int lane_a, int lane_w, int64_t lda64, int64_t ldw64, int k0, char* slot, int wave) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int64_t r = m0 + i * 64 + rb; r = r < m_max ? r : m_max;
-        int64_t c = n0 + i * 64 + rb; c = c < n_max ? c : n_max;
-        sa.aoff[i] = (int)((r - r0) * lda);
-        sa.woff[i] = (int)((c - c0) * ldw);
-    }
-    return sa;
+    for (int i = 0; i < 4; ++i) glds16(sa.ta + (i * lda64 + k0) + lane_a, slot + (i * 512 + wave * 64) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(sa.tw + (i * ldw64 + k0) + lane_w, slot + 256 * 128 + (i * 512 + wave * 64) * 16);
 }
 
-__device__ __forceinline__ void stage256(const StageAddr& sa, int k0, char* slot, int wave) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(sa.a + sa.aoff[i] + k0, slot + (i * 512 + wave * 64) * 16);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(sa.w + sa.woff[i] + k0, slot + 256 * 128 + (i * 512 + wave * 64) * 16);
-}
-
-template <int ABL, bool TRACE>
+template <int ABL, bool TRACE, int ACT, bool RES>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -221,8 +205,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int off_h1 = frow * 128 + (((4 + fk) ^ (frow & 7)) << 4);
     const int a_base = wm * 128 * 128;
     const int b_base = 256 * 128 + wn * 64 * 128;
-    char* img = smem + 2 * SLOT_BYTES + wave * (16 * EPI_STRIDE);   // wave-private 16-row epilogue image
-    const bool vec_ok = !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!p.residual || p.ldr % 8 == 0);
+    const bool vec_ok = !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!RES || p.ldr % 8 == 0);
 
     // Persistent: one block per CU walks the tile list (a new 512-thread / 144 KiB block per tile costs several us of
     // dispatch + an exposed prologue).  XCD-aware order: block b runs on XCD b % 8 and takes a contiguous chunk of the
@@ -245,17 +228,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     };
 
     unsigned long long t_begin = TRACE ? __builtin_readcyclecounter() : 0, t_wait = 0, t_loop = 0, t_pre = 0;
+    const int64_t lda64 = 64 * p.lda, ldw64 = 64 * p.ldw;
+    const int lane_a = (tid >> 3) * (int)p.lda + (((tid & 7) ^ ((tid >> 3) & 7)) << 3);   // row (tid>>3), swizzled k-chunk
+    const int lane_w = (tid >> 3) * (int)p.ldw + (((tid & 7) ^ ((tid >> 3) & 7)) << 3);
+    auto tile_m0 = [&](int t) -> int64_t { const int64_t m = (int64_t)t * 256; return m + 256 <= p.M ? m : p.M - 256; };
+    auto tile_n0 = [&](int t) -> int { const int n = t * 256; return n + 256 <= p.N ? n : p.N - 256; };
     int tm, tn;
     bool have = tile_of(0, tm, tn);
-    StageAddr sa{};
+    StageAddr sa{nullptr, nullptr};
     if (have) {
-        sa = stage_addr(A, p.lda, (int64_t)tm * 256, p.M - 1, W, p.ldw, tn * 256, p.N - 1, tid);
-        stage256(sa, 0, smem, wave);
-        if (nk > 1) stage256(sa, BK2, smem + SLOT_BYTES, wave);
+        sa = StageAddr{A + tile_m0(tm) * p.lda, W + (int64_t)tile_n0(tn) * p.ldw};
+        stage256(sa, lane_a, lane_w, lda64, ldw64, 0, smem, wave);
+        if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, BK2, smem + SLOT_BYTES, wave);
     }
     for (int it = 0; have; ++it) {
-        const int64_t m0 = (int64_t)tm * 256;
-        const int n0 = tn * 256;
+        const int64_t m0 = tile_m0(tm), m_lo = (int64_t)tm * 256;   // rows < m_lo belong to the previous tile
+        const int n0 = tile_n0(tn), n_lo = tn * 256;
         f32x4_t acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -277,7 +265,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 
         // One half-step: 32 MFMAs on (bfr, af) while the next half's fragments are read ({4 MFMA, 1 ds_read} x 8).  The B
         // fragments of the next half go into bn right after the first MFMA group, so no LDS wait gates the group head.
-        auto half_step = [&](const char* src, int off, bool load_next) {
+        auto half_step = [&](const char* src, int off, bool load_next, int dma_k0, char* dma_slot) {
             bf16x8_t bn[4];
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -291,6 +279,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                     af[i] = *(const bf16x8_t*)(src + a_base + off + i * 16 * 128);
                     if (i < 4) bn[i] = *(const bf16x8_t*)(src + b_base + off + i * 16 * 128);
+                    if (dma_k0 >= 0 && ABL != 1) {   // one LDS-DMA instruction per MFMA group instead of a burst behind the barrier
+                        int la = lane_a, lw = lane_w;
+                        asm volatile("" : "+v"(la), "+v"(lw));   // keep the 64-bit source addresses out of the loop-invariant set (VGPR pressure)
+                        if (i < 4) glds16(sa.ta + (i * lda64 + dma_k0) + la, dma_slot + (i * 512 + wave * 64) * 16);
+                        else glds16(sa.tw + ((i - 4) * ldw64 + dma_k0) + lw, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -305,21 +299,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + 2 < nk && ABL != 1)
-                stage256(sa, (kt + 2) * BK2, smem + (kt & 1) * SLOT_BYTES, wave);
         };
         for (int kt = 0; kt + 1 < nk; ++kt) {
             const char* slot = smem + (kt & 1) * SLOT_BYTES;
             const char* nslot = smem + ((kt + 1) & 1) * SLOT_BYTES;
-            half_step(slot, off_h1, true);      // MFMAs of (kt, h0); read (kt, h1)
+            half_step(slot, off_h1, true, -1, nullptr);      // MFMAs of (kt, h0); read (kt, h1)
             mid_sync(kt);
-            half_step(nslot, off_h0, true);     // MFMAs of (kt, h1); read (kt+1, h0)
+            // MFMAs of (kt, h1); read (kt+1, h0); refill slot kt with stage kt+2
+            half_step(nslot, off_h0, true, kt + 2 < nk ? (kt + 2) * BK2 : -1, smem + (kt & 1) * SLOT_BYTES);
         }
         {   // last k-step (peeled: nothing left to prefetch after its first half)
             const int kt = nk - 1;
-            half_step(smem + (kt & 1) * SLOT_BYTES, off_h1, true);
+            half_step(smem + (kt & 1) * SLOT_BYTES, off_h1, true, -1, nullptr);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            half_step(nullptr, 0, false);
+            half_step(nullptr, 0, false, -1, nullptr);
         }
         // bias for this lane's 4 x 4 output columns: loaded BEFORE the next tile's LDS-DMA is issued (an ordinary load
         // issued behind the DMA would have to drain it first: vmcnt is in-order)
@@ -327,7 +320,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nn = n0 + wn * 64 + j * 16 + fk * 4;
-            bias4[j] = (p.bias && nn < p.N) ? *(const f32x4_t*)(p.bias + nn) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            bias4[j] = p.bias ? *(const f32x4_t*)(p.bias + nn) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -338,72 +331,87 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const bool nhave = tile_of(it + 1, ntm, ntn);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const bool early = nhave && !p.residual;
-        if (nhave) sa = stage_addr(A, p.lda, (int64_t)ntm * 256, p.M - 1, W, p.ldw, ntn * 256, p.N - 1, tid);
+        const bool early = nhave && !RES;
+        if (nhave) sa = StageAddr{A + tile_m0(ntm) * p.lda, W + (int64_t)tile_n0(ntn) * p.ldw};
         if (early) {
-            stage256(sa, 0, smem, wave);
-            if (nk > 1) stage256(sa, BK2, smem + SLOT_BYTES, wave);
+            stage256(sa, lane_a, lane_w, lda64, ldw64, 0, smem, wave);
+            if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, BK2, smem + SLOT_BYTES, wave);
         }
 
         if (TRACE) { unsigned long long t = __builtin_readcyclecounter(); t_pre += t - t_begin; t_begin = t; }
         // ------------------------------------------------------------------------------------------ epilogue
         if (vec_ok) {
-            const int rr = lane >> 3, cc = (lane & 7) * 8;        // 8 lanes cover one 128-byte output row segment
-            const int n = n0 + wn * 64 + cc;
+            // Lane (frow, fk) holds row frow, columns 16j + 4fk .. +3 of each 16-column block j.  v_permlane16_swap between the
+            // 16-lane rows fk and fk^1 regroups a block PAIR (j0, j1) so that even-fk lanes own 8 consecutive columns of j0 and
+            // odd-fk lanes 8 consecutive columns of j1: one 16-byte store per lane per pair, no LDS round trip.
             bf16_t* Cb = (bf16_t*)p.C;
+            const int odd = fk & 1;
+            const int ncol0 = n0 + wn * 64 + (odd ? 16 + 4 * (fk - 1) : 4 * fk);   // pair 0 (blocks 0,1); pair 1 adds 32
+            // residual: rolling prefetch, two passes (4 x 16 B per lane) ahead of their use
+            auto load_res = [&](int i, uint4 (&dst)[2]) {
+                const int64_t m = m0 + wm * 128 + i * 16 + frow;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const int n = ncol0 + jp * 32;
+                    dst[jp] = (m >= m_lo && n >= n_lo) ? *(const uint4*)((const bf16_t*)p.residual + m * p.ldr + n) : make_uint4(0, 0, 0, 0);
+                }
+            };
+            uint4 res[3][2];
+            if (RES) { load_res(0, res[0]); load_res(1, res[1]); }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
+                const int64_t m = m0 + wm * 128 + i * 16 + frow;
+                if (RES && i + 2 < 8) load_res(i + 2, res[(i + 2) % 3]);
+                uint2 pk[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4_t v4 = acc[i][j];
                     v4 += bias4[j];
-                    if (p.act == SC_ACT_GELU) {
+                    if (ACT == SC_ACT_GELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[r] = gelu_erf(v4[r]);
-                    } else if (p.act == SC_ACT_QUICKGELU) {
+                    } else if (ACT == SC_ACT_QUICKGELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
                     }
-                    uint2 o;
-                    o.x = pack2bf(v4[0], v4[1]);
-                    o.y = pack2bf(v4[2], v4[3]);
-                    *(uint2*)(img + frow * EPI_STRIDE + (j * 16 + fk * 4) * 2) = o;
+                    pk[j].x = pack2bf(v4[0], v4[1]);
+                    pk[j].y = pack2bf(v4[2], v4[3]);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private image: no block barrier needed
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = h * 8 + rr;
-                    const int64_t m = m0 + wm * 128 + i * 16 + row;
-                    uint4 o = *(const uint4*)(img + row * EPI_STRIDE + cc * 2);
-                    if (m < p.M && n < p.N) {
-                        if (p.residual) {
-                            const uint4 rv = *(const uint4*)((const bf16_t*)p.residual + m * p.ldr + n);
+                for (int jp = 0; jp < 2; ++jp) {
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].x, pk[2 * jp + 1].x, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].y, pk[2 * jp + 1].y, false, false);
+                    uint4 o = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    const int n = ncol0 + jp * 32;
+                    if (m >= m_lo && n >= n_lo) {
+                        if (RES) {
+                            const uint4 rv = res[i % 3][jp];
                             o.x = pack2bf(lo2f(o.x) + lo2f(rv.x), hi2f(o.x) + hi2f(rv.x));
                             o.y = pack2bf(lo2f(o.y) + lo2f(rv.y), hi2f(o.y) + hi2f(rv.y));
                             o.z = pack2bf(lo2f(o.z) + lo2f(rv.z), hi2f(o.z) + hi2f(rv.z));
                             o.w = pack2bf(lo2f(o.w) + lo2f(rv.w), hi2f(o.w) + hi2f(rv.w));
                         }
-                        *(uint4*)(Cb + m * p.ldc + n) = o;
+                        if (ABL != 3) *(uint4*)(Cb + m * p.ldc + n) = o;
+                        else asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image rows are rewritten by the next i
             }
         } else {
             char* Cb = (char*)p.C;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int64_t m = m0 + wm * 128 + i * 16 + frow;
-                if (m >= p.M) continue;
+                if (m < m_lo) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int n = n0 + wn * 64 + j * 16 + fk * 4;
-                    if (n >= p.N) continue;
+                    if (n < n_lo) continue;
                     f32x4_t v4 = acc[i][j];
                     v4 += bias4[j];
-                    if (p.act == SC_ACT_GELU) {
+                    if (ACT == SC_ACT_GELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[r] = gelu_erf(v4[r]);
-                    } else if (p.act == SC_ACT_QUICKGELU) {
+                    } else if (ACT == SC_ACT_QUICKGELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
                     }
@@ -424,8 +432,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             }
         }
         if (nhave && !early) {
-            stage256(sa, 0, smem, wave);
-            if (nk > 1) stage256(sa, BK2, smem + SLOT_BYTES, wave);
+            stage256(sa, lane_a, lane_w, lda64, ldw64, 0, smem, wave);
+            if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, BK2, smem + SLOT_BYTES, wave);
         }
         have = nhave;
         tm = ntm;
@@ -439,27 +447,40 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     }
 }
 
-int launch256(const GemmParams& p, hipStream_t s) {
-    constexpr int lds = 2 * SLOT_BYTES + 8 * 16 * EPI_STRIDE;   // 128 KiB operand ring + 18 KiB epilogue images
+template <int ABL, bool TRACE, int ACT, bool RES>
+int launch256_one(const GemmParams& p, int grid, hipStream_t s) {
+    constexpr int lds = 2 * SLOT_BYTES;   // 128 KiB operand ring
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<ABL, TRACE, ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
+    hipLaunchKernelGGL((gemm256_kernel<ABL, TRACE, ACT, RES>), dim3(grid), dim3(512), lds, s, p);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int ABL, bool TRACE>
+int launch256_var(const GemmParams& p, int grid, hipStream_t s) {
+    const bool res = p.residual != nullptr;
+    switch (p.act) {
+        case SC_ACT_GELU: return res ? launch256_one<ABL, TRACE, SC_ACT_GELU, true>(p, grid, s) : launch256_one<ABL, TRACE, SC_ACT_GELU, false>(p, grid, s);
+        case SC_ACT_QUICKGELU: return res ? launch256_one<ABL, TRACE, SC_ACT_QUICKGELU, true>(p, grid, s) : launch256_one<ABL, TRACE, SC_ACT_QUICKGELU, false>(p, grid, s);
+        default: return res ? launch256_one<ABL, TRACE, SC_ACT_NONE, true>(p, grid, s) : launch256_one<ABL, TRACE, SC_ACT_NONE, false>(p, grid, s);
+    }
+}
+
+int launch256(const GemmParams& p, hipStream_t s) {
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     const int ntiles = p.tiles_m * p.tiles_n;
     const int grid = ntiles < n_cu ? ntiles : n_cu;
-    const char* abl = getenv("SC_GEMM_ABL");   // experiment switch: 1 = no LDS-DMA in the main loop, 2 = no MFMA
-    if (p.trace) hipLaunchKernelGGL((gemm256_kernel<0, true>), dim3(grid), dim3(512), lds, s, p);
-    else if (abl && abl[0] == '1') hipLaunchKernelGGL((gemm256_kernel<1, false>), dim3(grid), dim3(512), lds, s, p);
-    else if (abl && abl[0] == '2') hipLaunchKernelGGL((gemm256_kernel<2, false>), dim3(grid), dim3(512), lds, s, p);
-    else hipLaunchKernelGGL((gemm256_kernel<0, false>), dim3(grid), dim3(512), lds, s, p);
-    SC_CHECK_LAUNCH();
-    return 0;
+    const char* abl = getenv("SC_GEMM_ABL");   // experiment switches: 1 = no LDS-DMA in the main loop, 2 = no MFMA, 3 = no epilogue stores
+    if (p.trace && abl && abl[0] == '3') return launch256_var<3, true>(p, grid, s);
+    if (p.trace) return launch256_var<0, true>(p, grid, s);
+    if (abl && abl[0] == '1') return launch256_var<1, false>(p, grid, s);
+    if (abl && abl[0] == '2') return launch256_var<2, false>(p, grid, s);
+    return launch256_var<0, false>(p, grid, s);
 }
 
 template <int BM, int BN>
@@ -483,7 +504,7 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
     SC_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0 && p.ldc % 4 == 0, "sc_gemm: lda/ldw must be multiples of 8, ldc of 4");
     SC_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && ((uintptr_t)p.C & 15) == 0,
                  "sc_gemm: A/W/C must be 16-byte aligned");
-    if (batch == 1 && p.N >= 256 && p.K % 64 == 0) {
+    if (batch == 1 && p.N >= 256 && p.M >= 256 && p.K % 64 == 0) {
         const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         if (t256 >= 192 && !getenv("SC_GEMM_V1")) {
             p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (p.N + 255) / 256;
