@@ -270,10 +270,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
+                if (ABL == 4) {   // perf probe only (results are garbage): same operand traffic, half as many 32x32x16 MFMAs
+                    f32x16_t* a32 = (f32x16_t*)&acc[i][0];
+                    *a32 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[0], af[i], *a32, 0, 0, 0);
+                    *a32 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[2], af[i], *a32, 0, 0, 0);
+                    asm volatile("" :: "v"(bfr[1]), "v"(bfr[3]));
+                } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
                     else asm volatile("" :: "v"(bfr[j]), "v"(af[i]));
+                }
                 }
                 if (load_next) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -480,6 +487,7 @@ int launch256(const GemmParams& p, hipStream_t s) {
     if (p.trace) return launch256_var<0, true>(p, grid, s);
     if (abl && abl[0] == '1') return launch256_var<1, false>(p, grid, s);
     if (abl && abl[0] == '2') return launch256_var<2, false>(p, grid, s);
+    if (abl && abl[0] == '4') return launch256_var<4, false>(p, grid, s);
     return launch256_var<0, false>(p, grid, s);
 }
 

@@ -96,6 +96,63 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
     }
 }
 
+// Fast path for the hot shape (D = 768, bf16 -> bf16, affine): a wave owns TWO consecutive rows = 192 chunks of 16 B = exactly 3 chunks
+// per lane (16-byte loads/stores; chunk c = lane + 64*i belongs to row c / 96).  4 x this per step is 25 LayerNorms over [128000, 768].
+__global__ __launch_bounds__(256) void layernorm768_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           bf16_t* __restrict__ out, int64_t rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= rows) return;
+    const bool two = row0 + 1 < rows;
+    float v[3][8];
+    int rsel[3], col[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = lane + 64 * i;
+        rsel[i] = c >= 96;
+        col[i] = (c - rsel[i] * 96) * 8;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (!rsel[i] || two) u = *(const uint4*)(x + (row0 + rsel[i]) * 768 + col[i]);
+        v[i][0] = lo2f(u.x); v[i][1] = hi2f(u.x); v[i][2] = lo2f(u.y); v[i][3] = hi2f(u.y);
+        v[i][4] = lo2f(u.z); v[i][5] = hi2f(u.z); v[i][6] = lo2f(u.w); v[i][7] = hi2f(u.w);
+    }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += v[i][k];
+        if (rsel[i]) s1 += t; else s0 += t;
+    }
+    const float m0 = wave_sum(s0) * (1.0f / 768.0f), m1 = wave_sum(s1) * (1.0f / 768.0f);
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float mm = rsel[i] ? m1 : m0;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mm; t += d * d; }
+        if (rsel[i]) q1 += t; else q0 += t;
+    }
+    const float r0 = rsqrtf(wave_sum(q0) * (1.0f / 768.0f) + eps), r1 = rsqrtf(wave_sum(q1) * (1.0f / 768.0f) + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (rsel[i] && !two) continue;
+        const float mm = rsel[i] ? m1 : m0, rr = rsel[i] ? r1 : r0;
+        const f32x4_t g0 = *(const f32x4_t*)(gamma + col[i]), g1 = *(const f32x4_t*)(gamma + col[i] + 4);
+        const f32x4_t b0 = *(const f32x4_t*)(beta + col[i]), b1 = *(const f32x4_t*)(beta + col[i] + 4);
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[k] = (v[i][k] - mm) * rr * g0[k] + b0[k];
+            o[4 + k] = (v[i][4 + k] - mm) * rr * g1[k] + b1[k];
+        }
+        uint4 u;
+        u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]); u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+        *(uint4*)(out + (row0 + rsel[i]) * 768 + col[i]) = u;
+    }
+}
+
 // out[m,:] = sum_i softmax(w)_i * (normalize ? LN_noaffine(h_i[m,:]) : h_i[m,:])
 template <bool IN_F32>
 __global__ __launch_bounds__(256) void weighted_sum_kernel(const void* __restrict__ hidden, int64_t layer_stride, const float* __restrict__ w,
@@ -198,6 +255,11 @@ extern "C" int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, co
     dim3 grid((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int gelu = (flags & SC_LN_GELU) ? 1 : 0;
+    if (D == 768 && flags == 0 && gamma && ld_in == 768 && ld_out == 768 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(layernorm768_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, rows, eps);
+        SC_CHECK_LAUNCH();
+        return 0;
+    }
     const bool in32 = flags & SC_LN_IN_F32, out32 = flags & SC_LN_OUT_F32;
     if (in32 && out32) hipLaunchKernelGGL((layernorm_kernel<true, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
     else if (in32) hipLaunchKernelGGL((layernorm_kernel<true, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);

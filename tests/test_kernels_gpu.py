@@ -32,6 +32,16 @@ def test_layernorm(D, in_f32, out_f32, gelu, affine):
     torch.testing.assert_close(y.float(), ref, atol=tol, rtol=tol)
 
 
+def test_layernorm_768_fast_path_odd_rows():
+    from speechclip_amd import ops
+    g = _g(77)
+    for rows in (1, 2, 7, 1001):
+        x = (torch.randn(rows, 768, generator=g) * 3 - 1).to("cuda", BF)
+        gamma, beta = (1 + 0.3 * torch.randn(768, generator=g)).cuda(), (0.3 * torch.randn(768, generator=g)).cuda()
+        y = ops.layernorm(x, gamma, beta)
+        torch.testing.assert_close(y.float(), F.layer_norm(x.float(), (768,), gamma, beta, 1e-5), atol=2e-2, rtol=2e-2)
+
+
 def test_layernorm_strided_rows():
     from speechclip_amd import ops
     x = torch.randn(6, 5, 768, generator=_g(1)).cuda()
