@@ -75,6 +75,9 @@ __global__ __launch_bounds__(256) void conv0_coef_kernel(const double* __restric
 }
 
 // out[b][t][c] (channels-last bf16, P rows per utterance).  mode 0: GroupNorm coefficients + GELU; mode 1: raw conv + bias.
+// A lane owns 8 adjacent channels (held as 4 float2 so conv / normalise / GELU polynomial issue as v_pk_* ops), a wave one
+// frame at a time: one 16-byte store per lane = one full 1 KiB row per wave instruction, and the 10 broadcast LDS reads of
+// the frame's samples are shared by 8 channels.  The kernel is VALU-bound (the 8.4 GB output is 1.3 ms of HBM time).
 constexpr int TT = 64;
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ wav, int64_t ld, int64_t L, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float2* __restrict__ coef, bf16_t* __restrict__ out,
@@ -86,38 +89,48 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
         int64_t si = (int64_t)t0 * CS + i;
         xs[i] = si < L ? x[si] : 0.f;
     }
-    const int cpairs = C >> 1;
-    const int cp = tid % cpairs, fs = tid / cpairs, fpar = 256 / cpairs;
-    const int c0 = cp * 2;
-    // two adjacent channels per thread held as float2 so the conv / normalise / GELU polynomial issue as v_pk_* (the kernel is
-    // VALU-bound: 8.4 GB of output costs 1.3 ms of HBM time, the arithmetic more)
-    f32x2_t w2[CK];
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int cb = 0; cb < C; cb += 512) {            // C <= 512 in every shipped config: one pass
+        const int c0 = cb + lane * 8;
+        const bool active = c0 < C;
+        f32x2_t w2[4][CK], sc[4], sh[4];
 #pragma unroll
-    for (int j = 0; j < CK; ++j) w2[j] = (f32x2_t){w[c0 * CK + j], w[(c0 + 1) * CK + j]};
-    f32x2_t sc = {1.f, 1.f}, sh = {0.f, 0.f};
-    if (mode == 0) {
-        const float2 a = coef[(int64_t)b * C + c0], d = coef[(int64_t)b * C + c0 + 1];
-        sc = (f32x2_t){a.x, d.x}; sh = (f32x2_t){a.y, d.y};
-    } else if (bias) {
-        sh = (f32x2_t){bias[c0], bias[c0 + 1]};
-    }
-    __syncthreads();
-    for (int f = fs; f < TT; f += fpar) {
-        const int t = t0 + f;
-        if (t >= P) break;
-        uint32_t o = 0;
-        if (t < T0) {
-            f32x2_t y = {0.f, 0.f};
+        for (int q = 0; q < 4; ++q) {
+            const int c = active ? c0 + 2 * q : 0;
 #pragma unroll
-            for (int j = 0; j < CK; ++j) {
-                const float xv = xs[f * CS + j];
-                y = w2[j] * (f32x2_t){xv, xv} + y;
+            for (int j = 0; j < CK; ++j) w2[q][j] = (f32x2_t){w[c * CK + j], w[(c + 1) * CK + j]};
+            sc[q] = (f32x2_t){1.f, 1.f};
+            sh[q] = (f32x2_t){0.f, 0.f};
+            if (mode == 0) {
+                const float2 a = coef[(int64_t)b * C + c], d = coef[(int64_t)b * C + c + 1];
+                sc[q] = (f32x2_t){a.x, d.x}; sh[q] = (f32x2_t){a.y, d.y};
+            } else if (bias) {
+                sh[q] = (f32x2_t){bias[c], bias[c + 1]};
             }
-            y = y * sc + sh;
-            if (mode == 0) y = gelu_erf2(y);
-            o = pack2bf(y[0], y[1]);
         }
-        *(uint32_t*)(out + ((int64_t)b * P + t) * C + c0) = o;
+        __syncthreads();
+        for (int f = wave; f < TT; f += 4) {
+            const int t = t0 + f;
+            if (t >= P) break;
+            uint4 o = make_uint4(0, 0, 0, 0);
+            if (t < T0) {
+                f32x2_t y[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+                for (int j = 0; j < CK; ++j) {
+                    const float xv = xs[f * CS + j];
+                    const f32x2_t x2 = {xv, xv};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) y[q] = w2[q][j] * x2 + y[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    y[q] = y[q] * sc[q] + sh[q];
+                    if (mode == 0) y[q] = gelu_erf2(y[q]);
+                }
+                o = make_uint4(pack2bf(y[0][0], y[0][1]), pack2bf(y[1][0], y[1][1]), pack2bf(y[2][0], y[2][1]), pack2bf(y[3][0], y[3][1]));
+            }
+            if (active) *(uint4*)(out + ((int64_t)b * P + t) * C + c0) = o;
+        }
     }
 }
 
@@ -277,7 +290,7 @@ extern "C" int sc_conv0_gn_coef(const float* wav, int64_t ld, const float* w, co
 
 extern "C" int sc_conv0_fwd(const float* wav, int64_t ld, int64_t L, const float* w, const float* bias, const float* coef, void* out, int B,
                             int C, int T0, int P, int mode, void* stream) {
-    SC_CHECK_ARG(C >= 2 && C <= 512 && 512 % C == 0, "sc_conv0_fwd: C=%d must divide 512", C);
+    SC_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= 512, "sc_conv0_fwd: C=%d must be a multiple of 8, <= 512", C);
     SC_CHECK_ARG(mode == 1 || coef != nullptr, "sc_conv0_fwd: GroupNorm mode needs coef");
     SC_CHECK_ARG(P >= T0 && B > 0 && B <= 65535, "sc_conv0_fwd: need P >= T0 and 0 < B <= 65535");
     hipLaunchKernelGGL(conv0_fwd_kernel, dim3((P + TT - 1) / TT, B), dim3(256), 0, (hipStream_t)stream, wav, ld, L, w, bias, (const float2*)coef,

@@ -25,6 +25,7 @@ struct GemmParams {
     int tiles_m; int tiles_n;
     int act; int out_f32;
     unsigned long long* trace;   // debug: per-block s_memtime stamps (sc_debug_set_gemm_trace)
+    int rot;                     // rotate the K loop per block (L2 channel de-correlation)
 };
 
 constexpr int BK = 64;  // 128 bytes of bf16 per tile row = 8 chunks of 16 B
@@ -36,6 +37,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 // Stage a ROWS x 64 bf16 tile: LDS image is [row][8 chunks of 16 B], chunk position p of row r holds
 // global k-chunk (p ^ (r & 7)).  256 threads => 32 rows per pass.
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
 template <int ROWS>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t row_max,
                                            int k0, char* lds, int tid, int wave) {
@@ -200,6 +206,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const bf16_t* A = p.A;
     const bf16_t* W = p.W;
     const int nk = p.K / BK2;
+    // K rotation: the 32 CUs of an XCD would otherwise all stream the SAME W rows (and 2-3 of them the same A rows) at the same
+    // instant and pile onto a few L2 channels; block b starts its K loop at chunk rot(b) and wraps (fp32 sum order differs per
+    // block, deterministically).  SC_GEMM_NOROT=1 disables it for A/B timing.
+    const int rot = p.rot ? (int)((blockIdx.x >> 3) % (unsigned)nk) : 0;
+    auto kofs = [&](int st) -> int { int c = st + rot; c = c >= nk ? c - nk : c; return c * BK2; };
     const int frow = lane & 15, fk = lane >> 4;
     const int off_h0 = frow * 128 + ((fk ^ (frow & 7)) << 4);
     const int off_h1 = frow * 128 + (((4 + fk) ^ (frow & 7)) << 4);
@@ -238,8 +249,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     StageAddr sa{nullptr, nullptr};
     if (have) {
         sa = StageAddr{A + tile_m0(tm) * p.lda, W + (int64_t)tile_n0(tn) * p.ldw};
-        stage256(sa, lane_a, lane_w, lda64, ldw64, 0, smem, wave);
-        if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, BK2, smem + SLOT_BYTES, wave);
+        stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(0), smem, wave);
+        if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(1), smem + SLOT_BYTES, wave);
     }
     for (int it = 0; have; ++it) {
         const int64_t m0 = tile_m0(tm), m_lo = (int64_t)tm * 256;   // rows < m_lo belong to the previous tile
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             half_step(slot, off_h1, true, -1, nullptr);      // MFMAs of (kt, h0); read (kt, h1)
             mid_sync(kt);
             // MFMAs of (kt, h1); read (kt+1, h0); refill slot kt with stage kt+2
-            half_step(nslot, off_h0, true, kt + 2 < nk ? (kt + 2) * BK2 : -1, smem + (kt & 1) * SLOT_BYTES);
+            half_step(nslot, off_h0, true, kt + 2 < nk ? kofs(kt + 2) : -1, smem + (kt & 1) * SLOT_BYTES);
         }
         {   // last k-step (peeled: nothing left to prefetch after its first half)
             const int kt = nk - 1;
@@ -341,8 +352,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const bool early = nhave && !RES;
         if (nhave) sa = StageAddr{A + tile_m0(ntm) * p.lda, W + (int64_t)tile_n0(ntn) * p.ldw};
         if (early) {
-            stage256(sa, lane_a, lane_w, lda64, ldw64, 0, smem, wave);
-            if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, BK2, smem + SLOT_BYTES, wave);
+            stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(0), smem, wave);
+            if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(1), smem + SLOT_BYTES, wave);
         }
 
         if (TRACE) { unsigned long long t = __builtin_readcyclecounter(); t_pre += t - t_begin; t_begin = t; }
@@ -439,8 +450,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             }
         }
         if (nhave && !early) {
-            stage256(sa, lane_a, lane_w, lda64, ldw64, 0, smem, wave);
-            if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, BK2, smem + SLOT_BYTES, wave);
+            stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(0), smem, wave);
+            if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(1), smem + SLOT_BYTES, wave);
         }
         have = nhave;
         tm = ntm;
@@ -484,6 +495,8 @@ int launch256(const GemmParams& p, hipStream_t s) {
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     const char* abl = getenv("SC_GEMM_ABL");   // experiment switches: 1 = no LDS-DMA in the main loop, 2 = no MFMA, 3 = no epilogue stores
     if (p.trace && abl && abl[0] == '3') return launch256_var<3, true>(p, grid, s);
+    if (p.trace && abl && abl[0] == '1') return launch256_var<1, true>(p, grid, s);
+    if (p.trace && abl && abl[0] == '2') return launch256_var<2, true>(p, grid, s);
     if (p.trace) return launch256_var<0, true>(p, grid, s);
     if (abl && abl[0] == '1') return launch256_var<1, false>(p, grid, s);
     if (abl && abl[0] == '2') return launch256_var<2, false>(p, grid, s);
@@ -543,6 +556,7 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     p.M = M; p.N = N; p.K = K;
     p.act = flags & SC_GEMM_ACT_MASK; p.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0;
     p.trace = g_gemm_trace;
+    p.rot = getenv("SC_GEMM_NOROT") ? 0 : 1;
     return gemm_dispatch(p, 1, (hipStream_t)stream);
 }
 
