@@ -122,3 +122,92 @@ def test_base_dims_vs_oracle():
     assert cos_i.min().item() > 0.999, cos_i
     assert cos_a.min().item() > 0.999, cos_a
     assert abs(loss - ref_loss) < 2e-2, (loss, ref_loss)
+
+
+def _share_weights(model, ref, parallel=True, cascaded=False):
+    sd = model.state_dict()
+    ref.encoder.load_state_dict({k[len("audio_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("audio_encoder.encoder.")})
+    ref.clip.load_state_dict({k[len("clip.model."):]: v for k, v in sd.items() if k.startswith("clip.model.")})
+    with torch.no_grad():
+        ref.ws_weights.copy_(sd["audio_encoder.weightedsum_layer.weights"])
+    if parallel:
+        ref.parallel_branch.load_state_dict({k[len("parallel_branch."):]: v for k, v in sd.items() if k.startswith("parallel_branch.")})
+    if cascaded:
+        ref.cascaded_branch.load_state_dict({k[len("cascaded_branch."):]: v for k, v in sd.items()
+                                             if k.startswith("cascaded_branch.") and not k.startswith("cascaded_branch.clip.")
+                                             and "vector_quantizer" not in k})
+
+
+def test_large_dims_vs_oracle():
+    """BASELINE config 5 shapes: HuBERT-large (pre-LN, LN conv stack, wave layer-norm, normalised layer mix) + CLIP ViT-L/14,
+    trainable temperature, B=2 mixed lengths."""
+    from oracle.clip_ref import ClipRefConfig
+    from oracle.hubert_ref import HubertRefConfig
+    from oracle.speechclip_ref import SpeechClipRef
+    from speechclip_amd.model import KWClip_GeneralTransformer
+    torch.manual_seed(4321)
+    cfg = make_config(d_model=1024, branch_heads=8, hubert_name="hubert_large_ll60k", clip_name="ViT-L/14", normalize_hiddenstates=True,
+                      temperature_trainable=True)
+    model = KWClip_GeneralTransformer(cfg).eval()
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        model.audio_encoder.weightedsum_layer.weights.copy_(0.5 * torch.randn(25, generator=g))
+    ref = SpeechClipRef(HubertRefConfig.large(), ClipRefConfig.vit_l14(), parallel=True, branch_heads=8, normalize_hiddenstates=True,
+                        inv_temperature=model.criterion.current_temperature).eval()
+    _share_weights(model, ref)
+    lens = [24000, 17777]
+    wav = torch.zeros(2, max(lens))
+    for i, l in enumerate(lens):
+        wav[i, :l] = 0.1 * torch.randn(l, generator=g) + 0.01
+    batch = {"wav": wav, "wav_len": torch.tensor(lens), "image": torch.randn(2, 3, 224, 224, generator=g), "id": torch.tensor([1, 2])}
+    o = ref(batch)
+    ref_loss = ref.compute_loss(o)["loss"].item()
+    model = model.cuda()
+    with torch.no_grad():
+        lf, lm, _ = model({k: v.cuda() for k, v in batch.items()})
+        loss = model.compute_loss(lf)["loss"].item()
+    assert lf["image_feat"].shape == (2, 768) and lf["parallel_audio_feat"].shape == (2, 768)
+    assert _cos(lf["image_feat"], o["image_feat"]).min().item() > 0.999
+    assert _cos(lf["parallel_audio_feat"], o["parallel_audio_feat"]).min().item() > 0.998
+    assert abs(loss - ref_loss) < 2e-2, (loss, ref_loss)
+    assert abs(lm["cl_temp"] - 1 / 0.07) < 1e-3
+
+
+def test_cascaded_base_dims_vs_oracle(tmp_path):
+    """BASELINE config 3 shapes: cascaded base (8 keywords, 1-head attention, BatchNorm, cosine vs a reduced 8112-word
+    vocabulary, hard VQ, CLIP text tower)."""
+    from oracle.clip_ref import ClipRefConfig
+    from oracle.hubert_ref import HubertRefConfig
+    from oracle.speechclip_ref import SpeechClipRef
+    from speechclip_amd.model import KWClip_GeneralTransformer
+    g = torch.Generator().manual_seed(8)
+    vocab = torch.cat([torch.tensor([0, 320, 49406, 49407]), torch.randperm(49000, generator=g)[:8108] + 321]).numpy()
+    vp = str(tmp_path / "vocab.npy")
+    np.save(vp, np.stack([vocab, np.arange(len(vocab))[::-1] + 1], axis=1))
+    torch.manual_seed(99)
+    model = KWClip_GeneralTransformer(make_config(parallel=False, cascaded=True, reduce_vocab=vp)).eval()
+    with torch.no_grad():
+        model.audio_encoder.weightedsum_layer.weights.copy_(0.5 * torch.randn(13, generator=g))
+        bn = model.cascaded_branch.bn_layer.bn_layer
+        bn.running_mean.copy_(0.05 * torch.randn(bn.running_mean.shape, generator=g))
+        bn.running_var.copy_(1.0 + 0.2 * torch.rand(bn.running_var.shape, generator=g))
+    ref = SpeechClipRef(HubertRefConfig.base(), ClipRefConfig.vit_b32(), parallel=False, cascaded=True,
+                        reduced_vocab=torch.from_numpy(vocab)).eval()
+    _share_weights(model, ref, parallel=False, cascaded=True)
+    lens = [16000, 12000, 8000]
+    wav = torch.zeros(3, max(lens))
+    for i, l in enumerate(lens):
+        wav[i, :l] = 0.1 * torch.randn(l, generator=g)
+    batch = {"wav": wav, "wav_len": torch.tensor(lens), "image": torch.randn(3, 3, 224, 224, generator=g), "id": torch.tensor([5, 6, 6])}
+    o = ref(batch)
+    model = model.cuda()
+    with torch.no_grad():
+        lf, lm, others = model({k: v.cuda() for k, v in batch.items()})
+    agree = (others["vq_results"]["targets"].cpu() == o["vq_results"]["targets"]).float().mean().item()
+    assert agree >= 0.85, agree                    # arg-max over 8112 near-tied random embeddings; bf16 upstream features
+    assert others["vq_results"]["subword_prob"].shape == (3, 8, 8112) and others["keywords"].shape == (3, 8, 512)
+    same = (others["vq_results"]["targets"].cpu() == o["vq_results"]["targets"]).all(dim=1).squeeze(-1)
+    if same.any():                                  # utterances whose 8 keywords all agree must give the same embedding
+        assert _cos(lf["cascaded_audio_feat"][same.cuda()], o["cascaded_audio_feat"][same]).min().item() > 0.998
+    np.testing.assert_allclose(others["vq_results"]["ent_per_t"].cpu().numpy(), o["vq_results"]["ent_per_t"].numpy(), rtol=2e-2)
+    assert abs(float(others["vq_results"]["prob_perplexity"]) - float(o["vq_results"]["prob_perplexity"])) / float(o["vq_results"]["prob_perplexity"]) < 2e-2
