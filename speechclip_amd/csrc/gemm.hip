@@ -209,7 +209,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     // K rotation: the 32 CUs of an XCD would otherwise all stream the SAME W rows (and 2-3 of them the same A rows) at the same
     // instant and pile onto a few L2 channels; block b starts its K loop at chunk rot(b) and wraps (fp32 sum order differs per
     // block, deterministically).  SC_GEMM_NOROT=1 disables it for A/B timing.
-    const int rot = p.rot ? (int)((blockIdx.x >> 3) % (unsigned)nk) : 0;
+    // rot = M-panel index mod nk: the N-tiles of one A panel stay in lock-step (their A lines are fetched once and hit in L2 for
+    // the siblings) while different M-panels read different W rows at any instant.
+    int rot = 0;
     auto kofs = [&](int st) -> int { int c = st + rot; c = c >= nk ? c - nk : c; return c * BK2; };
     const int frow = lane & 15, fk = lane >> 4;
     const int off_h0 = frow * 128 + ((fk ^ (frow & 7)) << 4);
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     bool have = tile_of(0, tm, tn);
     StageAddr sa{nullptr, nullptr};
     if (have) {
+        rot = p.rot ? tm % nk : 0;
         sa = StageAddr{A + tile_m0(tm) * p.lda, W + (int64_t)tile_n0(tn) * p.ldw};
         stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(0), smem, wave);
         if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(1), smem + SLOT_BYTES, wave);
@@ -350,7 +353,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const bool early = nhave && !RES;
+        const int nrot = (nhave && p.rot) ? ntm % nk : 0;
         if (nhave) sa = StageAddr{A + tile_m0(ntm) * p.lda, W + (int64_t)tile_n0(ntn) * p.ldw};
+        rot = nrot;   // the k-loop of THIS tile is over; from here on kofs() addresses the next tile
         if (early) {
             stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(0), smem, wave);
             if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(1), smem + SLOT_BYTES, wave);
@@ -460,6 +465,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             unsigned long long t = __builtin_readcyclecounter();
             unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
             tr[0] = t_wait; tr[1] = t_loop; tr[2] = t_pre; tr[3] += t - t_begin; tr[4] = it + 1;
+            tr[5] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11));
             t_begin = t;
         }
     }

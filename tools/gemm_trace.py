@@ -25,4 +25,6 @@ for name in sys.argv[1:] or list(SH):
     per = t[:, :4] / tiles[:, None]
     m = per.mean(0)
     nk = K // 64
+    xcc = tr[:, 5].cpu().tolist()
+    print("   XCC id of blocks 0..15:", [int(v) & 15 for v in xcc[:16]], " blocks with xcc == bid%8:", sum(int(v) & 15 == (i % 8) for i, v in enumerate(xcc)), "/ 256")
     print(f"{name:6s} tiles/block={tiles.mean():.2f} per-tile cycles(100MHz ticks?): wait={m[0]:.0f} loop={m[1]:.0f} ({m[1]/nk:.1f}/kstep) prefetch-issue={m[2]:.0f} epilogue={m[3]:.0f}  total={m.sum():.0f}")
