@@ -533,7 +533,8 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
                  "sc_gemm: A/W/C must be 16-byte aligned");
     if (batch == 1 && p.N >= 256 && p.M >= 256 && p.K % 64 == 0) {
         const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-        if (t256 >= 192 && !getenv("SC_GEMM_V1")) {
+        static const int min_tiles = getenv("SC_GEMM_MIN_TILES") ? atoi(getenv("SC_GEMM_MIN_TILES")) : 100;
+        if (t256 >= min_tiles && !getenv("SC_GEMM_V1")) {
             p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (p.N + 255) / 256;
             return launch256(p, s);
         }

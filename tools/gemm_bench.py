@@ -9,7 +9,7 @@ SHAPES = [  # name, M, N, K, lda (None = K), act
     ("qkv", 128000, 2304, 768, None, 0), ("out", 128000, 768, 768, None, 0), ("fc1", 128000, 3072, 768, None, 1),
     ("fc2", 128000, 768, 3072, None, 0), ("proj", 128000, 768, 512, None, 0),
     ("conv1", 4096000, 512, 1536, 1024, 1), ("conv2", 2048000, 512, 1536, 1024, 1), ("conv4", 512000, 512, 1536, 1024, 1),
-    ("conv5", 256000, 512, 1024, 1024, 1), ("vit_fc1", 12800, 3072, 768, None, 2), ("sq8k", 8192, 8192, 8192, None, 0),
+    ("conv5", 256000, 512, 1024, 1024, 1), ("vit_fc1", 12800, 3072, 768, None, 2), ("vit_out", 12800, 768, 768, None, 0), ("vit_fc2", 12800, 768, 3072, None, 0), ("sq8k", 8192, 8192, 8192, None, 0),
 ]
 
 
