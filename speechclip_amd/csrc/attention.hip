@@ -21,17 +21,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 constexpr int KV = 64;          // keys per tile
-constexpr int VT_STRIDE = 136;  // bytes per V^T row (64 keys * 2 B + 8 B pad)
 constexpr int K_TILE_BYTES = KV * 128;
-constexpr int VT_TILE_BYTES = 64 * VT_STRIDE;
+constexpr int STAGE_BYTES = 2 * K_TILE_BYTES;   // K tile [64 keys][128 B] + V tile [64 keys][128 B], both row-major
+constexpr int NSTAGE = 3;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+// K chunk swizzle (16-B chunk p of key row r holds d-chunk p ^ (r & 7)); V chunk swizzle ((r >> 1) & 3) << 1 keeps the four
+// consecutive key rows touched by one ds_read_b64_tr_b16 group on different bank groups.
+__device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 3) << 1; }
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
                                                        const int32_t* __restrict__ klens, int T, int64_t ld_qkv,
                                                        int64_t ld_out, float scale_log2e, int causal, int B, int H, int nq) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Kbuf = smem;                       // 2 x 8 KiB
-    char* Vbuf = smem + 2 * K_TILE_BYTES;    // 2 x 8.5 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NSTAGE x (K 8 KiB + V 8 KiB)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,34 +67,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int c = 0; c < 4; ++c)
         qf[c] = *(const bf16x8_t*)(q + (row_base + qrow_c) * ld_qkv + hoff + c * 16 + g * 8);
 
-    // staging helpers
-    const int vj = tid >> 3, vdc = tid & 7;  // V: key pair, d-chunk
-    auto stage_k = [&](int tile, int buf) {
+    // K and V tiles both arrive by LDS-DMA (no VGPR staging): 2 + 2 instructions per thread per tile
+    auto stage = [&](int tile, int buf) {
+        char* kb = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int cid = i * 256 + tid;
-            int key = cid >> 3, pos = cid & 7;
+            const int cid = i * 256 + tid;
+            const int key = cid >> 3, pos = cid & 7;
             int kr = tile * KV + key;
             kr = kr < T ? kr : T - 1;
-            glds16(k + (row_base + kr) * ld_qkv + hoff + ((pos ^ (key & 7)) << 3), Kbuf + buf * K_TILE_BYTES + (i * 256 + wave * 64) * 16);
-        }
-    };
-    uint4 v0, v1;
-    auto load_v = [&](int tile) {
-        int k0 = tile * KV + 2 * vj, k1 = k0 + 1;
-        k0 = k0 < T ? k0 : T - 1;
-        k1 = k1 < T ? k1 : T - 1;
-        v0 = *(const uint4*)(v + (row_base + k0) * ld_qkv + hoff + vdc * 8);
-        v1 = *(const uint4*)(v + (row_base + k1) * ld_qkv + hoff + vdc * 8);
-    };
-    auto write_v = [&](int buf) {
-        char* base = Vbuf + buf * VT_TILE_BYTES + (vdc * 8) * VT_STRIDE + vj * 4;
-        const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w};
-        const uint32_t c[4] = {v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(uint32_t*)(base + (2 * i) * VT_STRIDE) = (a[i] & 0xffffu) | (c[i] << 16);
-            *(uint32_t*)(base + (2 * i + 1) * VT_STRIDE) = (a[i] >> 16) | (c[i] & 0xffff0000u);
+            const int64_t rowoff = (row_base + kr) * ld_qkv + hoff;
+            glds16(k + rowoff + ((pos ^ (key & 7)) << 3), kb + (i * 256 + wave * 64) * 16);
+            glds16(v + rowoff + ((pos ^ swz_v(key)) << 3), kb + K_TILE_BYTES + (i * 256 + wave * 64) * 16);
         }
     };
 
@@ -99,22 +87,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
+    // per-lane pieces of the V^T fragment address (ds_read_b64_tr_b16: within a 16-lane group, lane i points at key row i>>2,
+    // 4 consecutive d at (i&3)*4, and receives column (i) of the 4 x 16 block, i.e. V[k0..k0+3][d0 + i])
+    const int ti = lane & 15;
+    const int v_row_in = ti >> 2;                                  // key row within the group of 4
+    const int v_chunk_in = (((lane >> 4) & 1) << 1) + ((ti & 3) >> 1);   // 16-B chunk within the 64-B d-block
+    const int v_byte_in = (ti & 1) * 8;
+
     if (nkv > 0) {
-        stage_k(0, 0);
-        load_v(0);
-        write_v(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        stage(0, 0);
+        if (nkv > 1) stage(1, 1);
+        if (nkv > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
     for (int j = 0; j < nkv; ++j) {
-        const int cur = j & 1;
-        const bool more = (j + 1 < nkv);
-        if (more) {
-            stage_k(j + 1, cur ^ 1);
-            load_v(j + 1);
-        }
-        const char* kb_ = Kbuf + cur * K_TILE_BYTES;
-        const char* vb_ = Vbuf + cur * VT_TILE_BYTES;
+        if (j + 2 < nkv) stage(j + 2, (j + 2) % NSTAGE);    // that buffer held tile j-1: every wave passed the barrier after reading it
+        const char* kb_ = smem + (j % NSTAGE) * STAGE_BYTES;
+        const char* vb_ = kb_ + K_TILE_BYTES;
         // ---- S^T = K . Q^T
         f32x16_t s[2];
 #pragma unroll
@@ -180,27 +171,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
         }
-        // ---- O^T += V^T . P^T
+        // ---- O^T += V^T . P^T : V^T fragments come straight out of the row-major V tile via the transposing LDS read
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
             const int kb = c4 >> 1, hb = c4 & 1;
             bf16x8_t pf;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)s[kb][hb * 8 + jj];
-            const int kofs = (kb * 32 + hb * 16 + 4 * g) * 2;
+            const int k0 = kb * 32 + hb * 16 + 4 * g + v_row_in;    // first group of 4 keys; the second is k0 + 8
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const char* vr = vb_ + (db * 32 + ql) * VT_STRIDE + kofs;
-                const uint2 lo = *(const uint2*)vr;
-                const uint2 hi = *(const uint2*)(vr + 16);
-                uint4 u = {lo.x, lo.y, hi.x, hi.y};
-                bf16x8_t vf = __builtin_bit_cast(bf16x8_t, u);
+                const int ch = db * 4 + v_chunk_in;
+                const char* p0 = vb_ + k0 * 128 + ((ch ^ swz_v(k0)) << 4) + v_byte_in;
+                const char* p1 = vb_ + (k0 + 8) * 128 + ((ch ^ swz_v(k0 + 8)) << 4) + v_byte_in;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                const s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, both);
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
             }
         }
-        if (more) write_v(cur ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // tile j+1 must have landed before anyone reads it; tile j+2 (just issued) stays in flight across the barrier
+        if (j + 2 < nkv) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -312,7 +308,7 @@ extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, voi
     SC_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "sc_attention_fwd: misaligned pointers");
     if (B <= 0 || T <= 0) return 0;
     static bool attr = false;
-    constexpr int lds = 2 * K_TILE_BYTES + 2 * VT_TILE_BYTES;
+    constexpr int lds = NSTAGE * STAGE_BYTES;
     if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
     const int nq = (T + 127) / 128;
     const int64_t units8 = ((int64_t)H * B + 7) / 8;
