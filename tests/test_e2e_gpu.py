@@ -211,3 +211,40 @@ def test_cascaded_base_dims_vs_oracle(tmp_path):
         assert _cos(lf["cascaded_audio_feat"][same.cuda()], o["cascaded_audio_feat"][same]).min().item() > 0.998
     np.testing.assert_allclose(others["vq_results"]["ent_per_t"].cpu().numpy(), o["vq_results"]["ent_per_t"].numpy(), rtol=2e-2)
     assert abs(float(others["vq_results"]["prob_perplexity"]) - float(o["vq_results"]["prob_perplexity"])) / float(o["vq_results"]["prob_perplexity"]) < 2e-2
+
+
+def test_full_size_properties():
+    """BASELINE config-2 shape (10 s audio, 224^2 images, P-base) at B = 64, where the fp32 oracle is too slow to run:
+    size-independent properties instead -- bitwise run-to-run determinism, batch-permutation equivariance of the embeddings,
+    unit norms, and the HIP InfoNCE agreeing with the fp32 oracle loss evaluated on the SAME embeddings."""
+    from oracle.speechclip_ref import masked_contrastive_loss
+    from speechclip_amd.model import KWClip_GeneralTransformer
+    torch.manual_seed(7)
+    model = KWClip_GeneralTransformer(make_config()).eval().cuda()
+    g = torch.Generator().manual_seed(11)
+    B, L = 64, 160000
+    lens = torch.full((B,), L)
+    lens[::7] = 96000                                          # a few shorter utterances: exercises the key masks at full T
+    wav = 0.1 * torch.randn(B, L, generator=g)
+    for i in range(B):
+        wav[i, lens[i]:] = 0
+    batch = {"wav": wav.cuda(), "wav_len": lens.cuda(), "image": torch.randn(B, 3, 224, 224, generator=g).cuda(),
+             "id": torch.arange(B).cuda() // 2}
+    with torch.no_grad():
+        lf1, _, _ = model(batch)
+        a1, i1 = lf1["parallel_audio_feat"].clone(), lf1["image_feat"].clone()
+        lf2, _, _ = model(batch)
+        assert torch.equal(a1, lf2["parallel_audio_feat"]) and torch.equal(i1, lf2["image_feat"])      # deterministic
+        perm = torch.randperm(B, generator=g).cuda()
+        lf3, _, _ = model({k: v[perm] for k, v in batch.items()})
+        loss = model.compute_loss(lf1)["loss"].item()
+        loss_perm = model.compute_loss(lf3)["loss"].item()
+    assert torch.isfinite(a1).all() and torch.isfinite(i1).all()
+    torch.testing.assert_close(a1.norm(dim=-1), torch.ones(B, device="cuda"), atol=1e-5, rtol=0)
+    torch.testing.assert_close(i1.norm(dim=-1), torch.ones(B, device="cuda"), atol=1e-5, rtol=0)
+    # no cross-sample coupling except the shared batch max length (unchanged).  Not bitwise: the GEMM rotates its K loop by the
+    # tile's M-panel index, so the fp32 summation order of a row depends (deterministically) on its position in the batch.
+    assert _cos(lf3["image_feat"], i1[perm]).min().item() > 0.99999
+    assert _cos(lf3["parallel_audio_feat"], a1[perm]).min().item() > 0.99999
+    ref = masked_contrastive_loss(a1.cpu(), i1.cpu(), batch["id"].cpu()).item()
+    assert abs(loss - ref) < 1e-4 and abs(loss_perm - loss) < 1e-4
