@@ -102,6 +102,14 @@ int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, con
 int sc_cls_attention_fwd(const void* cls_qkv, const void* kv_x, int64_t ld_kv, const int32_t* lens, void* out, int B, int T,
                          int NQ, int H, int head_dim, float scale, void* stream);
 
+/* Algebraic form of the same pooling attention (no K/V of the frames is formed): score_r(x) = x . u_r + beta_r with
+ * u_r = scale * Wk_h^T Q_{q,h}, r = (q,h), R = NQ*H <= 8.  `scores` f32 [B*T, R] are the frame scores (one skinny sc_gemm_bf16 with
+ * W = u, bias = beta), `cls_scores` f32 [NQ, R] those of the CLS tokens; the kernel soft-maxes over [CLS tokens ; frames t < lens[b]]
+ * and writes xbar[b,r,:] = sum_keys p_r(key) x_key (bf16 [B,R,D], D <= 1024).  The caller finishes with
+ * out_{q,h} = Wv_h xbar_r + bv_h (sc_gemm_bf16_batched). */
+int sc_cls_pool_fwd(const void* x, int64_t ld_x, const void* cls_tok, const float* scores, const float* cls_scores,
+                    const int32_t* lens, void* xbar, int B, int T, int NQ, int R, int D, void* stream);
+
 /* ---- HuBERT conv layer 0 -- fairseq ConvFeatureExtractionModel block 0 (speech_encoder_plus.py:75)
  * wav f32 [B, ld] (zero padded, L valid columns), w f32 [C,10], out bf16 channels-last [B, P, C]
  * (P >= T0 rows per utterance; rows >= T0 are written as zeros).

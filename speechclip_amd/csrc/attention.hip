@@ -299,6 +299,90 @@ __global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Algebraic CLS pooling.  For a learned query q and head h the score of key x is
+//   scale * Q_{q,h} . (Wk_h x + bk_h) = x . u_r + beta_r   with u_r = scale * Wk_h^T Q_{q,h}  (r = (q,h), R = NQ*H <= 8)
+// and the head output is  Wv_h (sum_keys p_r x) + bv_h.  So neither K nor V of the frames is ever formed.  The frame scores
+// x . u_r + beta_r are one skinny GEMM ([B*T, D] x [D, R], done by sc_gemm_bf16 with bias = beta, f32 out); this kernel does the
+// softmax over [NQ CLS tokens ; frames t < lens[b]] and the R probability-weighted frame sums xbar_r in one streaming pass over x.
+// Block per utterance; wave w owns keys kk = w (mod 4) with 4 keys in flight; per-wave partial sums are combined through LDS.
+template <int DCH>   // DCH = ceil(D / 256) chunks of 4 elements per lane
+__global__ __launch_bounds__(256) void cls_pool_kernel(const bf16_t* __restrict__ x, int64_t ld_x, const bf16_t* __restrict__ cls_tok,
+                                                       const float* __restrict__ scores, const float* __restrict__ cls_scores,
+                                                       const int32_t* __restrict__ lens, bf16_t* __restrict__ xbar, int T, int NQ, int R, int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = (float*)smem;                 // [R][NQ + T]  probabilities
+    float* red = sc + 8 * (NQ + T);           // [4 waves][R][D] partial sums (only rows < R used)
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int len = lens ? lens[b] : T;
+    len = len < 0 ? 0 : (len > T ? T : len);
+    const int nkeys = NQ + len, skeys = NQ + T;
+    for (int i = tid; i < nkeys * R; i += 256) {
+        const int kk = i / R, r = i - kk * R;
+        sc[r * skeys + kk] = kk < NQ ? cls_scores[kk * R + r] : scores[((int64_t)b * T + (kk - NQ)) * R + r];
+    }
+    __syncthreads();
+    for (int r = wave; r < R; r += 4) {
+        float* row = sc + r * skeys;
+        float mx = -INFINITY;
+        for (int kk = lane; kk < nkeys; kk += 64) mx = fmaxf(mx, row[kk]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int kk = lane; kk < nkeys; kk += 64) { const float e = __expf(row[kk] - mx); row[kk] = e; sum += e; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int kk = lane; kk < nkeys; kk += 64) row[kk] *= inv;
+    }
+    __syncthreads();
+    float acc[8][DCH][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < DCH; ++c) acc[r][c][0] = acc[r][c][1] = acc[r][c][2] = acc[r][c][3] = 0.f;
+    for (int k0 = wave; k0 < nkeys; k0 += 16) {
+        uint2 xv[4][DCH];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = k0 + 4 * u;
+            const int kc = kk < nkeys ? kk : nkeys - 1;
+            const bf16_t* xr = kc < NQ ? cls_tok + (int64_t)kc * D : x + ((int64_t)b * T + (kc - NQ)) * ld_x;
+#pragma unroll
+            for (int c = 0; c < DCH; ++c) xv[u][c] = (c * 256 + lane * 4 < D) ? *(const uint2*)(xr + c * 256 + lane * 4) : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = k0 + 4 * u;
+            if (kk >= nkeys) break;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r >= R) break;
+                const float pw = sc[r * skeys + kk];
+#pragma unroll
+                for (int c = 0; c < DCH; ++c) {
+                    acc[r][c][0] += pw * lo2f(xv[u][c].x); acc[r][c][1] += pw * hi2f(xv[u][c].x);
+                    acc[r][c][2] += pw * lo2f(xv[u][c].y); acc[r][c][3] += pw * hi2f(xv[u][c].y);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r >= R) break;
+#pragma unroll
+        for (int c = 0; c < DCH; ++c)
+            if (c * 256 + lane * 4 < D)
+                *(f32x4_t*)(red + ((wave * 8 + r) * D) + c * 256 + lane * 4) = (f32x4_t){acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]};
+    }
+    __syncthreads();
+    for (int i = tid * 2; i < R * D; i += 512) {
+        const int r = i / D, d = i - r * D;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s0 += red[(w * 8 + r) * D + d]; s1 += red[(w * 8 + r) * D + d + 1]; }
+        *(uint32_t*)(xbar + ((int64_t)b * R + r) * D + d) = pack2bf(s0, s1);
+    }
+}
+
 }  // namespace
 
 extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H,
@@ -331,6 +415,29 @@ extern "C" int sc_cls_attention_fwd(const void* cls_qkv, const void* kv_x, int64
     (void)hipFuncSetAttribute((const void*)cls_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(cls_attn_kernel, dim3(H, B), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)cls_qkv, (const bf16_t*)kv_x, ld_kv,
                        lens, (bf16_t*)out, T, NQ, H, head_dim, scale);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_cls_pool_fwd(const void* x, int64_t ld_x, const void* cls_tok, const float* scores, const float* cls_scores,
+                               const int32_t* lens, void* xbar, int B, int T, int NQ, int R, int D, void* stream) {
+    SC_CHECK_ARG(NQ >= 1 && R >= NQ && R <= 8, "sc_cls_pool_fwd: need 1 <= NQ <= R <= 8 (NQ=%d R=%d)", NQ, R);
+    SC_CHECK_ARG(D > 0 && D <= 1024 && D % 4 == 0 && ld_x % 4 == 0, "sc_cls_pool_fwd: D=%d must be a multiple of 4, <= 1024", D);
+    if (B <= 0) return 0;
+    const int lds = (8 * (NQ + T) + 4 * 8 * D) * 4;
+    SC_CHECK_ARG(lds <= 160 * 1024, "sc_cls_pool_fwd: T=%d / D=%d too large for LDS", T, D);
+    hipStream_t s = (hipStream_t)stream;
+#define SC_POOL_LAUNCH(DCH)                                                                                                         \
+    do {                                                                                                                            \
+        (void)hipFuncSetAttribute((const void*)cls_pool_kernel<DCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);              \
+        hipLaunchKernelGGL(cls_pool_kernel<DCH>, dim3(B), dim3(256), lds, s, (const bf16_t*)x, ld_x, (const bf16_t*)cls_tok, scores, \
+                           cls_scores, lens, (bf16_t*)xbar, T, NQ, R, D);                                                           \
+    } while (0)
+    if (D <= 256) SC_POOL_LAUNCH(1);
+    else if (D <= 512) SC_POOL_LAUNCH(2);
+    else if (D <= 768) SC_POOL_LAUNCH(3);
+    else SC_POOL_LAUNCH(4);
+#undef SC_POOL_LAUNCH
     SC_CHECK_LAUNCH();
     return 0;
 }

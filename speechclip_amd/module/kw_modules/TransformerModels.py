@@ -30,20 +30,47 @@ def _frames_view(audio_feat: torch.Tensor):
     return x.view(B * T, D), T
 
 
+_POOL_CACHE = {}
+
+
+def _pool_operands(cls, in_w, in_b, heads):
+    """Parameter-only preprocessing of the algebraic CLS pooling (cached per parameter version, like weight-norm folding):
+    u_r = scale * Wk_h^T Q_{q,h},  beta_r = scale * Q_{q,h} . bk_h  for r = (q, h);  Q = Wq cls + bq."""
+    key = (cls.data_ptr(), in_w.data_ptr(), in_b.data_ptr(), heads)
+    ver = (cls._version, in_w._version, in_b._version, cls.device)
+    hit = _POOL_CACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        NQ, D = cls.shape[-2], cls.shape[-1]
+        hd = D // heads
+        c = cls.detach().reshape(NQ, D).float()
+        w, b = in_w.detach().float(), in_b.detach().float()
+        q = (c @ w[:D].t() + b[:D]).view(NQ, heads, hd) * hd ** -0.5
+        u = torch.einsum("qhj,hjd->qhd", q, w[D:2 * D].view(heads, hd, D)).reshape(NQ * heads, D).contiguous()
+        beta = (q * b[D:2 * D].view(1, heads, hd)).sum(-1).reshape(NQ * heads).contiguous()
+        c16 = c.to(BF)
+        ops_ = dict(u16=u.to(BF).contiguous(), beta=beta, cls16=c16.contiguous(), wv=w[2 * D:].to(BF).contiguous(), bv=b[2 * D:].contiguous(),
+                    cls_scores=(c16.float() @ u.to(BF).float().t() + beta).contiguous())                    # [NQ, R]
+    _POOL_CACHE[key] = (ver, ops_)
+    return ops_
+
+
 def _cls_attention_block(cls: torch.Tensor, audio_feat: torch.Tensor, audio_len: torch.Tensor, in_w, in_b, heads: int):
-    """Shared front half: q/k/v of the NQ CLS tokens, k/v of the frames, CLS-rows-only attention.
-    Returns bf16 [B*NQ, D]."""
+    """CLS-rows-only attention in its algebraic form (sc_cls_pool_fwd): scores x.u_r + beta_r over [CLS tokens ; valid frames],
+    softmax, probability-weighted frame sums, then the per-head value projection as a small batched GEMM.  K/V of the frames
+    are never materialised.  Returns bf16 [B*NQ, D] (the concatenated head outputs, before out_proj)."""
     B = audio_feat.shape[0]
     NQ, D = cls.shape[-2], cls.shape[-1]
+    hd, R = D // heads, NQ * heads
     rows, Tp = _frames_view(audio_feat)
-    w = in_w.detach().to(BF).contiguous()
-    b = in_b.detach().float().contiguous()
-    cls_rows = cls.detach().reshape(NQ, D).to(BF).contiguous()
-    cls_qkv = ops.gemm(cls_rows, w, b)                                   # [NQ, 3D]
-    kv_x = ops.gemm(rows, w[D:], b[D:])                                   # [B*Tp, 2D]
+    P = _pool_operands(cls, in_w, in_b, heads)
     lens = audio_len.to(device=rows.device, dtype=torch.int32).contiguous()
-    att = ops.cls_attention(cls_qkv, kv_x, lens, B, Tp, NQ, heads, D // heads)
-    return att.view(B * NQ, D)
+    scores = ops.gemm(rows, P["u16"], P["beta"], out_f32=True)                              # [B*Tp, R] = x . u_r + beta_r
+    xbar = ops.cls_pool(rows, P["cls16"], scores, P["cls_scores"], lens, B, Tp, NQ, R, D)   # bf16 [B, R, D]
+    out = torch.empty(B * NQ, D, device=rows.device, dtype=BF)
+    ops.gemm_batched(xbar, R * D, D, P["wv"], hd * D, heads, out, NQ * D, hd, P["bv"], B, hd, D, R)
+    return out
 
 
 class _EncoderStack(nn.Module):

@@ -138,6 +138,16 @@ def cls_attention(cls_qkv, kv_x, lens_i32, B, T, NQ, H, hd):
     return out
 
 
+def cls_pool(x_rows, cls16, scores, cls_scores, lens_i32, B, T, NQ, R, D):
+    """x_rows bf16 [B*T, D]; cls16 bf16 [NQ, D]; scores f32 [B*T, R]; cls_scores f32 [NQ, R] -> xbar bf16 [B, R, D]."""
+    _need_cuda(x_rows, cls16, scores, cls_scores)
+    assert x_rows.dtype == bf16 and x_rows.stride(1) == 1 and scores.dtype == torch.float32 and scores.shape == (B * T, R) and scores.is_contiguous()
+    xbar = torch.empty(B, R, D, device=x_rows.device, dtype=bf16)
+    check(lib().sc_cls_pool_fwd(ptr(x_rows), x_rows.stride(0), ptr(cls16), ptr(scores), ptr(cls_scores), ptr(lens_i32), ptr(xbar), B, T, NQ, R, D,
+                                stream()), "sc_cls_pool_fwd")
+    return xbar
+
+
 def conv0(wav, w, T0, P, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5, out=None):
     """HuBERT conv layer 0.  wav f32 [B, L]; w f32 [C, 10].  GroupNorm+GELU if gn_gamma given, else raw conv + bias.
     Returns channels-last bf16 [B, P, C] (+ (k-s) slack rows so the next conv-as-GEMM may over-read)."""

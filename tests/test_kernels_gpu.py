@@ -227,3 +227,26 @@ def test_infonce_golden():
         fa, fb, ids = (torch.from_numpy(gold[f"{k}_{B}"]).cuda() for k in ("fa", "fb", "ids"))
         mine = ops.infonce(fa, fb, ids if use_ids else None, inv_t, margin, bool(dcl), bool(a2b), bool(b2a))[0].item()
         assert abs(mine - val) < 1e-4 * max(1.0, abs(val)), (B, margin, dcl, a2b, b2a, val, mine)
+
+
+@pytest.mark.parametrize("NQ,H,D,T", [(1, 8, 768, 499), (8, 1, 768, 499), (1, 4, 128, 24), (8, 1, 128, 24)])
+def test_cls_pool_algebraic_equals_attention(NQ, H, D, T):
+    """sc_cls_pool_fwd + per-head value projection == explicit MHA rows of the CLS tokens over [CLS ; valid frames]."""
+    from speechclip_amd.module.kw_modules.TransformerModels import _cls_attention_block
+    g = _g(NQ * 100 + D)
+    B, hd = 3, D // H
+    cls = torch.randn(1, NQ, D, generator=g).cuda()
+    in_w = (torch.randn(3 * D, D, generator=g) * D ** -0.5).cuda()
+    in_b = (0.1 * torch.randn(3 * D, generator=g)).cuda()
+    x = torch.randn(B, T, D, generator=g).to("cuda", BF)
+    lens = torch.tensor([T, 1, T // 2], device="cuda")
+    y = _cls_attention_block(cls, x, lens, in_w, in_b, H).float().view(B, NQ, D)
+    ref = torch.zeros(B, NQ, D, device="cuda")
+    for b in range(B):
+        src = torch.cat([cls[0].to(BF).float(), x[b, : int(lens[b])].float()], 0)
+        q = (cls[0].to(BF).float() @ in_w[:D].t() + in_b[:D]).view(NQ, H, hd)
+        k = (src @ in_w[D:2 * D].t() + in_b[D:2 * D]).view(-1, H, hd)
+        v = (src @ in_w[2 * D:].to(BF).float().t() + in_b[2 * D:]).view(-1, H, hd)
+        s = torch.einsum("qhd,khd->hqk", q, k) * hd ** -0.5
+        ref[b] = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), v).reshape(NQ, D)
+    torch.testing.assert_close(y, ref, atol=3e-2, rtol=3e-2)
