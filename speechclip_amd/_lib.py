@@ -10,7 +10,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspeechclip_hip.so")
+# SPEECHCLIP_HIP_LIB: developer override (A/B timing of two builds in one process launch each); the default is the in-tree build.
+LIB_PATH = os.environ.get("SPEECHCLIP_HIP_LIB") or os.path.join(_HERE, "libspeechclip_hip.so")
 
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 GEMM_OUT_F32 = 0x10

@@ -54,6 +54,25 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {   // two values: the p
     f32x2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
     return x * r;
 }
+// Transcendental-free form for the GEMM epilogues (v_exp/v_rcp are not packable; everything below is v_pk_fma_f32/v_pk_mul_f32, two
+// values per issue): Phi(x) = 0.5 + xc * g(t), xc = clamp(x, +-4.25), t = 2 xc^2 / 4.25^2 - 1 in [-1, 1], g = degree-8 minimax
+// polynomial (weighted for the error of x * Phi).  max |err| 1.7e-5 on [-4.25, 4.25]; outside, Phi(+-4.25) = 1 - 7e-6 / 7e-6
+// (relative error 7e-6 on the positive side, |x| * 7e-6 absolute on the negative side).
+#define SC_GELU_P_C 4.25f
+#define SC_GELU_P_S 0.11072665f
+__device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
+    const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -SC_GELU_P_C, SC_GELU_P_C), __builtin_amdgcn_fmed3f(x[1], -SC_GELU_P_C, SC_GELU_P_C)};
+    const f32x2_t t = xc * xc * SC_GELU_P_S - 1.0f;
+    f32x2_t g = t * 2.012408951e-03f + -6.027759260e-03f;
+    g = g * t + 9.229262475e-03f;
+    g = g * t + -1.461630908e-02f;
+    g = g * t + 2.532269481e-02f;
+    g = g * t + -3.916527947e-02f;
+    g = g * t + 5.573306025e-02f;
+    g = g * t + -8.077754797e-02f;
+    g = g * t + 1.659348977e-01f;
+    return x * (xc * g + 0.5f);
+}
 __device__ __forceinline__ float gelu_erf_precise(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
 // CLIP QuickGELU: x * sigmoid(1.702 x)
 __device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }

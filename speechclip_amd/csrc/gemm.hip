@@ -26,6 +26,8 @@ struct GemmParams {
     int act; int out_f32;
     unsigned long long* trace;   // debug: per-block s_memtime stamps (sc_debug_set_gemm_trace)
     int rot;                     // rotate the K loop per block (L2 channel de-correlation)
+    int band;                    // N-tiles per column band of the persistent tile order (0/>=tiles_n: M-panel-major over all of N)
+    int epi_mode;                // next tile's first two stages: 0 issued before the epilogue, 2 interleaved with its stores (default), 3 after it
 };
 
 constexpr int BK = 64;  // 128 bytes of bf16 per tile row = 8 chunks of 16 B
@@ -234,9 +236,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const int cnt = q + (xcd < r8 ? 1 : 0);
         const int idx = it * nb_xcd + slot_in_xcd;
         if (idx >= cnt) return false;
-        const int v = begin + idx;
-        tm = v / p.tiles_n;
-        tn = v - tm * p.tiles_n;
+        int v = begin + idx;
+        // Column bands: the order walks all M-panels of a band of `band` N-tiles before moving to the next band, so the 32 blocks of
+        // an XCD work on (32 / band) M-panels x band N-tiles at a time: the band's slice of W (band x 256 x K) stays resident in the
+        // XCD's 4 MiB L2 while A streams through once per band.  With all of N in flight (qkv: 9 tiles = 3.5 MiB of W, fc1: 12 = 4.7 MiB)
+        // W and the A panels evict each other: measured TCC hit rate 69 %.
+        int nb = p.tiles_n, tn0 = 0;
+        if (p.band > 0 && p.band < p.tiles_n) {
+            const int per_band = p.band * p.tiles_m;
+            const int b = v / per_band;
+            tn0 = b * p.band;
+            v -= b * per_band;
+            nb = p.tiles_n - tn0 < p.band ? p.tiles_n - tn0 : p.band;
+        }
+        tm = v / nb;
+        tn = tn0 + (v - tm * nb);
         return true;
     };
 
@@ -352,13 +366,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const bool nhave = tile_of(it + 1, ntm, ntn);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const bool early = nhave && !RES;
         const int nrot = (nhave && p.rot) ? ntm % nk : 0;
         if (nhave) sa = StageAddr{A + tile_m0(ntm) * p.lda, W + (int64_t)tile_n0(ntn) * p.ldw};
         rot = nrot;   // the k-loop of THIS tile is over; from here on kofs() addresses the next tile
-        if (early) {
-            stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(0), smem, wave);
-            if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(1), smem + SLOT_BYTES, wave);
+        // q-th of the 16 prologue DMA instructions of the next tile (stage q >> 3; A row groups then W row groups)
+        auto issue_q = [&](int q) {
+            const int st = q >> 3, g = q & 7;
+            if (st == 1 && nk < 2) return;
+            char* slot = smem + st * SLOT_BYTES;
+            if (g < 4) glds16(sa.ta + (g * lda64 + kofs(st)) + lane_a, slot + (g * 512 + wave * 64) * 16);
+            else glds16(sa.tw + ((g - 4) * ldw64 + kofs(st)) + lane_w, slot + 256 * 128 + ((g - 4) * 512 + wave * 64) * 16);
+        };
+        const int emode = RES ? 3 : p.epi_mode;
+        if (nhave && emode == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) issue_q(q);
         }
 
         if (TRACE) { unsigned long long t = __builtin_readcyclecounter(); t_pre += t - t_begin; t_begin = t; }
@@ -366,13 +388,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         if (vec_ok) {
             // Lane (frow, fk) holds row frow, columns 16j + 4fk .. +3 of each 16-column block j.  v_permlane16_swap between the
             // 16-lane rows fk and fk^1 regroups a block PAIR (j0, j1) so that even-fk lanes own 8 consecutive columns of j0 and
-            // odd-fk lanes 8 consecutive columns of j1: one 16-byte store per lane per pair, no LDS round trip.
+            // odd-fk lanes 8 consecutive columns of j1 (16 bytes per lane).  Stored from there, the four lanes of every lane QUAD
+            // would hit four different rows, and the store path handles a wave quad by quad: 13 B/clk/CU measured, against
+            // 24-36 B/clk/CU when a quad covers 64 contiguous bytes (tools/probes/store_probe.hip).  So the 16 x 4 (row x chunk)
+            // lane matrix is transposed through the LDS crossbar (ds_bpermute, no LDS memory): lane L ends up with row L >> 2,
+            // 16-byte chunk L & 3 of the 32-column half, and a store instruction writes 16 rows x 64 contiguous bytes.
             bf16_t* Cb = (bf16_t*)p.C;
-            const int odd = fk & 1;
-            const int ncol0 = n0 + wn * 64 + (odd ? 16 + 4 * (fk - 1) : 4 * fk);   // pair 0 (blocks 0,1); pair 1 adds 32
-            // residual: rolling prefetch, two passes (4 x 16 B per lane) ahead of their use
+            const int srow = lane >> 2, schunk = lane & 3;
+            const int src_fk = ((schunk & 1) << 1) | (schunk >> 1);                          // lane row that holds this chunk after the swap
+            const int bperm = (src_fk * 16 + srow) << 2;
+            const int ncol0 = n0 + wn * 64 + schunk * 8;                                     // half 0; half 1 adds 32 columns
+            const int64_t mrow0 = m0 + wm * 128 + srow;
             auto load_res = [&](int i, uint4 (&dst)[2]) {
-                const int64_t m = m0 + wm * 128 + i * 16 + frow;
+                const int64_t m = mrow0 + i * 16;
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
                     const int n = ncol0 + jp * 32;
@@ -383,7 +411,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             if (RES) { load_res(0, res[0]); load_res(1, res[1]); }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int64_t m = m0 + wm * 128 + i * 16 + frow;
+                const int64_t m = mrow0 + i * 16;
                 if (RES && i + 2 < 8) load_res(i + 2, res[(i + 2) % 3]);
                 uint2 pk[4];
 #pragma unroll
@@ -391,8 +419,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     f32x4_t v4 = acc[i][j];
                     v4 += bias4[j];
                     if (ACT == SC_ACT_GELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v4[r] = gelu_erf(v4[r]);
+                        const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
+                        v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
                     } else if (ACT == SC_ACT_QUICKGELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
@@ -404,7 +432,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 for (int jp = 0; jp < 2; ++jp) {
                     const auto r0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].x, pk[2 * jp + 1].x, false, false);
                     const auto r1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].y, pk[2 * jp + 1].y, false, false);
-                    uint4 o = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    uint4 o = make_uint4(__builtin_amdgcn_ds_bpermute(bperm, r0[0]), __builtin_amdgcn_ds_bpermute(bperm, r1[0]),
+                                         __builtin_amdgcn_ds_bpermute(bperm, r0[1]), __builtin_amdgcn_ds_bpermute(bperm, r1[1]));
                     const int n = ncol0 + jp * 32;
                     if (m >= m_lo && n >= n_lo) {
                         if (RES) {
@@ -418,6 +447,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                         else asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
                     }
                 }
+                if (!RES && nhave && emode == 2) { issue_q(2 * i); issue_q(2 * i + 1); }
             }
         } else {
             char* Cb = (char*)p.C;
@@ -432,8 +462,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     f32x4_t v4 = acc[i][j];
                     v4 += bias4[j];
                     if (ACT == SC_ACT_GELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v4[r] = gelu_erf(v4[r]);
+                        const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
+                        v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
                     } else if (ACT == SC_ACT_QUICKGELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
@@ -454,9 +484,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 }
             }
         }
-        if (nhave && !early) {
-            stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(0), smem, wave);
-            if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(1), smem + SLOT_BYTES, wave);
+        if (nhave && (emode == 3 || (emode == 2 && !vec_ok))) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) issue_q(q);
         }
         have = nhave;
         tm = ntm;
@@ -498,7 +528,8 @@ int launch256(const GemmParams& p, hipStream_t s) {
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    int grid = ntiles < n_cu ? ntiles : n_cu;
+    if (getenv("SC_GEMM_GRID")) grid = atoi(getenv("SC_GEMM_GRID")) < grid ? atoi(getenv("SC_GEMM_GRID")) : grid;
     const char* abl = getenv("SC_GEMM_ABL");   // experiment switches: 1 = no LDS-DMA in the main loop, 2 = no MFMA, 3 = no epilogue stores
     if (p.trace && abl && abl[0] == '3') return launch256_var<3, true>(p, grid, s);
     if (p.trace && abl && abl[0] == '1') return launch256_var<1, true>(p, grid, s);
@@ -536,6 +567,7 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
         static const int min_tiles = getenv("SC_GEMM_MIN_TILES") ? atoi(getenv("SC_GEMM_MIN_TILES")) : 100;
         if (t256 >= min_tiles && !getenv("SC_GEMM_V1")) {
             p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (p.N + 255) / 256;
+            if (p.band < 0) p.band = p.tiles_n >= 16 ? 4 : 0;   // measured: 8192^3 +20 %; N <= 3072 (the step's shapes) neutral
             return launch256(p, s);
         }
     }
@@ -564,6 +596,8 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     p.act = flags & SC_GEMM_ACT_MASK; p.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0;
     p.trace = g_gemm_trace;
     p.rot = getenv("SC_GEMM_NOROT") ? 0 : 1;
+    p.band = getenv("SC_GEMM_BAND") ? atoi(getenv("SC_GEMM_BAND")) : -1;   // -1: chosen by the dispatcher
+    p.epi_mode = getenv("SC_GEMM_EPI") ? atoi(getenv("SC_GEMM_EPI")) : 2;
     return gemm_dispatch(p, 1, (hipStream_t)stream);
 }
 

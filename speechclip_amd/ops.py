@@ -13,7 +13,7 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, GEMM_OUT_F32, check, lib, p
 bf16 = torch.bfloat16
 
 # Optional HIP-event instrumentation of the dominant kernel (bench.py roofline leg): when PROFILE is a list, every
-# sc_gemm_bf16 launch appends (start_event, end_event, flops) recorded on the launch stream.
+# sc_gemm_bf16 launch appends (start_event, end_event, flops, shape_tag) recorded on the launch stream.
 PROFILE = None
 
 
@@ -48,7 +48,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
                              residual.stride(-2) if residual is not None else 0, M, N, K, flags, stream()), "sc_gemm_bf16")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K))
+        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, act, residual is not None, out_f32)))
     return out
 
 
@@ -61,7 +61,7 @@ def gemm_batched(a, lda, stride_a, w, stride_w, w_mod, out, ldc, stride_c, bias,
                                      M, N, K, batch, act, stream()), "sc_gemm_bf16_batched")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K * batch))
+        PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, act, False, False, batch)))
     return out
 
 
