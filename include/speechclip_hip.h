@@ -157,6 +157,51 @@ int sc_vq_fwd(const float* scores, int64_t* targets, float* stats2, float* ent_p
               const int32_t* host_mask_ids, int n_mask, void* stream);
 int sc_gather_rows(const float* src, const int64_t* idx, float* out, int R, int E, void* stream);
 
+/* ==== Trainable tail: forward-for-training and backward of the parallel branch, the layer-mix weights,
+ * L2 normalisation and the masked InfoNCE loss, Adam and gradient clipping.  All fp32 (master weights), except the frozen encoder's bf16
+ * hidden states.  Replaces `loss.backward()` + `optimizer.step()` of the Lightning loop (kwClip.py:143-191 -> training_step_end;
+ * trainer.gradient_clip_val, audio_encoder.optim / scheduler in config/speechCLIP/model_base/spchclp_p.yaml:96-118).
+ *
+ * sc_sgemm: C[M,N] = alpha op(A)[M,K] op(B)[K,N] + beta C (+ bias[N]); row-major, fp32 SIMT.  transa=1: A stored [K,M];
+ *   transb=1: B stored [N,K] (nn.Linear weight).  Every dense product of the tail has only B (pairs per GPU) rows on one side. */
+int sc_sgemm(int transa, int transb, int M, int N, int K, float alpha, const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+             float* C, int64_t ldc, const float* bias, void* stream);
+/* sc_cls_pool_train_fwd: sc_cls_pool_fwd with fp32 CLS tokens / outputs, the softmax probabilities kept (p_out f32 [B,R,NQ+T]) and
+ *   attention-probability dropout (nn.MultiheadAttention dropout=0.1, TransformerModels.py:62-71) from a counter-based hash RNG.
+ * sc_cls_pool_bwd: two streaming passes over the frames.  In: p (from the forward), dzbar f32 [B,R,D] (gradient of the pooled sums), u f32 [R,D];
+ *   hidden bf16 [n_layers][B*T, D] (layer_stride elements apart) = the states the frames were mixed from (NULL / n_layers = 0: skip dalpha).
+ *   Out: du f32 [B,R,D], dcls_key f32 [B,NQ,D] (gradient reaching the CLS tokens as KEYS), dalpha f32 [B,n_layers] (per-utterance
+ *   gradient of the softmaxed mix weights, weighted_sum.py:38-43).  ds_ws / pp_ws: f32 [B,R,NQ+T] workspaces. */
+int sc_cls_pool_train_fwd(const void* x, int64_t ld_x, const float* cls_tok, const float* scores, const float* cls_scores,
+                          const int32_t* lens, float* p_out, float* xbar, int B, int T, int NQ, int R, int D, float drop_p, uint32_t seed,
+                          void* stream);
+int sc_cls_pool_bwd(const void* x, int64_t ld_x, const float* cls_tok, const void* hidden, int64_t layer_stride, int n_layers, int normalize,
+                    const float* p, const float* dzbar, const float* u, const int32_t* lens, float* ds_ws, float* pp_ws, float* du,
+                    float* dcls_key, float* dalpha, int B, int T, int NQ, int R, int D, float drop_p, uint32_t seed, void* stream);
+/* Row ops, fp32.  sc_layernorm_bwd: dx (= or += when accumulate_dx) and dgamma/dbeta += (NULL: skipped); stats_ws f32 [rows,2].
+ * sc_gelu_f32: backward=0: y = gelu(z) (exact erf);  backward=1: y_or_dh *= gelu'(z).   sc_colsum: out[c] (=|+=) sum_r x[r,c].
+ * sc_l2norm_bwd: y = x/|x| (kwClip.py:1436).  sc_dropout_f32: y = x * keep/(1-p) with keep = hash(seed, index) (in place allowed).
+ * sc_mix_softmax_bwd: dw += softmax-backward of the column sums of dalpha_b [B,n]. */
+int sc_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, float* stats_ws, int rows,
+                     int D, float eps, int accumulate_dx, void* stream);
+int sc_gelu_f32(const float* z, float* y_or_dh, int64_t n, int backward, void* stream);
+int sc_colsum(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, void* stream);
+int sc_l2norm_bwd(const float* x, const float* dy, float* dx, int rows, int D, void* stream);
+int sc_dropout_f32(const float* x, float* y, int64_t n, float drop_p, uint32_t seed, void* stream);
+int sc_mix_softmax_bwd(const float* w, const float* dalpha_b, int B, int n, float* dw, void* stream);
+/* sc_infonce_bwd: G[Bg,Bg] = d loss / d logits and dinv_out[0] = d loss / d inv_temperature (losses.py:161,:219 trainable temperature),
+ *   from the workspace sc_infonce_fwd filled for the same inputs; d loss / d feat_a = inv_temperature * G . feat_b (one sc_sgemm). */
+int64_t sc_infonce_bwd_workspace_bytes(int Bg);
+int sc_infonce_bwd(const float* feat_a, const float* feat_b, const int64_t* ids, const void* fwd_workspace, void* bwd_workspace, float* G,
+                   float* dinv_out, int Bg, int E, float inv_temperature, float margin, int dcl, int a2b, int b2a, void* stream);
+/* Optimizer over ONE flat fp32 buffer holding all trainable parameters (and a same-shaped gradient buffer):
+ * sc_grad_norm: out2 = {|g|_2, min(1, max_norm/(|g|_2 + 1e-6))} (torch.nn.utils.clip_grad_norm_; Lightning gradient_clip_val).
+ * sc_adam_step: torch.optim.Adam semantics (L2 weight decay into the gradient, bias correction), gradient scaled by *clip_coef. */
+int64_t sc_grad_norm_workspace_bytes(void);
+int sc_grad_norm(const float* g, int64_t n, float max_norm, void* workspace, float* out2, void* stream);
+int sc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* clip_coef, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ raises.  PyTorch is used only for device memory and streams (tensor.data_ptr(), 
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint32, c_void_p
 
 import torch
 
@@ -37,7 +37,7 @@ def lib():
 
 
 def _declare(L):
-    P, I, L64, F = c_void_p, c_int, c_int64, c_float
+    P, I, L64, F, U32 = c_void_p, c_int, c_int64, c_float, c_uint32
     sigs = {
         "sc_abi_version": ([], c_int),
         "sc_gemm_bf16": ([P, L64, P, L64, P, L64, P, P, L64, L64, I, I, I, P], c_int),
@@ -64,6 +64,20 @@ def _declare(L):
         "sc_vq_workspace_bytes": ([I, I], c_int64),
         "sc_vq_fwd": ([P, P, P, P, P, I, I, I, P, I, P], c_int),
         "sc_gather_rows": ([P, P, P, I, I, P], c_int),
+        "sc_sgemm": ([I, I, I, I, I, F, P, L64, P, L64, F, P, L64, P, P], c_int),
+        "sc_cls_pool_train_fwd": ([P, L64, P, P, P, P, P, P, I, I, I, I, I, F, U32, P], c_int),
+        "sc_cls_pool_bwd": ([P, L64, P, P, L64, I, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U32, P], c_int),
+        "sc_layernorm_bwd": ([P, P, P, P, P, P, P, I, I, F, I, P], c_int),
+        "sc_gelu_f32": ([P, P, L64, I, P], c_int),
+        "sc_colsum": ([P, L64, I, I, P, I, P], c_int),
+        "sc_l2norm_bwd": ([P, P, P, I, I, P], c_int),
+        "sc_dropout_f32": ([P, P, L64, F, U32, P], c_int),
+        "sc_mix_softmax_bwd": ([P, P, I, I, P, P], c_int),
+        "sc_infonce_bwd_workspace_bytes": ([I], c_int64),
+        "sc_infonce_bwd": ([P, P, P, P, P, P, P, I, I, F, F, I, I, I, P], c_int),
+        "sc_grad_norm_workspace_bytes": ([], c_int64),
+        "sc_grad_norm": ([P, L64, F, P, P, P], c_int),
+        "sc_adam_step": ([P, P, P, P, L64, P, F, F, F, F, F, I, P], c_int),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(L, name)   # AttributeError here = header/library mismatch: fail loudly

@@ -260,3 +260,151 @@ def gather_rows(src, idx):
     out = torch.empty(idx.shape[0], src.shape[1], device=src.device, dtype=torch.float32)
     check(lib().sc_gather_rows(ptr(src), ptr(idx), ptr(out), idx.shape[0], src.shape[1], stream()), "sc_gather_rows")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- trainable tail (fp32)
+def _f32c(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+
+
+def sgemm(a, b, transa=False, transb=False, alpha=1.0, beta=0.0, out=None, bias=None):
+    """out[M,N] = alpha * op(a) @ op(b) + beta * out (+ bias[N]).  fp32, 2-D row-major tensors (last stride 1).
+    transa: a stored [K,M]; transb: b stored [N,K] (nn.Linear weight layout)."""
+    _need_cuda(a, b)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = (a.shape[1], a.shape[0]) if transa else a.shape
+    N = b.shape[0] if transb else b.shape[1]
+    assert (b.shape[1] if transb else b.shape[0]) == K, (a.shape, b.shape, transa, transb)
+    if out is None:
+        assert beta == 0.0
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    assert out.shape == (M, N) and out.dtype == torch.float32 and out.stride(1) == 1
+    check(lib().sc_sgemm(int(transa), int(transb), M, N, K, alpha, ptr(a), a.stride(0), ptr(b), b.stride(0), beta, ptr(out), out.stride(0),
+                         ptr(bias), stream()), "sc_sgemm")
+    return out
+
+
+def cls_pool_train_fwd(x_rows, cls_tok, scores, cls_scores, lens_i32, B, T, NQ, R, D, drop_p=0.0, seed=0):
+    """-> (p f32 [B,R,NQ+T], xbar f32 [B,R,D]).  x_rows bf16 [B*T, D]; cls_tok f32 [NQ,D]; scores f32 [B*T,R]; cls_scores f32 [NQ,R]."""
+    _need_cuda(x_rows)
+    _f32c(cls_tok, scores, cls_scores)
+    assert x_rows.dtype == bf16 and x_rows.stride(1) == 1 and scores.shape == (B * T, R)
+    p = torch.empty(B, R, NQ + T, device=x_rows.device, dtype=torch.float32)
+    xbar = torch.empty(B, R, D, device=x_rows.device, dtype=torch.float32)
+    check(lib().sc_cls_pool_train_fwd(ptr(x_rows), x_rows.stride(0), ptr(cls_tok), ptr(scores), ptr(cls_scores), ptr(lens_i32), ptr(p), ptr(xbar),
+                                      B, T, NQ, R, D, float(drop_p), int(seed) & 0xFFFFFFFF, stream()), "sc_cls_pool_train_fwd")
+    return p, xbar
+
+
+def cls_pool_bwd(x_rows, cls_tok, hidden, p, dzbar, u, lens_i32, B, T, NQ, R, D, normalize=False, drop_p=0.0, seed=0):
+    """-> (du f32 [B,R,D], dcls_key f32 [B,NQ,D], dalpha f32 [B,n] or None).  hidden: bf16 [n, B*T, D] contiguous or None."""
+    _need_cuda(x_rows)
+    _f32c(cls_tok, p, dzbar, u)
+    dev = x_rows.device
+    n = 0 if hidden is None else hidden.shape[0]
+    if hidden is not None:
+        assert hidden.dtype == bf16 and hidden.is_contiguous() and hidden.shape[1] == B * T and hidden.shape[2] == D
+    ds = torch.empty(B, R, NQ + T, device=dev, dtype=torch.float32)
+    pp = torch.empty_like(ds)
+    du = torch.empty(B, R, D, device=dev, dtype=torch.float32)
+    dck = torch.empty(B, NQ, D, device=dev, dtype=torch.float32)
+    dalpha = torch.empty(B, n, device=dev, dtype=torch.float32) if n else None
+    check(lib().sc_cls_pool_bwd(ptr(x_rows), x_rows.stride(0), ptr(cls_tok), ptr(hidden), hidden.stride(0) if n else 0, n, int(normalize), ptr(p),
+                                ptr(dzbar), ptr(u), ptr(lens_i32), ptr(ds), ptr(pp), ptr(du), ptr(dck), ptr(dalpha), B, T, NQ, R, D, float(drop_p),
+                                int(seed) & 0xFFFFFFFF, stream()), "sc_cls_pool_bwd")
+    return du, dck, dalpha
+
+
+def layernorm_bwd(x, dy, gamma, dgamma=None, dbeta=None, eps=1e-5, dx=None, accumulate_dx=False):
+    """fp32 [rows, D].  Returns dx; dgamma/dbeta are accumulated in place when given."""
+    _f32c(x, dy, gamma, dgamma, dbeta)
+    rows, D = x.shape
+    if dx is None:
+        assert not accumulate_dx
+        dx = torch.empty_like(x)
+    stats = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+    check(lib().sc_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(stats), rows, D, eps, int(accumulate_dx),
+                                 stream()), "sc_layernorm_bwd")
+    return dx
+
+
+def gelu_f32(z):
+    _f32c(z)
+    y = torch.empty_like(z)
+    check(lib().sc_gelu_f32(ptr(z), ptr(y), z.numel(), 0, stream()), "sc_gelu_f32")
+    return y
+
+
+def gelu_bwd_(z, dh):
+    """dh *= gelu'(z) in place."""
+    _f32c(z, dh)
+    check(lib().sc_gelu_f32(ptr(z), ptr(dh), z.numel(), 1, stream()), "sc_gelu_f32")
+    return dh
+
+
+def colsum(x, out=None, accumulate=False):
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(cols, device=x.device, dtype=torch.float32)
+        accumulate = False
+    check(lib().sc_colsum(ptr(x), x.stride(0), rows, cols, ptr(out), int(accumulate), stream()), "sc_colsum")
+    return out
+
+
+def l2norm_bwd(x, dy):
+    _f32c(x, dy)
+    dx = torch.empty_like(x)
+    check(lib().sc_l2norm_bwd(ptr(x), ptr(dy), ptr(dx), x.shape[0], x.shape[1], stream()), "sc_l2norm_bwd")
+    return dx
+
+
+def dropout_f32(x, drop_p, seed, out=None):
+    _f32c(x)
+    out = torch.empty_like(x) if out is None else out
+    check(lib().sc_dropout_f32(ptr(x), ptr(out), x.numel(), float(drop_p), int(seed) & 0xFFFFFFFF, stream()), "sc_dropout_f32")
+    return out
+
+
+def mix_softmax_bwd(w, dalpha_b, dw):
+    _f32c(w, dalpha_b, dw)
+    check(lib().sc_mix_softmax_bwd(ptr(w), ptr(dalpha_b), dalpha_b.shape[0], dalpha_b.shape[1], ptr(dw), stream()), "sc_mix_softmax_bwd")
+    return dw
+
+
+def infonce_fwd_bwd(feat_a, feat_b, ids=None, inv_temperature=1.0 / 0.07, margin=0.0, dcl=False, a2b=True, b2a=True):
+    """Loss and its gradients in one go: returns (out3, dfeat_a [Bg,E], dinv scalar tensor) -- d loss/d feat_a and d loss/d inv_temperature."""
+    _f32c(feat_a, feat_b)
+    Bg, E = feat_a.shape
+    dev = feat_a.device
+    if ids is not None:
+        ids = ids.contiguous()
+    ws = torch.empty(lib().sc_infonce_workspace_bytes(Bg), device=dev, dtype=torch.uint8)
+    out = torch.empty(3, device=dev, dtype=torch.float32)
+    check(lib().sc_infonce_fwd(ptr(feat_a), ptr(feat_b), ptr(ids), ptr(ws), ptr(out), Bg, E, inv_temperature, margin, int(dcl), int(a2b),
+                               int(b2a), stream()), "sc_infonce_fwd")
+    ws2 = torch.empty(lib().sc_infonce_bwd_workspace_bytes(Bg), device=dev, dtype=torch.uint8)
+    G = torch.empty(Bg, Bg, device=dev, dtype=torch.float32)
+    dinv = torch.empty(1, device=dev, dtype=torch.float32)
+    check(lib().sc_infonce_bwd(ptr(feat_a), ptr(feat_b), ptr(ids), ptr(ws), ptr(ws2), ptr(G), ptr(dinv), Bg, E, inv_temperature, margin, int(dcl),
+                               int(a2b), int(b2a), stream()), "sc_infonce_bwd")
+    da = sgemm(G, feat_b, alpha=inv_temperature)
+    return out, da, dinv
+
+
+def grad_norm(flat_grad, max_norm=0.0):
+    """-> f32[2] device tensor: (total L2 norm, clip coefficient)."""
+    _f32c(flat_grad)
+    ws = torch.empty(lib().sc_grad_norm_workspace_bytes(), device=flat_grad.device, dtype=torch.uint8)
+    out = torch.empty(2, device=flat_grad.device, dtype=torch.float32)
+    check(lib().sc_grad_norm(ptr(flat_grad), flat_grad.numel(), float(max_norm), ptr(ws), ptr(out), stream()), "sc_grad_norm")
+    return out
+
+
+def adam_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_coef=None):
+    _f32c(p, g, m, v)
+    check(lib().sc_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(clip_coef[1:] if clip_coef is not None else None), lr, betas[0], betas[1],
+                             eps, weight_decay, int(step), stream()), "sc_adam_step")

@@ -1,0 +1,252 @@
+"""Backward / optimizer kernels of the trainable tail vs torch autograd (fp32) on the same inputs.  Tolerances are fp32 round-off
+(different summation orders), except where bf16 frames enter (stated inline)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("transa,transb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(256, 768, 3072), (1, 768, 96), (37, 130, 19), (768, 3072, 256), (8, 768, 128000 // 50)])
+def test_sgemm(transa, transb, M, N, K):
+    from speechclip_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((K, M) if transa else (M, K), generator=g).to(dev())
+    b = torch.randn((N, K) if transb else (K, N), generator=g).to(dev())
+    bias = torch.randn(N, generator=g).to(dev())
+    c0 = torch.randn(M, N, generator=g).to(dev())
+    ref = 0.5 * ((a.t() if transa else a).double() @ (b.t() if transb else b).double()) + 2.0 * c0.double() + bias.double()
+    out = ops.sgemm(a, b, transa, transb, alpha=0.5, beta=2.0, out=c0.clone(), bias=bias)
+    tol = 1e-5 * math.sqrt(K) * 4
+    assert (out.double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item() / 10)
+    # strided operands (row slices of wider matrices)
+    wide = torch.randn(a.shape[0], a.shape[1] + 8, generator=g).to(dev())
+    av = wide[:, 4:4 + a.shape[1]]
+    out2 = ops.sgemm(av, b, transa, transb)
+    ref2 = (av.t() if transa else av).double() @ (b.t() if transb else b).double()
+    assert (out2.double() - ref2).abs().max().item() < tol * max(1.0, ref2.abs().max().item() / 10)
+
+
+def test_sgemm_split_k_weight_grad_shape():
+    """dW = dY^T X with many rows: the split-K (atomic) path."""
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(3)
+    dy, x = torch.randn(4096, 48, generator=g).to(dev()), torch.randn(4096, 96, generator=g).to(dev())
+    out = ops.sgemm(dy, x, transa=True)
+    ref = dy.double().t() @ x.double()
+    assert (out.double() - ref).abs().max().item() < 2e-3
+
+
+def test_layernorm_bwd_matches_autograd():
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for rows, D in [(256, 768), (5, 1024), (33, 128)]:
+        x = (torch.randn(rows, D, generator=g) * 2 + 0.5).to(dev()).requires_grad_(True)
+        gamma = torch.randn(D, generator=g).to(dev()).requires_grad_(True)
+        beta = torch.randn(D, generator=g).to(dev()).requires_grad_(True)
+        dy = torch.randn(rows, D, generator=g).to(dev())
+        torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5).backward(dy)
+        dg, db = torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+        dx = ops.layernorm_bwd(x.detach(), dy, gamma.detach(), dg, db)
+        assert (dx - x.grad).abs().max().item() < 2e-5 * max(1.0, x.grad.abs().max().item())
+        assert (dg - gamma.grad).abs().max().item() < 1e-4 * max(1.0, gamma.grad.abs().max().item())
+        assert (db - beta.grad).abs().max().item() < 1e-4 * max(1.0, beta.grad.abs().max().item())
+        # accumulate_dx adds onto an existing gradient
+        base = torch.randn(rows, D, generator=g).to(dev())
+        dx2 = ops.layernorm_bwd(x.detach(), dy, gamma.detach(), dx=base.clone(), accumulate_dx=True)
+        assert (dx2 - (base + x.grad)).abs().max().item() < 3e-5 * max(1.0, x.grad.abs().max().item())
+
+
+def test_gelu_fwd_bwd_exact_erf():
+    from speechclip_amd import ops
+    z = torch.linspace(-9, 9, 20001, device=dev()).requires_grad_(True)
+    y = torch.nn.functional.gelu(z)
+    dh = torch.randn(20001, generator=torch.Generator().manual_seed(1)).to(dev())
+    y.backward(dh)
+    assert (ops.gelu_f32(z.detach()) - y.detach()).abs().max().item() < 1e-6
+    assert (ops.gelu_bwd_(z.detach(), dh.clone()) - z.grad).abs().max().item() < 1e-5
+
+
+def test_colsum_l2norm_bwd_mix_softmax_bwd():
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(256, 3072, generator=g).to(dev())
+    assert (ops.colsum(x) - x.double().sum(0).float()).abs().max().item() < 1e-4
+    acc = torch.ones(3072, device=dev())
+    ops.colsum(x, acc, accumulate=True)
+    assert (acc - 1 - x.double().sum(0).float()).abs().max().item() < 1e-4
+    f = torch.randn(256, 512, generator=g).to(dev()).requires_grad_(True)
+    dy = torch.randn(256, 512, generator=g).to(dev())
+    (f / f.norm(dim=-1, keepdim=True)).backward(dy)
+    assert (ops.l2norm_bwd(f.detach(), dy) - f.grad).abs().max().item() < 1e-6
+    w = torch.randn(13, generator=g).to(dev()).requires_grad_(True)
+    dalpha_b = torch.randn(256, 13, generator=g).to(dev())
+    (torch.softmax(w, 0) * dalpha_b.sum(0)).sum().backward()
+    dw = torch.full((13,), 0.25, device=dev())
+    ops.mix_softmax_bwd(w.detach(), dalpha_b, dw)
+    assert (dw - 0.25 - w.grad).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("Bg,E,dup,margin,dcl,a2b,b2a", [(256, 512, False, 0.0, False, True, True), (300, 768, True, 0.0, False, True, True),
+                                                          (64, 512, True, 0.2, False, True, False), (130, 512, True, 0.0, True, False, True)])
+def test_infonce_backward_matches_autograd(Bg, E, dup, margin, dcl, a2b, b2a):
+    from oracle.speechclip_ref import masked_contrastive_loss
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(Bg + E)
+    a = torch.nn.functional.normalize(torch.randn(Bg, E, generator=g), dim=-1)
+    b = torch.nn.functional.normalize(torch.randn(Bg, E, generator=g), dim=-1)
+    ids = torch.arange(Bg)
+    if dup:
+        ids[1::7] = ids[0::7][: len(ids[1::7])]
+    inv_t = torch.tensor(1 / 0.07, requires_grad=True)
+    ar = a.clone().requires_grad_(True)
+    loss = masked_contrastive_loss(ar, b, ids, inv_t, margin=margin, dcl=dcl, a2b=a2b, b2a=b2a)
+    loss.backward()
+    out, da, dinv = ops.infonce_fwd_bwd(a.to(dev()), b.to(dev()), ids.to(dev()), 1 / 0.07, margin, dcl, a2b, b2a)
+    assert abs(out[0].item() - loss.item()) < 1e-4
+    assert (da.cpu() - ar.grad).abs().max().item() < 2e-5 * max(1.0, ar.grad.abs().max().item() * 10)
+    assert abs(dinv.item() - inv_t.grad.item()) < 1e-5 * max(1.0, abs(inv_t.grad.item()) * 10)
+
+
+def _pool_reference(x16, cls, u, beta, lens, NQ, H, keepmask=None, keep_scale=1.0):
+    """fp32 autograd model of the algebraic pooling: scores z.u_r + beta_r over [CLS ; valid frames], softmax, (dropout), weighted sums."""
+    B, T, D = x16.shape
+    R = NQ * H
+    z = torch.cat([cls.unsqueeze(0).expand(B, NQ, D), x16], 1)                     # [B, NQ+T, D]
+    s = torch.einsum("bkd,rd->brk", z, u) + beta.view(1, R, 1)
+    valid = torch.arange(NQ + T).view(1, 1, -1) < (lens.view(B, 1, 1) + NQ)
+    s = s.masked_fill(~valid, float("-inf"))
+    p = torch.softmax(s, -1)
+    pp = p if keepmask is None else p * keepmask * keep_scale
+    return p, torch.einsum("brk,bkd->brd", pp, z)
+
+
+@pytest.mark.parametrize("B,T,D,NQ,H,n,normalize", [(5, 37, 768, 1, 8, 13, False), (3, 50, 128, 8, 1, 0, False), (4, 21, 1024, 1, 8, 5, True)])
+def test_cls_pool_train_fwd_bwd_matches_autograd(B, T, D, NQ, H, n, normalize):
+    from speechclip_amd import ops
+    R = NQ * H
+    g = torch.Generator().manual_seed(B * 100 + T)
+    hid = torch.randn(max(n, 1), B, T, D, generator=g).to(torch.bfloat16)
+    alpha = torch.softmax(torch.randn(max(n, 1), generator=g), 0).requires_grad_(True)
+    hsrc = hid.float()
+    if normalize:
+        hsrc = torch.nn.functional.layer_norm(hsrc, (D,))
+    xmix = torch.einsum("n,nbtd->btd", alpha, hsrc)
+    x16 = xmix.to(torch.bfloat16)
+    xr = x16.float().detach().requires_grad_(True)          # the kernels see the bf16-rounded frames
+    cls = torch.randn(NQ, D, generator=g).requires_grad_(True)
+    u = (torch.randn(R, D, generator=g) * D ** -0.5).requires_grad_(True)
+    beta = torch.randn(R, generator=g)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    dzbar = torch.randn(B, R, D, generator=g)
+    p_ref, zbar_ref = _pool_reference(xr, cls, u, beta, lens, NQ, H)
+    zbar_ref.backward(dzbar)
+    # d alpha through the (unrounded) mix, as the reference autograd would see it: dalpha_n = sum dx . H_n
+    dalpha_ref = torch.einsum("btd,nbtd->bn", xr.grad, hsrc) if n else None
+
+    d = dev()
+    x_rows = x16.reshape(B * T, D).to(d)
+    scores = (x_rows.float() @ u.detach().to(d).t() + beta.to(d)).contiguous()
+    cls_scores = (cls.detach().to(d) @ u.detach().to(d).t() + beta.to(d)).contiguous()
+    lens_i = lens.to(d, torch.int32)
+    p, xbar = ops.cls_pool_train_fwd(x_rows, cls.detach().to(d).contiguous(), scores, cls_scores, lens_i, B, T, NQ, R, D)
+    assert (p.cpu() - p_ref.detach()).abs().max().item() < 2e-5
+    assert (xbar.cpu() - zbar_ref.detach()).abs().max().item() < 2e-4
+    du, dck, dalpha = ops.cls_pool_bwd(x_rows, cls.detach().to(d).contiguous(), hid.reshape(max(n, 1), B * T, D).to(d) if n else None, p, dzbar.to(d),
+                                       u.detach().to(d).contiguous(), lens_i, B, T, NQ, R, D, normalize=normalize)
+    scale = max(1.0, u.grad.abs().max().item())
+    assert (du.sum(0).cpu() - u.grad).abs().max().item() < 5e-4 * scale
+    # CLS tokens as keys: cls.grad of the reference = sum_b dz of the CLS key rows
+    assert (dck.sum(0).cpu() - cls.grad).abs().max().item() < 5e-4 * max(1.0, cls.grad.abs().max().item())
+    if n:
+        assert (dalpha.cpu() - dalpha_ref).abs().max().item() < 2e-3 * max(1.0, dalpha_ref.abs().max().item())
+
+
+def test_cls_pool_dropout_is_consistent_between_forward_and_backward():
+    """With attention dropout the forward's keep-mask must be the one the backward uses: recover the mask from p' / p and check the
+    gradients against autograd with that mask; the kept fraction must be close to 1 - p."""
+    from speechclip_amd import ops
+    B, T, D, NQ, H = 6, 200, 256, 1, 8
+    R = NQ * H
+    g = torch.Generator().manual_seed(9)
+    x16 = torch.randn(B, T, D, generator=g).to(torch.bfloat16)
+    cls = torch.randn(NQ, D, generator=g).requires_grad_(True)
+    u = (torch.randn(R, D, generator=g) * D ** -0.5).requires_grad_(True)
+    beta = torch.zeros(R)
+    lens = torch.full((B,), T)
+    dzbar = torch.randn(B, R, D, generator=g)
+    d = dev()
+    x_rows = x16.reshape(B * T, D).to(d)
+    scores = (x_rows.float() @ u.detach().to(d).t()).contiguous()
+    cls_scores = (cls.detach().to(d) @ u.detach().to(d).t()).contiguous()
+    lens_i = lens.to(d, torch.int32)
+    pd, seed = 0.1, 1234
+    p, xbar = ops.cls_pool_train_fwd(x_rows, cls.detach().to(d).contiguous(), scores, cls_scores, lens_i, B, T, NQ, R, D, pd, seed)
+    p0, xbar0 = ops.cls_pool_train_fwd(x_rows, cls.detach().to(d).contiguous(), scores, cls_scores, lens_i, B, T, NQ, R, D, 0.0, seed)
+    assert torch.equal(p, p0) and not torch.allclose(xbar, xbar0)
+    # recover the mask by probing the backward's p' workspace through a second call with a one-hot dzbar is overkill: rebuild it from
+    # linearity -- pooled sum with x = identity-like probes is not available, so compare against autograd using the mask implied by
+    # xbar: solve per (b, r) is ill-posed; instead check determinism + statistics + gradient consistency by finite differences on u.
+    p2, xbar2 = ops.cls_pool_train_fwd(x_rows, cls.detach().to(d).contiguous(), scores, cls_scores, lens_i, B, T, NQ, R, D, pd, seed)
+    assert torch.equal(xbar, xbar2)
+    p3, xbar3 = ops.cls_pool_train_fwd(x_rows, cls.detach().to(d).contiguous(), scores, cls_scores, lens_i, B, T, NQ, R, D, pd, seed + 1)
+    assert not torch.equal(xbar, xbar3)
+    # E[xbar] = xbar0 (inverted dropout): average over seeds
+    acc = torch.zeros_like(xbar0)
+    K = 64
+    for s in range(K):
+        acc += ops.cls_pool_train_fwd(x_rows, cls.detach().to(d).contiguous(), scores, cls_scores, lens_i, B, T, NQ, R, D, pd, 100 + s)[1]
+    rel = ((acc / K - xbar0).norm() / xbar0.norm()).item()
+    assert rel < 0.08, rel
+    # backward consistency: directional derivative of L = <xbar, dzbar> along a random du direction, by central differences on the
+    # forward kernel with the SAME seed (the mask is fixed, so L is smooth in u)
+    du, dck, _ = ops.cls_pool_bwd(x_rows, cls.detach().to(d).contiguous(), None, p, dzbar.to(d), u.detach().to(d).contiguous(), lens_i, B, T, NQ, R, D,
+                                  drop_p=pd, seed=seed)
+    dirn = torch.randn(R, D, generator=g).to(d) * D ** -0.5
+    eps = 1e-2
+
+    def L(uu):
+        sc = (x_rows.float() @ uu.t()).contiguous()
+        cs = (cls.detach().to(d) @ uu.t()).contiguous()
+        return (ops.cls_pool_train_fwd(x_rows, cls.detach().to(d).contiguous(), sc, cs, lens_i, B, T, NQ, R, D, pd, seed)[1].double() * dzbar.to(d).double()).sum().item()
+    fd = (L(u.detach().to(d) + eps * dirn) - L(u.detach().to(d) - eps * dirn)) / (2 * eps)
+    an = (du.sum(0).double() * dirn.double()).sum().item()
+    assert abs(fd - an) < 2e-2 * max(1.0, abs(an)), (fd, an)
+
+
+def test_dropout_f32_statistics_and_determinism():
+    from speechclip_amd import ops
+    x = torch.ones(1 << 20, device=dev())
+    y = ops.dropout_f32(x, 0.1, 77)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.9) < 3e-3
+    assert abs(y.mean().item() - 1.0) < 5e-3 and abs(y.max().item() - 1 / 0.9) < 1e-6
+    assert torch.equal(y, ops.dropout_f32(x, 0.1, 77)) and not torch.equal(y, ops.dropout_f32(x, 0.1, 78))
+    assert torch.equal(ops.dropout_f32(x, 0.0, 5), x)
+
+
+def test_adam_and_grad_clip_match_torch():
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(2)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-3, weight_decay=1e-6)
+    p, m, v = p0.clone().to(dev()), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * (3.0 if step % 2 else 0.01)
+        pt.grad = grad.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pt], 4.0)
+        opt.step()
+        gd = grad.to(dev())
+        nc = ops.grad_norm(gd, 4.0)
+        assert abs(nc[0].item() - tn.item()) < 1e-3 * tn.item()
+        ops.adam_step(p, gd, m, v, step, 1e-3, weight_decay=1e-6, clip_coef=nc)
+        assert (p.cpu() - pt.detach()).abs().max().item() < 2e-6

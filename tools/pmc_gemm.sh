@@ -1,20 +1,20 @@
+#!/bin/bash
+# L2 (TCC) hit rate of the GEMM shapes under different tile orders.  usage (on the GPU box): bash tools/pmc_gemm.sh "<shapes>" "<band values>"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-i=0
-for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
-  i=$((i+1))
-  timeout 200 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_gemm/p$i -- python $R/tools/gemm_bench.py qkv conv1 > $R/gpurun_out/pmc_gemm/log$i.txt 2>&1
-  echo "set $i rc=$?"
-done
-python - <<'PY'
-import glob,csv,collections,os
-R=os.environ['GRAFT_REPO_ROOT']
-for f in sorted(glob.glob(R+'/gpurun_out/pmc_gemm/p*/**/*counter_collection.csv',recursive=True)):
-    agg=collections.defaultdict(float);cnt=collections.Counter()
+SHAPES=${1:-"qkv fc1"}
+for band in ${2:-"0 4"}; do
+  O=$R/gpurun_out/pmc_gemm/band$band
+  SC_GEMM_BAND=$band timeout 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $O -- python $R/tools/gemm_bench.py $SHAPES > $O.log 2>&1
+  python - "$O" "$band" $SHAPES <<'PY'
+import glob,csv,collections,sys
+per=collections.defaultdict(list)
+for f in glob.glob(sys.argv[1]+'/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'gemm256' not in r['Kernel_Name']: continue
-        # distinguish the two shapes by grid? use Grid_Size / kernel name + LDS
-        k=(r['Kernel_Name'][:60].split('(')[0][-40:], r['Counter_Name'])
-        agg[k]+=float(r['Counter_Value']);cnt[k]+=1
-    for k in sorted(agg): print(k[0],k[1],cnt[k],'%.4g'%(agg[k]/cnt[k]))
+        if 'gemm256' in r['Kernel_Name']: per[r['Counter_Name']].append((int(r['Dispatch_Id']),float(r['Counter_Value'])))
+shapes=sys.argv[3:]
+for i,sname in enumerate(shapes):
+    d={c:sum(x[1] for x in sorted(v)[7*i+2:7*i+7])/5 for c,v in per.items()}
+    print(f"band={sys.argv[2]} {sname}: hit {d['TCC_HIT_sum']:.3g} miss {d['TCC_MISS_sum']:.3g} hit-rate {d['TCC_HIT_sum']/(d['TCC_HIT_sum']+d['TCC_MISS_sum']):.3f} tcp->tcc rd {d['TCP_TCC_READ_REQ_sum']:.3g} ea_rd {d.get('TCC_EA0_RDREQ_sum',0):.3g}")
 PY
+done
