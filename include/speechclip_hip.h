@@ -169,13 +169,14 @@ int sc_sgemm(int transa, int transb, int M, int N, int K, float alpha, const flo
 /* sc_cls_pool_train_fwd: sc_cls_pool_fwd with fp32 CLS tokens / outputs, the softmax probabilities kept (p_out f32 [B,R,NQ+T]) and
  *   attention-probability dropout (nn.MultiheadAttention dropout=0.1, TransformerModels.py:62-71) from a counter-based hash RNG.
  * sc_cls_pool_bwd: two streaming passes over the frames.  In: p (from the forward), dzbar f32 [B,R,D] (gradient of the pooled sums), u f32 [R,D];
- *   hidden bf16 [n_layers][B*T, D] (layer_stride elements apart) = the states the frames were mixed from (NULL / n_layers = 0: skip dalpha).
+ *   hidden bf16 (f32 when hidden_f32: the pre-LN encoder's residual stream) [n_layers][B*T, D] (layer_stride elements apart) = the states the frames were mixed from (NULL / n_layers = 0: skip dalpha).
  *   Out: du f32 [B,R,D], dcls_key f32 [B,NQ,D] (gradient reaching the CLS tokens as KEYS), dalpha f32 [B,n_layers] (per-utterance
  *   gradient of the softmaxed mix weights, weighted_sum.py:38-43).  ds_ws / pp_ws: f32 [B,R,NQ+T] workspaces. */
 int sc_cls_pool_train_fwd(const void* x, int64_t ld_x, const float* cls_tok, const float* scores, const float* cls_scores,
                           const int32_t* lens, float* p_out, float* xbar, int B, int T, int NQ, int R, int D, float drop_p, uint32_t seed,
                           void* stream);
-int sc_cls_pool_bwd(const void* x, int64_t ld_x, const float* cls_tok, const void* hidden, int64_t layer_stride, int n_layers, int normalize,
+int sc_cls_pool_bwd(const void* x, int64_t ld_x, const float* cls_tok, const void* hidden, int hidden_f32, int64_t layer_stride, int n_layers,
+                    int normalize,
                     const float* p, const float* dzbar, const float* u, const int32_t* lens, float* ds_ws, float* pp_ws, float* du,
                     float* dcls_key, float* dalpha, int B, int T, int NQ, int R, int D, float drop_p, uint32_t seed, void* stream);
 /* Row ops, fp32.  sc_layernorm_bwd: dx (= or += when accumulate_dx) and dgamma/dbeta += (NULL: skipped); stats_ws f32 [rows,2].
@@ -188,6 +189,7 @@ int sc_gelu_f32(const float* z, float* y_or_dh, int64_t n, int backward, void* s
 int sc_colsum(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, void* stream);
 int sc_l2norm_bwd(const float* x, const float* dy, float* dx, int rows, int D, void* stream);
 int sc_dropout_f32(const float* x, float* y, int64_t n, float drop_p, uint32_t seed, void* stream);
+int sc_add_rows_f32(const float* a, const float* b, float* out, int rows, int cols, int b_rows, float alpha, void* stream);   /* out = alpha*a + b[r % b_rows] */
 int sc_mix_softmax_bwd(const float* w, const float* dalpha_b, int B, int n, float* dw, void* stream);
 /* sc_infonce_bwd: G[Bg,Bg] = d loss / d logits and dinv_out[0] = d loss / d inv_temperature (losses.py:161,:219 trainable temperature),
  *   from the workspace sc_infonce_fwd filled for the same inputs; d loss / d feat_a = inv_temperature * G . feat_b (one sc_sgemm). */

@@ -66,13 +66,14 @@ def _declare(L):
         "sc_gather_rows": ([P, P, P, I, I, P], c_int),
         "sc_sgemm": ([I, I, I, I, I, F, P, L64, P, L64, F, P, L64, P, P], c_int),
         "sc_cls_pool_train_fwd": ([P, L64, P, P, P, P, P, P, I, I, I, I, I, F, U32, P], c_int),
-        "sc_cls_pool_bwd": ([P, L64, P, P, L64, I, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U32, P], c_int),
+        "sc_cls_pool_bwd": ([P, L64, P, P, I, L64, I, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U32, P], c_int),
         "sc_layernorm_bwd": ([P, P, P, P, P, P, P, I, I, F, I, P], c_int),
         "sc_gelu_f32": ([P, P, L64, I, P], c_int),
         "sc_colsum": ([P, L64, I, I, P, I, P], c_int),
         "sc_l2norm_bwd": ([P, P, P, I, I, P], c_int),
         "sc_dropout_f32": ([P, P, L64, F, U32, P], c_int),
         "sc_mix_softmax_bwd": ([P, P, I, I, P, P], c_int),
+        "sc_add_rows_f32": ([P, P, P, I, I, I, F, P], c_int),
         "sc_infonce_bwd_workspace_bytes": ([I], c_int64),
         "sc_infonce_bwd": ([P, P, P, P, P, P, P, I, I, F, F, I, I, I, P], c_int),
         "sc_grad_norm_workspace_bytes": ([], c_int64),

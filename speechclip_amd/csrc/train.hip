@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void cls_pool_bwd_scores_kernel(const bf16_t* 
 //   dalpha_n[b]  = sum_t dz_t . H_n[b,t]  (H_n layer-normalised without affine when `normalize`)   -> dalpha [B, n]
 template <int DCH>
 __global__ __launch_bounds__(256) void cls_pool_bwd_frames_kernel(const bf16_t* __restrict__ x, int64_t ld_x, const float* __restrict__ cls_tok,
-                                                                  const bf16_t* __restrict__ hidden, int64_t layer_stride, int n_layers, int normalize, float eps,
+                                                                  const void* __restrict__ hidden, int hidden_f32, int64_t layer_stride, int n_layers, int normalize, float eps,
                                                                   const float* __restrict__ pp, const float* __restrict__ ds, const float* __restrict__ dzbar,
                                                                   const float* __restrict__ u, const int32_t* __restrict__ lens,
                                                                   float* __restrict__ du, float* __restrict__ dcls_key, float* __restrict__ dalpha,
@@ -245,8 +245,14 @@ __global__ __launch_bounds__(256) void cls_pool_bwd_frames_kernel(const bf16_t* 
                 for (int c = 0; c < DCH; ++c) {
                     const int e = c * 256 + lane * 4;
                     if (e < D) {
-                        const uint2 t = *(const uint2*)(hidden + (int64_t)n * layer_stride + row * D + e);
-                        hv[c][0] = lo2f(t.x); hv[c][1] = hi2f(t.x); hv[c][2] = lo2f(t.y); hv[c][3] = hi2f(t.y);
+                        const int64_t off = (int64_t)n * layer_stride + row * D + e;
+                        if (hidden_f32) {
+                            const f32x4_t t = *(const f32x4_t*)((const float*)hidden + off);
+                            hv[c][0] = t[0]; hv[c][1] = t[1]; hv[c][2] = t[2]; hv[c][3] = t[3];
+                        } else {
+                            const uint2 t = *(const uint2*)((const bf16_t*)hidden + off);
+                            hv[c][0] = lo2f(t.x); hv[c][1] = hi2f(t.x); hv[c][2] = lo2f(t.y); hv[c][3] = hi2f(t.y);
+                        }
                     } else { hv[c][0] = hv[c][1] = hv[c][2] = hv[c][3] = 0.f; }
                 }
                 if (normalize) {
@@ -411,6 +417,13 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     y[i] = keep_elem(seed, (uint32_t)i, thresh) ? x[i] * keep_scale : 0.f;
+}
+// out[r, c] = alpha * a[r, c] + b[r % b_rows, c]   (residual adds of the branch: b_rows = rows, or 1 for the broadcast CLS token)
+__global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int rows, int cols, int b_rows, float alpha) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    out[i] = fmaf(alpha, a[i], b[(int64_t)(r % b_rows) * cols + c]);
 }
 // layer-mix weights: alpha = softmax(w);  dw_n = alpha_n (dalpha_n - sum alpha dalpha) with dalpha = column sums of dalpha_b [B, n]
 __global__ void mix_softmax_bwd_kernel(const float* __restrict__ w, const float* __restrict__ dalpha_b, int B, int n, float* __restrict__ dw) {
@@ -582,8 +595,8 @@ extern "C" int sc_cls_pool_train_fwd(const void* x, int64_t ld_x, const float* c
     return 0;
 }
 
-extern "C" int sc_cls_pool_bwd(const void* x, int64_t ld_x, const float* cls_tok, const void* hidden, int64_t layer_stride, int n_layers,
-                               int normalize, const float* p, const float* dzbar, const float* u, const int32_t* lens, float* ds_ws,
+extern "C" int sc_cls_pool_bwd(const void* x, int64_t ld_x, const float* cls_tok, const void* hidden, int hidden_f32, int64_t layer_stride,
+                               int n_layers, int normalize, const float* p, const float* dzbar, const float* u, const int32_t* lens, float* ds_ws,
                                float* pp_ws, float* du, float* dcls_key, float* dalpha, int B, int T, int NQ, int R, int D, float drop_p,
                                uint32_t seed, void* stream) {
     if (pool_args_ok(T, NQ, R, D, ld_x, "sc_cls_pool_bwd")) return -1;
@@ -595,7 +608,7 @@ extern "C" int sc_cls_pool_bwd(const void* x, int64_t ld_x, const float* cls_tok
                   drop_thresh(drop_p), 1.0f / (1.0f - drop_p));
     SC_CHECK_LAUNCH();
     const int lds_b = 4 * 8 * D * 4;
-    POOL_DISPATCH(cls_pool_bwd_frames_kernel, lds_b, (const bf16_t*)x, ld_x, cls_tok, (const bf16_t*)(n_layers ? hidden : nullptr), layer_stride,
+    POOL_DISPATCH(cls_pool_bwd_frames_kernel, lds_b, (const bf16_t*)x, ld_x, cls_tok, (const void*)(n_layers ? hidden : nullptr), hidden_f32, layer_stride,
                   n_layers, normalize, 1e-5f, pp_ws, ds_ws, dzbar, u, lens, du, dcls_key, dalpha, T, NQ, R, D);
     SC_CHECK_LAUNCH();
     return 0;
@@ -643,6 +656,13 @@ extern "C" int sc_dropout_f32(const float* x, float* y, int64_t n, float drop_p,
     if (n <= 0) return 0;
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, seed, drop_thresh(drop_p),
                        1.0f / (1.0f - drop_p));
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_add_rows_f32(const float* a, const float* b, float* out, int rows, int cols, int b_rows, float alpha, void* stream) {
+    SC_CHECK_ARG(rows > 0 && cols > 0 && b_rows > 0, "sc_add_rows_f32: bad shape");
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)(((int64_t)rows * cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, rows, cols, b_rows, alpha);
     SC_CHECK_LAUNCH();
     return 0;
 }

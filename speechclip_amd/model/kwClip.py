@@ -91,7 +91,8 @@ class KWClipBase(BaseLightningModel):
         if "loss" in outputs:
             return {"loss": torch.mean(outputs["loss"])}
         if "loss_feats" in outputs and "log_metrics" in outputs:
-            losses_ = self.compute_loss(parallel.gather_loss_feats(outputs["loss_feats"]))
+            from ..train_tail import gather_loss_feats_train
+            losses_ = self.compute_loss(gather_loss_feats_train(outputs["loss_feats"]))
             self.log_dict(self._reduce_metrics("train", losses_, outputs["log_metrics"]), on_step=True, on_epoch=True,
                           prog_bar=True, logger=True, sync_dist=True)
             return {"loss": losses_["loss"]}
@@ -169,7 +170,15 @@ class KWClipBase(BaseLightningModel):
 
     def configure_optimizers(self) -> Tuple[list, list]:
         params = self.getTrainableParams()
-        opt = getattr(torch.optim, self.config.audio_encoder.optim.name)(params, **self.config.audio_encoder.optim.args)
+        oc = self.config.audio_encoder.optim
+        if oc.name == "Adam" and all(p.is_cuda for p in params):
+            # same update rule as torch.optim.Adam, on one flat buffer (sc_grad_norm + sc_adam_step); Lightning's
+            # trainer.gradient_clip_val (clip_grad_norm_) is folded into the step
+            from ..train_tail import FusedAdam
+            clip = float(self.config.trainer.get("gradient_clip_val", 0.0) or 0.0) if hasattr(self.config, "trainer") else 0.0
+            opt = FusedAdam(params, max_grad_norm=clip, **oc.args)
+        else:
+            opt = getattr(torch.optim, oc.name)(params, **oc.args)
         sched = get_scheduler(optimizer=opt, **self.config.audio_encoder.scheduler)
         return [opt], [{"scheduler": sched, "interval": "step"}]
 
@@ -192,11 +201,33 @@ class KW_ParallelBranch(nn.Module):
         raise NotImplementedError("analysis-only path (feature_extractor_s3prl); SURVEY.md section 8f")
 
     def forward(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and self.cls.requires_grad:
+            return self._forward_train(audio_feat, audio_len)
         out = self.self_att.forward_cls(self.cls, audio_feat, audio_len)            # bf16 [B, d]
         if hasattr(self, "linear_proj"):
             out = ops.gemm(out, self.linear_proj.weight.detach().to(torch.bfloat16).contiguous(),
                            self.linear_proj.bias.detach().float().contiguous(), out_f32=True)
         return out
+
+
+def _kw_parallel_forward_train(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> torch.Tensor:
+    """Differentiable path (train_tail.ParallelBranchTrainFn): fp32 master weights, dropout active in train() mode."""
+    from ..train_tail import ParallelBranchTrainFn
+    L = self.self_att.model.layers[0]
+    sa = L.self_attn
+    src = getattr(audio_feat, "_mix_src", None)
+    hidden, mixw, normalize = (src[0], src[1].weights, src[1].normalize_features) if src is not None else (None, None, False)
+    drop_p = float(L.dropout.p) if self.training else 0.0
+    seed = int(torch.randint(0, 2 ** 31 - 8, (1,)).item()) if drop_p > 0 else 0
+    meta = dict(heads=self.self_att.nhead, eps=self.self_att.eps, drop_p=drop_p, seed=seed, normalize=normalize)
+    proj = (self.linear_proj.weight, self.linear_proj.bias) if hasattr(self, "linear_proj") else (None, None)
+    return ParallelBranchTrainFn.apply(meta, hidden, audio_feat.detach(), audio_len, mixw, self.cls, sa.in_proj_weight, sa.in_proj_bias,
+                                       sa.out_proj.weight, sa.out_proj.bias, L.norm1.weight, L.norm1.bias, L.linear1.weight, L.linear1.bias,
+                                       L.linear2.weight, L.linear2.bias, L.norm2.weight, L.norm2.bias, self.self_att.model.norm.weight,
+                                       self.self_att.model.norm.bias, *proj)
+
+
+KW_ParallelBranch._forward_train = _kw_parallel_forward_train
 
 
 class KW_CascadedBranch(nn.Module):
@@ -227,6 +258,9 @@ class KW_CascadedBranch(nn.Module):
                                          parallel=bn.parallel if hasattr(bn, "parallel") else False)
 
     def forward(self, audio_feat: torch.Tensor, audio_len: torch.Tensor):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training the cascaded branch (train-mode Kw_BatchNorm statistics, straight-through VQ, gradients through "
+                                      "the CLIP text tower) is SURVEY.md section 8f work after the parallel tail; use eval() / no_grad() here")
         B, K = audio_feat.shape[0], self.keyword_num
         kw = self.self_att.forward_cls(self.cls, audio_feat, audio_len)                       # bf16 [B, K, d]
         kw = ops.gemm(kw.view(B * K, -1), self.linear_proj.weight.detach().to(torch.bfloat16).contiguous(),
@@ -296,7 +330,11 @@ class KWClip_GeneralTransformer(KWClipBase):
             p_feat = self.parallel_branch(audio_feat=audio_feat, audio_len=audio_len)
             if self.p_branch_proj_net is not None:
                 p_feat = self.p_branch_proj_net(p_feat)
-            p_feat = ops.l2norm(p_feat)
+            if p_feat.requires_grad:
+                from ..train_tail import L2NormFn
+                p_feat = L2NormFn.apply(p_feat)
+            else:
+                p_feat = ops.l2norm(p_feat)
         return c_feat, p_feat, vq, kw
 
     def encode_speech(self, wav) -> dict:

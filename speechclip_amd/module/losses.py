@@ -38,5 +38,9 @@ class MaskedContrastiveLoss(nn.Module):
         assert feat_A.shape == feat_B.shape, (feat_A.shape, feat_B.shape)
         if index is not None:
             assert index.shape[0] == feat_A.shape[0], (index.shape, feat_A.shape)
+        if torch.is_grad_enabled() and (feat_A.requires_grad or feat_B.requires_grad or (self.temperature_trainable and self.temperature.requires_grad)):
+            from ..train_tail import MaskedContrastiveFn
+            return MaskedContrastiveFn.apply(feat_A, feat_B, index, self.temperature if self.temperature_trainable else None,
+                                             self.current_temperature, self.margin, self.dcl, self.a2b, self.b2a)
         out = ops.infonce(feat_A.float(), feat_B.float(), index, self.current_temperature, self.margin, self.dcl, self.a2b, self.b2a)
         return out[0]

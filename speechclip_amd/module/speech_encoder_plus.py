@@ -141,7 +141,12 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             hs = layers()
             out.extend([{"last_hidden_state": hs[-1], "hidden_states": hs}, feat_len])
         elif feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
-            out.extend([self.weightedsum_layer(hidden)[:, :T], feat_len])
+            mixed = self.weightedsum_layer(hidden)[:, :T]
+            if torch.is_grad_enabled() and self.weightedsum_layer.weights.requires_grad:
+                # training of the tail (speechclip_amd/train_tail.py): the branch's backward produces the gradient of the mix weights
+                # in the same pass over the frames, so it needs the frozen states the frames were mixed from
+                mixed._mix_src = (hidden, self.weightedsum_layer)
+            out.extend([mixed, feat_len])
         elif isinstance(feat_select_idx, list):
             hs = layers()
             out.extend([[hs[i] for i in feat_select_idx], feat_len])

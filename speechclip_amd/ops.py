@@ -299,19 +299,19 @@ def cls_pool_train_fwd(x_rows, cls_tok, scores, cls_scores, lens_i32, B, T, NQ, 
 
 
 def cls_pool_bwd(x_rows, cls_tok, hidden, p, dzbar, u, lens_i32, B, T, NQ, R, D, normalize=False, drop_p=0.0, seed=0):
-    """-> (du f32 [B,R,D], dcls_key f32 [B,NQ,D], dalpha f32 [B,n] or None).  hidden: bf16 [n, B*T, D] contiguous or None."""
+    """-> (du f32 [B,R,D], dcls_key f32 [B,NQ,D], dalpha f32 [B,n] or None).  hidden: bf16 / f32 [n, B*T, D] contiguous or None."""
     _need_cuda(x_rows)
     _f32c(cls_tok, p, dzbar, u)
     dev = x_rows.device
     n = 0 if hidden is None else hidden.shape[0]
     if hidden is not None:
-        assert hidden.dtype == bf16 and hidden.is_contiguous() and hidden.shape[1] == B * T and hidden.shape[2] == D
+        assert hidden.dtype in (bf16, torch.float32) and hidden.is_contiguous() and hidden.shape[1] == B * T and hidden.shape[2] == D
     ds = torch.empty(B, R, NQ + T, device=dev, dtype=torch.float32)
     pp = torch.empty_like(ds)
     du = torch.empty(B, R, D, device=dev, dtype=torch.float32)
     dck = torch.empty(B, NQ, D, device=dev, dtype=torch.float32)
     dalpha = torch.empty(B, n, device=dev, dtype=torch.float32) if n else None
-    check(lib().sc_cls_pool_bwd(ptr(x_rows), x_rows.stride(0), ptr(cls_tok), ptr(hidden), hidden.stride(0) if n else 0, n, int(normalize), ptr(p),
+    check(lib().sc_cls_pool_bwd(ptr(x_rows), x_rows.stride(0), ptr(cls_tok), ptr(hidden), int(n > 0 and hidden.dtype == torch.float32), hidden.stride(0) if n else 0, n, int(normalize), ptr(p),
                                 ptr(dzbar), ptr(u), ptr(lens_i32), ptr(ds), ptr(pp), ptr(du), ptr(dck), ptr(dalpha), B, T, NQ, R, D, float(drop_p),
                                 int(seed) & 0xFFFFFFFF, stream()), "sc_cls_pool_bwd")
     return du, dck, dalpha
@@ -366,6 +366,14 @@ def dropout_f32(x, drop_p, seed, out=None):
     _f32c(x)
     out = torch.empty_like(x) if out is None else out
     check(lib().sc_dropout_f32(ptr(x), ptr(out), x.numel(), float(drop_p), int(seed) & 0xFFFFFFFF, stream()), "sc_dropout_f32")
+    return out
+
+
+def add_rows(a, b, alpha=1.0, out=None):
+    """out = alpha * a + b[r % b.shape[0]]  (fp32 2-D)."""
+    _f32c(a, b)
+    out = torch.empty_like(a) if out is None else out
+    check(lib().sc_add_rows_f32(ptr(a), ptr(b), ptr(out), a.shape[0], a.shape[1], b.shape[0], float(alpha), stream()), "sc_add_rows_f32")
     return out
 
 

@@ -3,20 +3,17 @@ import torch
 
 
 def get_scheduler(name: str, optimizer: torch.optim.Optimizer, **kwargs):
-    if name == "linear_warmup_decay":
-        warmup, max_step = kwargs["warmup"], kwargs["max_step"]
-        init_lr, final_lr = kwargs.get("init_lr", 0.0), kwargs.get("final_lr", 0.0)
-        base = optimizer.param_groups[0]["lr"]
+    if name == "linear_warmup_decay":      # avssl/optim/scheduler.py:22-38, same multiplier step for step
+        warmup, max_step = kwargs.get("warmup", 4000), kwargs.get("max_step", 1000000)
+        final_lr_rate = kwargs.get("final_lr", 1e-8) / optimizer.param_groups[0]["lr"]
 
         def fn(step):
             if step < warmup:
-                lr = init_lr + (base - init_lr) * step / max(1, warmup)
-            else:
-                lr = base + (final_lr - base) * min(1.0, (step - warmup) / max(1, max_step - warmup))
-            return lr / base
+                return (step + 1) / warmup
+            return 1.0 - (1.0 - final_lr_rate) * (step + 1 - warmup) / (max_step - warmup)
 
         return torch.optim.lr_scheduler.LambdaLR(optimizer, fn)
     if name == "noam":
-        warmup = kwargs["warmup"]
-        return torch.optim.lr_scheduler.LambdaLR(optimizer, lambda s: min((s + 1) ** -0.5, (s + 1) * warmup ** -1.5) * warmup ** 0.5)
+        warmup = kwargs.get("warmup", 4000)     # avssl/optim/scheduler.py:10-19
+        return torch.optim.lr_scheduler.LambdaLR(optimizer, lambda s: (s + 1) / warmup if s < warmup else (warmup / (s + 1)) ** 0.5)
     raise NotImplementedError(name)

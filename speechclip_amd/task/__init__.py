@@ -45,10 +45,35 @@ class BaseTask:
 
 
 class TrainKWClip_GeneralTransformer(BaseTask):
-    def run(self, batches=None):
-        """Build the model; if `batches` (iterable of collate_general-style dicts) is given, run validation_step /
-        validation_step_end / validation_epoch_end over them exactly in Lightning's order and return the recalls."""
+    @staticmethod
+    def fit(model, train_batches, max_steps=None, log_every=0):
+        """Lightning's training loop for the trainable tail, hook for hook: training_step -> training_step_end -> backward ->
+        (gradient clipping inside the optimizer step) -> optimizer.step -> scheduler.step (interval: step).  Returns the loss history."""
+        model = model.cuda().train()
+        (opt,), (sch,) = model.configure_optimizers()
+        hist = []
+        for i, b in enumerate(train_batches):
+            if max_steps is not None and i >= max_steps:
+                break
+            b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+            opt.zero_grad()
+            loss = model.training_step_end(model.training_step(b, i))["loss"]
+            loss.backward()
+            opt.step()
+            sch["scheduler"].step()
+            hist.append(float(loss))
+            if log_every and i % log_every == 0:
+                print(f"step {i}: loss {hist[-1]:.4f} lr {opt.param_groups[0]['lr']:.3e}")
+        return hist
+
+    def run(self, batches=None, train_batches=None):
+        """Build the model; `train_batches` (iterable of collate_general-style dicts): train the tail over them (fit);
+        `batches`: run validation_step / validation_step_end / validation_epoch_end over them exactly in Lightning's order and
+        return the recalls."""
         model = self.build_model(KWClip_GeneralTransformer)
+        if train_batches is not None:
+            max_steps = self.config.trainer.get("max_steps", None) if hasattr(self.config, "trainer") else None
+            self.loss_history = self.fit(model, train_batches, max_steps=max_steps)
         if batches is None:
             return model
         model = model.cuda().eval()

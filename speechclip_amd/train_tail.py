@@ -1,0 +1,283 @@
+"""Training of the trainable tail on MI355X.
+
+The reference trains, on top of frozen HuBERT and CLIP, only the parallel branch (`KW_ParallelBranch`, kwClip.py:1004-1108), the
+layer-mix weights (`WeightedSumLayer.weights`, weighted_sum.py:19) and -- for the large models -- the loss temperature
+(losses.py:161); Lightning calls `training_step` -> `training_step_end` -> `loss.backward()` -> clip(4) -> Adam -> LambdaLR.
+Here the same hook protocol works with torch autograd as the *plumbing*: three `torch.autograd.Function`s whose forward and backward
+bodies are calls into libspeechclip_hip.so (fp32 master weights; frames stay bf16), so `loss.backward()` fills `.grad` of exactly the
+parameters the reference optimises and any torch optimizer -- or `FusedAdam` below (sc_grad_norm + sc_adam_step on one flat buffer)
+-- can step them.
+
+  ParallelBranchTrainFn : hidden states -> layer mix -> [CLS; frames] encoder layer (CLS row only) -> final LN -> Linear  [B, E]
+  L2NormFn              : x / |x|                                                      (kwClip.py:1436)
+  MaskedContrastiveFn   : masked InfoNCE on the gathered global batch                  (losses.py:185-245)
+  GatherFeatsFn         : RCCL all-gather whose backward keeps the local rows           (replaces DP's gather, kwClip.py:147-191)
+
+Dropout (0.1 at four sites of nn.TransformerEncoderLayer) uses a counter-based hash RNG inside the kernels, seeded per call from
+torch's generator: masks are reproducible from (seed, site) and are regenerated -- not stored -- in the backward.
+"""
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops, parallel
+
+BF = torch.bfloat16
+
+
+def _c(t):
+    return t.detach().float().contiguous()
+
+
+class ParallelBranchTrainFn(torch.autograd.Function):
+    """out f32 [B, E (or D)] = linear_proj(norm(layer([CLS; mix(hidden)]))[:, 0]).
+
+    args: meta (dict: heads, eps, drop_p, seed, normalize), hidden bf16 [n, B, Tp, D] (frozen encoder states) or None,
+          x16 bf16 [B, T<=Tp, D] view of the mixed frames (what WeightedSumLayer produced from `hidden`), lens int [B],
+          then tensors: mixw [n] | None, cls [1,1,D], in_w [3D,D], in_b [3D], out_w, out_b, n1w, n1b, l1w, l1b, l2w, l2b, n2w, n2b,
+          nfw, nfb, pw [E,D] | None, pb [E] | None."""
+
+    @staticmethod
+    def forward(ctx, meta, hidden, x16, lens, mixw, cls, in_w, in_b, out_w, out_b, n1w, n1b, l1w, l1b, l2w, l2b, n2w, n2b, nfw, nfb, pw, pb):
+        from .module.kw_modules.TransformerModels import _frames_view
+        H, eps, pd, seed = meta["heads"], meta["eps"], float(meta["drop_p"]), int(meta["seed"])
+        B, T, D = x16.shape
+        NQ = cls.shape[-2]
+        assert NQ == 1, "the parallel branch has one CLS token (kwClip.py:1040-1047)"
+        hd, R = D // H, NQ * H
+        scale = hd ** -0.5
+        rows, Tp = _frames_view(x16)
+        dev = rows.device
+        lens_i = lens.to(device=dev, dtype=torch.int32).contiguous()
+        c = _c(cls).view(NQ, D)
+        Win, bin_ = _c(in_w), _c(in_b)
+        # ---- parameter-only part: queries of the CLS token, u_r = scale Wk_h^T q_h, beta_r = scale q_h . bk_h
+        qt = ops.sgemm(c, Win[:D], transb=True, bias=bin_[:D])                              # [NQ, D]
+        U = torch.empty(R, D, device=dev, dtype=torch.float32)
+        beta = torch.empty(R, device=dev, dtype=torch.float32)
+        for h in range(H):
+            sl = slice(h * hd, (h + 1) * hd)
+            ops.sgemm(qt[:, sl], Win[D + h * hd:D + (h + 1) * hd], alpha=scale, out=U.view(NQ, H, D)[:, h, :])
+            ops.sgemm(qt[:, sl], bin_[D + h * hd:D + (h + 1) * hd].view(hd, 1), alpha=scale, out=beta.view(NQ, H)[:, h:h + 1])
+        # ---- frame scores on the MFMA GEMM (bf16 frames x bf16 u, fp32 accumulate/out), pooling in fp32
+        scores = ops.gemm(rows, U.to(BF).contiguous(), beta, out_f32=True)                    # [B*Tp, R]
+        cls_scores = ops.sgemm(c, U, transb=True, bias=beta)                                  # [NQ, R]
+        p, zbar = ops.cls_pool_train_fwd(rows, c, scores, cls_scores, lens_i, B, Tp, NQ, R, D, pd, seed)
+        att = torch.empty(B * NQ, D, device=dev, dtype=torch.float32)
+        for h in range(H):
+            ops.sgemm(zbar[:, h, :], Win[2 * D + h * hd:2 * D + (h + 1) * hd], transb=True, bias=bin_[2 * D + h * hd:2 * D + (h + 1) * hd],
+                      out=att[:, h * hd:(h + 1) * hd])
+        # ---- rest of the encoder layer on the CLS rows (post-LN), final norm, projection
+        sa = ops.sgemm(att, _c(out_w), transb=True, bias=_c(out_b))
+        if pd > 0:
+            ops.dropout_f32(sa, pd, seed + 1, out=sa)
+        y = ops.add_rows(sa, c)                                                               # x + dropout1(SA(x)), x = CLS token
+        x1 = ops.layernorm(y, _c(n1w), _c(n1b), eps, out_f32=True)
+        z1 = ops.sgemm(x1, _c(l1w), transb=True, bias=_c(l1b))
+        hm = ops.gelu_f32(z1)
+        if pd > 0:
+            ops.dropout_f32(hm, pd, seed + 2, out=hm)
+        ff = ops.sgemm(hm, _c(l2w), transb=True, bias=_c(l2b))
+        if pd > 0:
+            ops.dropout_f32(ff, pd, seed + 3, out=ff)
+        y2 = ops.add_rows(ff, x1)
+        x2 = ops.layernorm(y2, _c(n2w), _c(n2b), eps, out_f32=True)
+        x3 = ops.layernorm(x2, _c(nfw), _c(nfb), 1e-5, out_f32=True)
+        out = ops.sgemm(x3, _c(pw), transb=True, bias=_c(pb)) if pw is not None else x3.clone()
+        ctx.meta = dict(meta, B=B, Tp=Tp, D=D, NQ=NQ, R=R, hd=hd, scale=scale)
+        ctx.hidden = hidden
+        ctx.has = (mixw is not None, pw is not None)
+        ctx.save_for_backward(rows, lens_i, c, Win, qt, U, p, zbar, att, y, x1, z1, hm, y2, x2, x3,
+                              _c(out_w), _c(n1w), _c(l1w), _c(l2w), _c(n2w), _c(nfw), _c(pw) if pw is not None else c,
+                              _c(mixw) if mixw is not None else c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rows, lens_i, c, Win, qt, U, p, zbar, att, y, x1, z1, hm, y2, x2, x3, Wo, g1, W1, W2, g2, gf, Wp, mixw) = ctx.saved_tensors
+        m = ctx.meta
+        B, Tp, D, NQ, R, hd, H, scale, eps, pd, seed = m["B"], m["Tp"], m["D"], m["NQ"], m["R"], m["hd"], m["heads"], m["scale"], m["eps"], float(m["drop_p"]), int(m["seed"])
+        has_mix, has_proj = ctx.has
+        dev = rows.device
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)   # noqa: E731
+        dout = dout.float().contiguous()
+        # projection, final norm, norm2
+        if has_proj:
+            dpw = ops.sgemm(dout, x3, transa=True)
+            dpb = ops.colsum(dout)
+            dx3 = ops.sgemm(dout, Wp)
+        else:
+            dpw = dpb = None
+            dx3 = dout
+        dnfw, dnfb, dn2w, dn2b, dn1w, dn1b = z(D), z(D), z(D), z(D), z(D), z(D)
+        dx2 = ops.layernorm_bwd(x2, dx3, gf, dnfw, dnfb, 1e-5)
+        dy2 = ops.layernorm_bwd(y2, dx2, g2, dn2w, dn2b, eps)
+        # FFN
+        dff = ops.dropout_f32(dy2, pd, seed + 3) if pd > 0 else dy2
+        dl2w = ops.sgemm(dff, hm, transa=True)
+        dl2b = ops.colsum(dff)
+        dhm = ops.sgemm(dff, W2)
+        if pd > 0:
+            ops.dropout_f32(dhm, pd, seed + 2, out=dhm)
+        ops.gelu_bwd_(z1, dhm)                                                              # dhm is now dz1
+        dl1w = ops.sgemm(dhm, x1, transa=True)
+        dl1b = ops.colsum(dhm)
+        dx1 = ops.sgemm(dhm, W1, beta=1.0, out=dy2.clone())                                   # residual + through linear1
+        dy = ops.layernorm_bwd(y, dx1, g1, dn1w, dn1b, eps)
+        # attention block: y = c + dropout1(att Wo^T + bo)
+        dcls = ops.colsum(dy).view(NQ, D)
+        dsa = ops.dropout_f32(dy, pd, seed + 1) if pd > 0 else dy
+        dWo = ops.sgemm(dsa, att, transa=True)
+        dbo = ops.colsum(dsa)
+        datt = ops.sgemm(dsa, Wo)
+        dWin, dbin = z(3 * D, D), z(3 * D)
+        dzbar = torch.empty(B, R, D, device=dev, dtype=torch.float32)
+        for h in range(H):
+            sl = slice(h * hd, (h + 1) * hd)
+            ops.sgemm(datt[:, sl], zbar[:, h, :], transa=True, out=dWin[2 * D + h * hd:2 * D + (h + 1) * hd])
+            ops.colsum(datt[:, sl], out=dbin[2 * D + h * hd:2 * D + (h + 1) * hd])
+            ops.sgemm(datt[:, sl], Win[2 * D + h * hd:2 * D + (h + 1) * hd], out=dzbar[:, h, :])
+        hid = ctx.hidden
+        hid2 = hid.reshape(hid.shape[0], B * Tp, D) if (has_mix and hid is not None) else None
+        du, dck, dalpha = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)), drop_p=pd, seed=seed)
+        dU = ops.colsum(du.view(B, R * D)).view(R, D)
+        ops.colsum(dck.view(B, NQ * D), out=dcls.view(NQ * D), accumulate=True)               # CLS token as a key / value
+        # parameter-only chain: u_r = scale Wk_h^T q_h (beta carries no gradient: softmax is shift invariant)
+        dqt = torch.empty(NQ, D, device=dev, dtype=torch.float32)
+        for h in range(H):
+            sl = slice(h * hd, (h + 1) * hd)
+            ops.sgemm(qt[:, sl], dU.view(NQ, H, D)[:, h, :], transa=True, alpha=scale, out=dWin[D + h * hd:D + (h + 1) * hd])
+            ops.sgemm(dU.view(NQ, H, D)[:, h, :], Win[D + h * hd:D + (h + 1) * hd], transb=True, alpha=scale, out=dqt[:, sl])
+        ops.sgemm(dqt, c, transa=True, out=dWin[:D])
+        ops.colsum(dqt, out=dbin[:D])
+        ops.sgemm(dqt, Win[:D], beta=1.0, out=dcls)
+        dmix = None
+        if has_mix and dalpha is not None:
+            dmix = z(mixw.shape[0])
+            ops.mix_softmax_bwd(mixw, dalpha, dmix)
+        return (None, None, None, None, dmix, dcls.view(1, NQ, D), dWin, dbin, dWo, dbo, dn1w, dn1b, dl1w, dl1b, dl2w, dl2b, dn2w, dn2b, dnfw, dnfb,
+                dpw, dpb)
+
+
+class L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.float().contiguous()
+        ctx.save_for_backward(x)
+        return ops.l2norm(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.l2norm_bwd(x, dy.float().contiguous())
+
+
+class MaskedContrastiveFn(torch.autograd.Function):
+    """loss = MaskedContrastiveLoss(feat_a, feat_b, ids); gradients for feat_a and (if given) the log-temperature parameter."""
+
+    @staticmethod
+    def forward(ctx, feat_a, feat_b, ids, log_temp, inv_t, margin, dcl, a2b, b2a):
+        if log_temp is not None:
+            inv_t = float(log_temp.detach().float().exp().item())
+        out, da, dinv = ops.infonce_fwd_bwd(feat_a.detach().float().contiguous(), feat_b.detach().float().contiguous(), ids, inv_t, margin, dcl, a2b, b2a)
+        ctx.save_for_backward(da, dinv)
+        ctx.inv_t, ctx.has_temp = inv_t, log_temp is not None
+        if feat_b.requires_grad:
+            raise NotImplementedError("image-side gradients: the CLIP tower and its projection are frozen in every shipped config")
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        da, dinv = ctx.saved_tensors
+        g = dloss.float()
+        dtemp = (dinv * ctx.inv_t * g).reshape(()) if ctx.has_temp else None       # inv_t = exp(param)
+        return da * g, None, None, dtemp, None, None, None, None, None
+
+
+class GatherFeatsFn(torch.autograd.Function):
+    """all_gather of [B_local, E] rows in rank-major order.  Every rank evaluates the SAME global loss, so the gradient of its local
+    rows is simply its slice of d loss / d gathered (no reduce-scatter); parameter gradients are summed over ranks afterwards."""
+
+    @staticmethod
+    def forward(ctx, x):
+        rank, ws = parallel.world()
+        ctx.rank, ctx.B = rank, x.shape[0]
+        if ws == 1:
+            return x
+        out = torch.empty(ws * x.shape[0], *x.shape[1:], device=x.device, dtype=x.dtype)
+        dist.all_gather_into_tensor(out, x.contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy[ctx.rank * ctx.B:(ctx.rank + 1) * ctx.B]
+
+
+def gather_loss_feats_train(feats: dict) -> dict:
+    """Training-time variant of parallel.gather_loss_feats: differentiable w.r.t. the audio features."""
+    rank, ws = parallel.world()
+    if ws == 1:
+        return feats
+    out = {}
+    for k, v in feats.items():
+        if k == "id":
+            g = torch.empty(ws * v.shape[0], device=v.device, dtype=v.dtype)
+            dist.all_gather_into_tensor(g, v.contiguous())
+            out[k] = g
+        elif torch.is_tensor(v) and v.requires_grad:
+            out[k] = GatherFeatsFn.apply(v)
+        elif torch.is_tensor(v):
+            g = torch.empty(ws * v.shape[0], *v.shape[1:], device=v.device, dtype=v.dtype)
+            dist.all_gather_into_tensor(g, v.contiguous())
+            out[k] = g
+        else:
+            out[k] = v
+    return out
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics on ONE flat fp32 buffer: parameters, gradients and both moments live contiguously, `p.data` / `p.grad`
+    are views, so a step is  [all-reduce of the flat gradient over ranks]  ->  sc_grad_norm (clip coefficient)  ->  sc_adam_step."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm: float = 0.0):
+        params = [p for p in params if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        for p in params:
+            k = p.numel()
+            self.flat_p[off:off + k] = p.data.detach().float().reshape(-1)
+            p.data = self.flat_p[off:off + k].view_as(p)
+            p.grad = self.flat_g[off:off + k].view_as(p)
+            off += k
+        self._params = params
+        self.max_grad_norm = max_grad_norm
+        self.steps = 0
+        self.last_grad_norm: Optional[torch.Tensor] = None
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_g.zero_()
+        off = 0
+        for p in self._params:          # re-attach the views if someone replaced .grad
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_g[off:off + k].data_ptr():
+                p.grad = self.flat_g[off:off + k].view_as(p)
+            off += k
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        rank, ws = parallel.world()
+        if ws > 1:
+            dist.all_reduce(self.flat_g)            # sum over ranks of the per-rank contributions to the single global loss
+        g = self.param_groups[0]
+        nc = ops.grad_norm(self.flat_g, self.max_grad_norm)
+        self.last_grad_norm = nc
+        self.steps += 1
+        ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.steps, g["lr"], g["betas"], g["eps"], g["weight_decay"], clip_coef=nc)

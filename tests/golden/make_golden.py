@@ -116,6 +116,11 @@ def install_stubs():
     _mod("PIL", Image=types.SimpleNamespace())
     sys.modules["PIL.Image"] = sys.modules["PIL"].Image
     sys.path.insert(0, REF)
+    # /root/reference/avssl has no __init__.py (namespace package), so this repo's regular `avssl/` alias package would win the import
+    # regardless of path order: pin `avssl` to the reference tree explicitly.
+    ref_pkg = types.ModuleType("avssl")
+    ref_pkg.__path__ = [os.path.join(REF, "avssl")]
+    sys.modules["avssl"] = ref_pkg
 
 
 def np_state(sd):
@@ -217,6 +222,21 @@ def gen_small_ops(ws_mod, du_mod):
     m = du_mod.get_keypadding_mask(10, lens)
     assert torch.equal(m, speechclip_ref.keypadding_mask(10, lens))
     out["kpm_lens"], out["kpm_mask"] = lens.numpy(), m.numpy()
+    # LR schedules of the reference (avssl/optim/scheduler.py:10-47): learning rate after k scheduler steps
+    import avssl.optim.scheduler as sched_mod
+    steps = [0, 1, 2, 10, 11, 12, 40, 99, 100]
+    for name, kw in (("linear_warmup_decay", dict(warmup=10, max_step=100, final_lr=1e-8)), ("noam", dict(warmup=10))):
+        prm = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([prm], lr=1e-4)
+        sch = sched_mod.get_scheduler(name, opt, **kw)
+        lrs = []
+        for k in range(max(steps) + 1):
+            if k in steps:
+                lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        out[f"sched_{name}_lr"] = np.array(lrs, dtype=np.float64)
+    out["sched_steps"] = np.array(steps)
     save("small_ops.npz", **out)
 
 
@@ -302,6 +322,26 @@ def gen_end_to_end(kwclip_mod, OrderedNamespace, tag, hubert_cfg, clip_cfg, casc
         arrays["keywords"] = others["keywords"].numpy()
     my_loss = sc.compute_loss(o, w_par=1.0 if parallel else 0.0, w_casc=1.0 if cascaded else 0.0)["loss"].item()
     assert abs(my_loss - loss["loss"].item()) < 1e-5
+    if parallel and not cascaded:
+        # gradients of the trainable tail from the reference's own modules (eval mode: dropout off; HuBERT / CLIP frozen):
+        # loss.backward() as Lightning would call it after training_step_end (kwClip.py:147-191)
+        model.zero_grad()
+        losses_g, _, _ = model.forward(batch)
+        model.compute_loss(losses_g)["loss"].backward()
+        n_grad = 0
+        for k, prm in model.named_parameters():
+            if prm.grad is not None and (k.startswith("parallel_branch.") or k == "audio_encoder.weightedsum_layer.weights"):
+                arrays["grad/" + k] = prm.grad.detach().numpy().copy()
+                n_grad += 1
+        assert n_grad == 18, n_grad   # 17 branch tensors + the layer-mix weights
+        # and the oracle's autograd on the same weights must agree with them
+        sc.zero_grad()
+        feat_o = speechclip_ref.weighted_sum([h.detach() for h in sc.forward_audio(batch["wav"], batch["wav_len"])[2]], sc.ws_weights, normalize_hiddenstates)
+        pa = speechclip_ref.l2_normalize(sc.parallel_branch(feat_o, o["audio_len"]))
+        speechclip_ref.masked_contrastive_loss(pa, o["image_feat"], batch["id"], sc.inv_temperature).backward()
+        for k, prm in sc.parallel_branch.named_parameters():
+            assert torch.allclose(prm.grad, torch.from_numpy(arrays["grad/parallel_branch." + k]), atol=2e-5, rtol=1e-3), k
+        assert torch.allclose(sc.ws_weights.grad, torch.from_numpy(arrays["grad/audio_encoder.weightedsum_layer.weights"]), atol=2e-5, rtol=1e-3)
     for k, v in np_state(sd).items():
         if k.startswith("criterion.") or k.startswith("cascaded_branch.clip."):
             continue

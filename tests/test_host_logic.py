@@ -206,3 +206,63 @@ def test_gather_loss_feats_gloo_world2():
         assert torch.equal(out0[k], out1[k])
         assert torch.equal(out0[k], torch.cat([loc0[k], loc1[k]], 0))
     assert out0["id"].dtype == torch.int64 and abs(loss0 - loss1) < 1e-7
+
+
+# --------------------------------------------------------------------------------------------------- training tail, host side
+def test_lr_schedulers_match_reference_values():
+    """get_scheduler reproduces the reference's LambdaLR curves (golden: avssl/optim/scheduler.py run by make_golden.py)."""
+    from speechclip_amd.optim import get_scheduler
+    g = np.load(os.path.join(GOLD, "small_ops.npz"))
+    steps = g["sched_steps"].tolist()
+    for name, kw in (("linear_warmup_decay", dict(warmup=10, max_step=100, final_lr=1e-8)), ("noam", dict(warmup=10))):
+        prm = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([prm], lr=1e-4)
+        sch = get_scheduler(name, opt, **kw)
+        lrs = []
+        for k in range(max(steps) + 1):
+            if k in steps:
+                lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        assert np.allclose(np.array(lrs), g[f"sched_{name}_lr"], rtol=1e-12, atol=0), (name, lrs, g[f"sched_{name}_lr"])
+
+
+def _train_gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.speechclip_ref import masked_contrastive_loss
+    from speechclip_amd.train_tail import gather_loss_feats_train
+    g = torch.Generator().manual_seed(100 + rank)
+    B, E = 5, 16
+    a = torch.nn.functional.normalize(torch.randn(B, E, generator=g), dim=-1).requires_grad_(True)
+    feats = {"id": torch.tensor([7, 7, 3 + rank, 2 ** 40 + rank, -1 - rank]), "image_feat": torch.nn.functional.normalize(torch.randn(B, E, generator=g), dim=-1),
+             "parallel_audio_feat": a}
+    out = gather_loss_feats_train(feats)
+    loss = masked_contrastive_loss(out["parallel_audio_feat"], out["image_feat"], out["id"])
+    loss.backward()
+    q.put((rank, a.detach().clone(), feats["image_feat"].clone(), feats["id"].clone(), a.grad.clone(), loss.item()))
+    dist.destroy_process_group()
+
+
+def test_training_gather_backward_keeps_local_rows_gloo_world2():
+    """Every rank evaluates the same global loss on the all-gathered batch; the gradient of its local audio features must be its slice
+    of the single-process gradient (the reference's DP gather on device 0, kwClip.py:147-191)."""
+    import torch.multiprocessing as mp
+    from oracle.speechclip_ref import masked_contrastive_loss
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    A = torch.cat([r[1] for r in res]).requires_grad_(True)
+    Bm, ids = torch.cat([r[2] for r in res]), torch.cat([r[3] for r in res])
+    loss = masked_contrastive_loss(A, Bm, ids)
+    loss.backward()
+    assert abs(res[0][5] - loss.item()) < 1e-6 and abs(res[1][5] - loss.item()) < 1e-6
+    assert torch.allclose(torch.cat([r[4] for r in res]), A.grad, atol=1e-6)
