@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--audio-len", type=int, default=160000)
     ap.add_argument("--cpu-pairs", type=int, default=32, help="pairs for the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--train", action="store_true", help="time the TRAINING step of the trainable tail instead (forward in train mode + loss.backward() "
+                    "+ grad all-reduce + clip + Adam + LR schedule); not the headline metric, reported with config.mode = 'train'")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +129,7 @@ def main():
 
     from speechclip_amd import ops, parallel
     model = build_model()
-    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_pairs > 0 and world == 1) else None
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_pairs > 0 and world == 1 and not args.train) else None
     model = model.to(dev)
     B, L = args.batch, args.audio_len
     g = torch.Generator(device="cpu").manual_seed(7122 + rank)
@@ -135,10 +137,22 @@ def main():
     batch = {"wav": wav, "wav_len": torch.full((B,), L, dtype=torch.long), "image": torch.randn(B, 3, 224, 224, generator=g).to(dev),
              "id": (torch.arange(B) + rank * B).to(dev)}
 
-    def step():
-        with torch.no_grad():
-            lf, _, _ = model(batch)
-            return model.compute_loss(parallel.gather_loss_feats(lf))["loss"]
+    if args.train:
+        model.train()
+        (opt,), (sch,) = model.configure_optimizers()
+
+        def step():
+            opt.zero_grad()
+            loss = model.training_step_end(model.training_step(batch, 0))["loss"]
+            loss.backward()
+            opt.step()
+            sch["scheduler"].step()
+            return loss.detach()
+    else:
+        def step():
+            with torch.no_grad():
+                lf, _, _ = model(batch)
+                return model.compute_loss(parallel.gather_loss_feats(lf))["loss"]
 
     def fence():
         if world > 1:
@@ -178,7 +192,7 @@ def main():
                "config": {"workload": "Parallel SpeechCLIP base (HuBERT-base + ViT-B/32) forward + InfoNCE, 10 s/16 kHz audio + 224^2 images",
                           "pairs_per_gpu": B, "global_batch": world * B, "audio_samples": L, "frames": conv_lens(L)[-1],
                           "parallelism": f"dp{world}" if world > 1 else "single", "weights": "random-init (no network)",
-                          "algorithmic_gflop_per_pair": round(total_gf, 2)},
+                          "algorithmic_gflop_per_pair": round(total_gf, 2), "mode": "train (tail: branch + layer-mix weights)" if args.train else "forward + loss"},
                "e2e_tflops_per_gpu": round(total_gf * 1e9 * pairs_per_s / world / 1e12, 1),
                "e2e_frac_of_bf16_peak": round(total_gf * 1e9 * pairs_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
                "loss": round(float(loss), 5), "roofline": roof, "cpu_baseline": None}

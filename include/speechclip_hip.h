@@ -131,6 +131,10 @@ int sc_posconv_pack(const void* x, const int32_t* valid, void* xg, int B, int Tp
 int sc_posconv_finish(const void* x, const int32_t* valid, const void* conv, const float* bias, const float* gamma, const float* beta,
                       void* out, int B, int Tp, int D, int G, int out_f32, float eps, void* stream);
 
+/* sc_crop_pad: out[b,j] = j < lens[b] ? wav[b, starts[b]+j] : 0 -- train-mode random crop (audio_transforms.py:5-23; offsets drawn on the
+ * host exactly as the reference draws them) + zero right-padding (speech_encoder_plus.py:510-518) for the whole batch in one launch. */
+int sc_crop_pad(const float* wav, int64_t ld, const int32_t* starts, const int32_t* lens, float* out, int B, int Lout, void* stream);
+
 /* ---- CLIP ViT stem -- openai VisionTransformer.forward up to ln_pre (clip_official.py:209) ----- */
 int sc_vit_patchify(const float* img, void* cols, int B, int R, int p, int Kpad, void* stream);
 int sc_vit_embed(const void* patch, const float* cls, const float* pos, const float* gamma, const float* beta, float* out, int B,
@@ -166,19 +170,23 @@ int sc_gather_rows(const float* src, const int64_t* idx, float* out, int R, int 
  *   transb=1: B stored [N,K] (nn.Linear weight).  Every dense product of the tail has only B (pairs per GPU) rows on one side. */
 int sc_sgemm(int transa, int transb, int M, int N, int K, float alpha, const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
              float* C, int64_t ldc, const float* bias, void* stream);
+int sc_sgemm_batched(int transa, int transb, int M, int N, int K, float alpha, const float* A, int64_t lda, int64_t strideA, const float* B,
+                     int64_t ldb, int64_t strideB, float beta, float* C, int64_t ldc, int64_t strideC, const float* bias, int64_t strideBias,
+                     int batch, void* stream);   /* operand i of the batch at X + i*strideX: the per-head products in one launch */
 /* sc_cls_pool_train_fwd: sc_cls_pool_fwd with fp32 CLS tokens / outputs, the softmax probabilities kept (p_out f32 [B,R,NQ+T]) and
  *   attention-probability dropout (nn.MultiheadAttention dropout=0.1, TransformerModels.py:62-71) from a counter-based hash RNG.
  * sc_cls_pool_bwd: two streaming passes over the frames.  In: p (from the forward), dzbar f32 [B,R,D] (gradient of the pooled sums), u f32 [R,D];
  *   hidden bf16 (f32 when hidden_f32: the pre-LN encoder's residual stream) [n_layers][B*T, D] (layer_stride elements apart) = the states the frames were mixed from (NULL / n_layers = 0: skip dalpha).
- *   Out: du f32 [B,R,D], dcls_key f32 [B,NQ,D] (gradient reaching the CLS tokens as KEYS), dalpha f32 [B,n_layers] (per-utterance
- *   gradient of the softmaxed mix weights, weighted_sum.py:38-43).  ds_ws / pp_ws: f32 [B,R,NQ+T] workspaces. */
+ *   Out (PARTIAL rows, B*nsplit of them -- the keys of an utterance are split over nsplit blocks; every consumer sums over rows):
+ *   du f32 [B*nsplit,R,D], dcls_key f32 [B*nsplit,NQ,D] (gradient reaching the CLS tokens as KEYS), dalpha f32 [B*nsplit,n_layers]
+ *   (gradient of the softmaxed mix weights, weighted_sum.py:38-43).  ds_ws / pp_ws: f32 [B,R,NQ+T] workspaces. */
 int sc_cls_pool_train_fwd(const void* x, int64_t ld_x, const float* cls_tok, const float* scores, const float* cls_scores,
                           const int32_t* lens, float* p_out, float* xbar, int B, int T, int NQ, int R, int D, float drop_p, uint32_t seed,
                           void* stream);
 int sc_cls_pool_bwd(const void* x, int64_t ld_x, const float* cls_tok, const void* hidden, int hidden_f32, int64_t layer_stride, int n_layers,
                     int normalize,
                     const float* p, const float* dzbar, const float* u, const int32_t* lens, float* ds_ws, float* pp_ws, float* du,
-                    float* dcls_key, float* dalpha, int B, int T, int NQ, int R, int D, float drop_p, uint32_t seed, void* stream);
+                    float* dcls_key, float* dalpha, int B, int T, int NQ, int R, int D, int nsplit, float drop_p, uint32_t seed, void* stream);
 /* Row ops, fp32.  sc_layernorm_bwd: dx (= or += when accumulate_dx) and dgamma/dbeta += (NULL: skipped); stats_ws f32 [rows,2].
  * sc_gelu_f32: backward=0: y = gelu(z) (exact erf);  backward=1: y_or_dh *= gelu'(z).   sc_colsum: out[c] (=|+=) sum_r x[r,c].
  * sc_l2norm_bwd: y = x/|x| (kwClip.py:1436).  sc_dropout_f32: y = x * keep/(1-p) with keep = hash(seed, index) (in place allowed).

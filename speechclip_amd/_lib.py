@@ -54,6 +54,7 @@ def _declare(L):
         "sc_conv0_fwd": ([P, L64, L64, P, P, P, P, I, I, I, I, I, P], c_int),
         "sc_posconv_pack": ([P, P, P, I, I, I, I, I, P], c_int),
         "sc_posconv_finish": ([P, P, P, P, P, P, P, I, I, I, I, I, F, P], c_int),
+        "sc_crop_pad": ([P, L64, P, P, P, I, I, P], c_int),
         "sc_vit_patchify": ([P, P, I, I, I, I, P], c_int),
         "sc_vit_embed": ([P, P, P, P, P, P, I, I, I, F, P], c_int),
         "sc_infonce_workspace_bytes": ([I], c_int64),
@@ -65,8 +66,9 @@ def _declare(L):
         "sc_vq_fwd": ([P, P, P, P, P, I, I, I, P, I, P], c_int),
         "sc_gather_rows": ([P, P, P, I, I, P], c_int),
         "sc_sgemm": ([I, I, I, I, I, F, P, L64, P, L64, F, P, L64, P, P], c_int),
+        "sc_sgemm_batched": ([I, I, I, I, I, F, P, L64, L64, P, L64, L64, F, P, L64, L64, P, L64, I, P], c_int),
         "sc_cls_pool_train_fwd": ([P, L64, P, P, P, P, P, P, I, I, I, I, I, F, U32, P], c_int),
-        "sc_cls_pool_bwd": ([P, L64, P, P, I, L64, I, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U32, P], c_int),
+        "sc_cls_pool_bwd": ([P, L64, P, P, I, L64, I, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, U32, P], c_int),
         "sc_layernorm_bwd": ([P, P, P, P, P, P, P, I, I, F, I, P], c_int),
         "sc_gelu_f32": ([P, P, L64, I, P], c_int),
         "sc_colsum": ([P, L64, I, I, P, I, P], c_int),

@@ -336,3 +336,23 @@ extern "C" int sc_vit_embed(const void* patch, const float* cls, const float* po
     SC_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ K1: crop + right-pad a batch of waves
+// out[b, j] = j < lens[b] ? wav[b, starts[b] + j] : 0   (train-mode random crop to max_audio_len, audio_transforms.py:5-23, then the
+// zero right-padding of preprocess_input, speech_encoder_plus.py:510-518) -- one launch instead of one slice copy per utterance.
+namespace {
+__global__ void crop_pad_kernel(const float* __restrict__ wav, int64_t ld, const int32_t* __restrict__ starts, const int32_t* __restrict__ lens,
+                                float* __restrict__ out, int Lout) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Lout) return;
+    out[(int64_t)b * Lout + j] = j < lens[b] ? wav[(int64_t)b * ld + starts[b] + j] : 0.f;
+}
+}  // namespace
+
+extern "C" int sc_crop_pad(const float* wav, int64_t ld, const int32_t* starts, const int32_t* lens, float* out, int B, int Lout, void* stream) {
+    SC_CHECK_ARG(B > 0 && Lout > 0 && wav && starts && lens && out, "sc_crop_pad: bad arguments");
+    hipLaunchKernelGGL(crop_pad_kernel, dim3((Lout + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, wav, ld, starts, lens, out, Lout);
+    SC_CHECK_LAUNCH();
+    return 0;
+}

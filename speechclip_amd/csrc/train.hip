@@ -178,37 +178,50 @@ __global__ __launch_bounds__(256) void cls_pool_bwd_scores_kernel(const bf16_t* 
 // ------------------------------------------------------------------------------------------------ CLS pooling backward, pass B
 // One streaming pass over the frames of utterance b and the n hidden layers they were mixed from:
 //   dz_t = sum_r p'_rt dzbar_r + ds_rt u_r   (kept in registers, never stored)
-//   du_r[b]      = sum_t ds_rt z_t                      -> du [B, R, D]        (summed over b by the caller)
-//   dcls_key[b]  = dz of the NQ CLS keys                 -> dcls_key [B, NQ, D]
-//   dalpha_n[b]  = sum_t dz_t . H_n[b,t]  (H_n layer-normalised without affine when `normalize`)   -> dalpha [B, n]
-template <int DCH>
-__global__ __launch_bounds__(256) void cls_pool_bwd_frames_kernel(const bf16_t* __restrict__ x, int64_t ld_x, const float* __restrict__ cls_tok,
+//   du_r        = sum_t ds_rt z_t                       -> du [B*S, R, D]
+//   dcls_key    = dz of the NQ CLS keys                  -> dcls_key [B*S, NQ, D]
+//   dalpha_n    = sum_t dz_t . H_n[b,t]  (H_n layer-normalised without affine when `normalize`)   -> dalpha [B*S, n]
+// Grid (B, S): the keys of an utterance are split over S blocks, each writing its own partial row -- every consumer sums these
+// outputs over b anyway (colsum / sc_mix_softmax_bwd), so the split costs nothing and gives the memory system 4 x S waves per
+// utterance instead of 4.  Per-wave partials meet in ONE [8][D] LDS buffer through ds_add (24 KiB: several blocks per CU).
+template <int DCH, int NL>   // NL: compile-time bound of n_layers (16 or 32): per-layer partial sums stay in registers, loads of several layers overlap
+__global__ __launch_bounds__(512) void cls_pool_bwd_frames_kernel(const bf16_t* __restrict__ x, int64_t ld_x, const float* __restrict__ cls_tok,
                                                                   const void* __restrict__ hidden, int hidden_f32, int64_t layer_stride, int n_layers, int normalize, float eps,
                                                                   const float* __restrict__ pp, const float* __restrict__ ds, const float* __restrict__ dzbar,
                                                                   const float* __restrict__ u, const int32_t* __restrict__ lens,
                                                                   float* __restrict__ du, float* __restrict__ dcls_key, float* __restrict__ dalpha,
                                                                   int T, int NQ, int R, int D) {
+    // dzbar_r and u_r of the block's utterance live in LDS (they are the same for all 8 waves, and 16 x 12 floats per lane in registers
+    // would leave one wave per SIMD -- no memory-level parallelism); only the du accumulators stay in registers.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = (float*)smem;                // [4 waves][8][D] then [4][32] for dalpha
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* sg = (float*)smem;                 // [8][D] dzbar_r
+    float* su = sg + 8 * D;                   // [8][D] u_r
+    float* red = su + 8 * D;                  // [8][D] du accumulators (ds_add from the 8 waves)
+    float* sda = red + 8 * D;                 // [32]   dalpha
+    const int NW = 8;
+    const int b = blockIdx.x, S = gridDim.y, sp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t orow = (int64_t)b * S + sp;  // output row of this block
     int len = lens ? lens[b] : T;
     len = len < 0 ? 0 : (len > T ? T : len);
     const int nkeys = NQ + len, skeys = NQ + T;
-    float g[8][DCH][4], uu[8][DCH][4], dua[8][DCH][4];
+    for (int i = tid; i < 8 * D; i += 512) {
+        const int r = i / D, d = i - r * D;
+        sg[i] = r < R ? dzbar[((int64_t)b * R + r) * D + d] : 0.f;
+        su[i] = r < R ? u[(int64_t)r * D + d] : 0.f;
+        red[i] = 0.f;
+    }
+    if (tid < 32) sda[tid] = 0.f;
+    for (int i = tid; i < NQ * D; i += 512) dcls_key[orow * NQ * D + i] = 0.f;     // rows of CLS keys this block does not own stay zero
+    float dua[8][DCH][4];
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int c = 0; c < DCH; ++c) {
-            const int e = c * 256 + lane * 4;
-            f32x4_t t = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
-            if (r < R && e < D) { t = *(const f32x4_t*)(dzbar + ((int64_t)b * R + r) * D + e); t2 = *(const f32x4_t*)(u + (int64_t)r * D + e); }
+        for (int c = 0; c < DCH; ++c) dua[r][c][0] = dua[r][c][1] = dua[r][c][2] = dua[r][c][3] = 0.f;
+    float da[NL];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { g[r][c][k] = t[k]; uu[r][c][k] = t2[k]; dua[r][c][k] = 0.f; }
-        }
-    float da[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) da[i] = 0.f;
-    for (int kk = wave; kk < nkeys; kk += 4) {
+    for (int n = 0; n < NL; ++n) da[n] = 0.f;
+    __syncthreads();
+    for (int kk = sp * NW + wave; kk < nkeys; kk += NW * S) {
         float zv[DCH][4], dz[DCH][4];
 #pragma unroll
         for (int c = 0; c < DCH; ++c) {
@@ -224,21 +237,28 @@ __global__ __launch_bounds__(256) void cls_pool_bwd_frames_kernel(const bf16_t* 
             if (r >= R) break;
             const float ppv = pp[((int64_t)b * R + r) * skeys + kk], dsv = ds[((int64_t)b * R + r) * skeys + kk];
 #pragma unroll
-            for (int c = 0; c < DCH; ++c)
+            for (int c = 0; c < DCH; ++c) {
+                const int e = c * 256 + lane * 4;
+                if (e < D) {
+                    const f32x4_t g4 = *(const f32x4_t*)(sg + r * D + e), u4 = *(const f32x4_t*)(su + r * D + e);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    dz[c][k] = fmaf(ppv, g[r][c][k], fmaf(dsv, uu[r][c][k], dz[c][k]));
-                    dua[r][c][k] = fmaf(dsv, zv[c][k], dua[r][c][k]);
+                    for (int k = 0; k < 4; ++k) {
+                        dz[c][k] = fmaf(ppv, g4[k], fmaf(dsv, u4[k], dz[c][k]));
+                        dua[r][c][k] = fmaf(dsv, zv[c][k], dua[r][c][k]);
+                    }
                 }
+            }
         }
         if (kk < NQ) {
 #pragma unroll
             for (int c = 0; c < DCH; ++c)
                 if (c * 256 + lane * 4 < D)
-                    *(f32x4_t*)(dcls_key + ((int64_t)b * NQ + kk) * D + c * 256 + lane * 4) = (f32x4_t){dz[c][0], dz[c][1], dz[c][2], dz[c][3]};
+                    *(f32x4_t*)(dcls_key + (orow * NQ + kk) * D + c * 256 + lane * 4) = (f32x4_t){dz[c][0], dz[c][1], dz[c][2], dz[c][3]};
         } else if (hidden) {
             const int64_t row = (int64_t)b * T + (kk - NQ);
-            for (int n = 0; n < n_layers; ++n) {
+#pragma unroll
+            for (int n = 0; n < NL; ++n) {
+                if (n >= n_layers) break;
                 float hv[DCH][4];
                 float s = 0.f;
 #pragma unroll
@@ -278,39 +298,31 @@ __global__ __launch_bounds__(256) void cls_pool_bwd_frames_kernel(const bf16_t* 
 #pragma unroll
                         for (int k = 0; k < 4; ++k) s = fmaf(dz[c][k], hv[c][k], s);
                 }
-                // n_layers <= 32: static register index via full unroll of a select chain would be wasteful; accumulate through LDS-free trick:
-#pragma unroll
-                for (int i = 0; i < 32; ++i) da[i] += (i == n) ? s : 0.f;
+                da[n] += s;
             }
         }
     }
-    // reduce du over the 4 waves
+    if (hidden) {
+#pragma unroll
+        for (int n = 0; n < NL; ++n) {
+            if (n >= n_layers) break;
+            const float t = wave_sum(da[n]);
+            if (lane == 0) atomicAdd(&sda[n], t);
+        }
+    }
+    // the 8 waves add their du partials into the shared [8][D] buffer
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         if (r >= R) break;
 #pragma unroll
         for (int c = 0; c < DCH; ++c)
             if (c * 256 + lane * 4 < D)
-                *(f32x4_t*)(red + ((wave * 8 + r) * D) + c * 256 + lane * 4) = (f32x4_t){dua[r][c][0], dua[r][c][1], dua[r][c][2], dua[r][c][3]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(&red[r * D + c * 256 + lane * 4 + k], dua[r][c][k]);
     }
     __syncthreads();
-    for (int i = tid; i < R * D; i += 256) {
-        const int r = i / D, d = i - r * D;
-        float s0 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) s0 += red[(w * 8 + r) * D + d];
-        du[((int64_t)b * R + r) * D + d] = s0;
-    }
-    __syncthreads();
-    if (hidden) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const float s = wave_sum(da[i]);
-            if (lane == 0) red[wave * 32 + i] = s;
-        }
-        __syncthreads();
-        if (tid < n_layers) dalpha[(int64_t)b * n_layers + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
-    }
+    for (int i = tid; i < R * D; i += 512) du[orow * R * D + i] = red[i];
+    if (hidden && tid < n_layers) dalpha[orow * n_layers + tid] = sda[tid];
 }
 
 // ------------------------------------------------------------------------------------------------ small row kernels
@@ -390,13 +402,23 @@ __global__ void gelu_fwd_kernel(const float* __restrict__ z, float* __restrict__
     const float v = z[i];
     y[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
 }
-// out[c] (+)= sum_r x[r, c]
-__global__ void colsum_kernel(const float* __restrict__ x, int64_t ld, int rows, int cols, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// out[c] (+)= sum_r x[r, c].  Grid (column blocks of 64, row chunks): tall inputs are reduced by several blocks per column block through
+// atomics on a pre-zeroed / pre-existing `out`.
+__global__ void colsum_kernel(const float* __restrict__ x, int64_t ld, int rows, int cols, float* __restrict__ out, int accumulate, int rows_per_block) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;                       // 4 row-interleaved partial sums per column
+    __shared__ float part[4][64];
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[(int64_t)r * ld + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < cols)
+        for (int r = r0 + sub; r < r1; r += 4) s += x[(int64_t)r * ld + c];
+    part[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && c < cols) {
+        s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (gridDim.y > 1) atomicAdd(out + c, s);
+        else out[c] = accumulate ? out[c] + s : s;
+    }
 }
 // y = x / |x|:  dx = (dy - y (y . dy)) / |x|
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int rows, int D) {
@@ -597,19 +619,30 @@ extern "C" int sc_cls_pool_train_fwd(const void* x, int64_t ld_x, const float* c
 
 extern "C" int sc_cls_pool_bwd(const void* x, int64_t ld_x, const float* cls_tok, const void* hidden, int hidden_f32, int64_t layer_stride,
                                int n_layers, int normalize, const float* p, const float* dzbar, const float* u, const int32_t* lens, float* ds_ws,
-                               float* pp_ws, float* du, float* dcls_key, float* dalpha, int B, int T, int NQ, int R, int D, float drop_p,
-                               uint32_t seed, void* stream) {
+                               float* pp_ws, float* du, float* dcls_key, float* dalpha, int B, int T, int NQ, int R, int D, int nsplit,
+                               float drop_p, uint32_t seed, void* stream) {
     if (pool_args_ok(T, NQ, R, D, ld_x, "sc_cls_pool_bwd")) return -1;
     SC_CHECK_ARG(n_layers >= 0 && n_layers <= 32, "sc_cls_pool_bwd: n_layers=%d (max 32)", n_layers);
+    SC_CHECK_ARG(nsplit >= 1 && nsplit <= 64, "sc_cls_pool_bwd: nsplit=%d (1..64)", nsplit);
     if (B <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int lds_a = 8 * (NQ + T) * 4;
     POOL_DISPATCH(cls_pool_bwd_scores_kernel, lds_a, (const bf16_t*)x, ld_x, cls_tok, p, dzbar, lens, ds_ws, pp_ws, T, NQ, R, D, seed,
                   drop_thresh(drop_p), 1.0f / (1.0f - drop_p));
     SC_CHECK_LAUNCH();
-    const int lds_b = 4 * 8 * D * 4;
-    POOL_DISPATCH(cls_pool_bwd_frames_kernel, lds_b, (const bf16_t*)x, ld_x, cls_tok, (const void*)(n_layers ? hidden : nullptr), hidden_f32, layer_stride,
-                  n_layers, normalize, 1e-5f, pp_ws, ds_ws, dzbar, u, lens, du, dcls_key, dalpha, T, NQ, R, D);
+    const int lds_b = (3 * 8 * D + 32) * 4;
+    const dim3 grid_b(B, nsplit);
+#define FRAMES_LAUNCH(DCH_) do { if (n_layers <= 16) FRAMES_LAUNCH2(DCH_, 16); else FRAMES_LAUNCH2(DCH_, 32); } while (0)
+#define FRAMES_LAUNCH2(DCH_, NL_) do {                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)cls_pool_bwd_frames_kernel<DCH_, NL_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);                   \
+    hipLaunchKernelGGL((cls_pool_bwd_frames_kernel<DCH_, NL_>), grid_b, dim3(512), lds_b, s, (const bf16_t*)x, ld_x, cls_tok, (const void*)(n_layers ? hidden : nullptr), \
+                       hidden_f32, layer_stride, n_layers, normalize, 1e-5f, pp_ws, ds_ws, dzbar, u, lens, du, dcls_key, dalpha, T, NQ, R, D); } while (0)
+    if (D <= 256) FRAMES_LAUNCH(1);
+    else if (D <= 512) FRAMES_LAUNCH(2);
+    else if (D <= 768) FRAMES_LAUNCH(3);
+    else FRAMES_LAUNCH(4);
+#undef FRAMES_LAUNCH
+#undef FRAMES_LAUNCH2
     SC_CHECK_LAUNCH();
     return 0;
 }
@@ -639,7 +672,14 @@ extern "C" int sc_gelu_f32(const float* z, float* y_or_dh, int64_t n, int backwa
 
 extern "C" int sc_colsum(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, void* stream) {
     if (rows <= 0 || cols <= 0) return 0;
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, ld, rows, cols, out, accumulate);
+    hipStream_t s = (hipStream_t)stream;
+    const int cb = (cols + 63) / 64;
+    int chunks = 1;
+    if (rows >= 256 && cb < 512) chunks = min((rows + 63) / 64, max(1, 1024 / cb));
+    const int rpb = (rows + chunks - 1) / chunks;
+    chunks = (rows + rpb - 1) / rpb;
+    if (chunks > 1 && !accumulate) { if (hipMemsetAsync(out, 0, (size_t)cols * 4, s) != hipSuccess) { sc_set_error("sc_colsum: memset failed"); return -2; } }
+    hipLaunchKernelGGL(colsum_kernel, dim3(cb, chunks), dim3(256), 0, s, x, ld, rows, cols, out, accumulate, rpb);
     SC_CHECK_LAUNCH();
     return 0;
 }

@@ -120,6 +120,18 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 keep = torch.arange(lmax, device=dev)[None, :] < torch.tensor(lens, device=dev)[:, None]
                 padded = padded * keep
             padded = padded.contiguous()
+        elif isinstance(wav, torch.Tensor) and wav.dim() == 2 and len(wav_len) > 0 and self.training and wav.is_cuda:
+            # train mode on a padded device batch: the reference crops every utterance longer than max_audio_len at a random offset
+            # (np.random.randint, one draw per cropped utterance, in batch order -- reproduced here) and re-pads; one kernel for the batch
+            full = [min(int(l), wav.shape[1]) for l in (wav_len.tolist() if torch.is_tensor(wav_len) else wav_len)]
+            starts, lens = [], []
+            for n in full:
+                if self.max_audio_len < 0 or n <= self.max_audio_len:
+                    starts.append(0); lens.append(n)
+                else:
+                    starts.append(int(np.random.randint(n - self.max_audio_len))); lens.append(self.max_audio_len)
+            from .. import ops
+            padded = ops.crop_pad(wav.to(dev, torch.float32), starts, lens, max(lens))
         else:
             wavs = self._to_list(wav, wav_len)
             if self.training:

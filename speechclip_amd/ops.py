@@ -182,6 +182,18 @@ def posconv(x, valid_i32, wg, bias, gamma, beta, B, Tp, D, G, Kw, out=None, out_
     return out
 
 
+def crop_pad(wav, starts, lens, Lout):
+    """wav f32 [B, L] (device); starts/lens host int lists -> f32 [B, Lout]: out[b, j] = wav[b, starts[b] + j] for j < lens[b], else 0."""
+    _need_cuda(wav)
+    assert wav.dtype == torch.float32 and wav.dim() == 2 and wav.stride(1) == 1
+    B = wav.shape[0]
+    assert all(0 <= s and s + l <= wav.shape[1] and l <= Lout for s, l in zip(starts, lens))
+    meta = torch.tensor([list(starts), list(lens)], dtype=torch.int32).to(wav.device)
+    out = torch.empty(B, Lout, device=wav.device, dtype=torch.float32)
+    check(lib().sc_crop_pad(ptr(wav), wav.stride(0), ptr(meta[0]), ptr(meta[1]), ptr(out), B, Lout, stream()), "sc_crop_pad")
+    return out
+
+
 def vit_patchify(img, p, Kpad):
     _need_cuda(img)
     B, C, R, _ = img.shape
@@ -286,6 +298,17 @@ def sgemm(a, b, transa=False, transb=False, alpha=1.0, beta=0.0, out=None, bias=
     return out
 
 
+def sgemm_batched(M, N, K, a, lda, stride_a, b, ldb, stride_b, out, ldc, stride_c, batch, transa=False, transb=False, alpha=1.0, beta=0.0,
+                  bias=None, stride_bias=0):
+    """`batch` products out_i[M,N] = alpha op(a_i) op(b_i) + beta out_i (+ bias_i) with operand i at base + i*stride (elements): the
+    per-head products of the attention block in one launch.  a / b / out / bias are tensors (or views) whose data_ptr is operand 0."""
+    _need_cuda(a, b, out)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and out.dtype == torch.float32
+    check(lib().sc_sgemm_batched(int(transa), int(transb), M, N, K, alpha, ptr(a), lda, stride_a, ptr(b), ldb, stride_b, beta, ptr(out), ldc, stride_c,
+                                 ptr(bias), stride_bias, batch, stream()), "sc_sgemm_batched")
+    return out
+
+
 def cls_pool_train_fwd(x_rows, cls_tok, scores, cls_scores, lens_i32, B, T, NQ, R, D, drop_p=0.0, seed=0):
     """-> (p f32 [B,R,NQ+T], xbar f32 [B,R,D]).  x_rows bf16 [B*T, D]; cls_tok f32 [NQ,D]; scores f32 [B*T,R]; cls_scores f32 [NQ,R]."""
     _need_cuda(x_rows)
@@ -298,22 +321,25 @@ def cls_pool_train_fwd(x_rows, cls_tok, scores, cls_scores, lens_i32, B, T, NQ, 
     return p, xbar
 
 
-def cls_pool_bwd(x_rows, cls_tok, hidden, p, dzbar, u, lens_i32, B, T, NQ, R, D, normalize=False, drop_p=0.0, seed=0):
-    """-> (du f32 [B,R,D], dcls_key f32 [B,NQ,D], dalpha f32 [B,n] or None).  hidden: bf16 / f32 [n, B*T, D] contiguous or None."""
+def cls_pool_bwd(x_rows, cls_tok, hidden, p, dzbar, u, lens_i32, B, T, NQ, R, D, normalize=False, drop_p=0.0, seed=0, nsplit=None):
+    """-> (du f32 [B*S,R,D], dcls_key f32 [B*S,NQ,D], dalpha f32 [B*S,n] or None): PARTIAL rows (S = nsplit key-splits per utterance); the
+    caller sums over rows.  hidden: bf16 / f32 [n, B*T, D] contiguous or None."""
     _need_cuda(x_rows)
     _f32c(cls_tok, p, dzbar, u)
     dev = x_rows.device
     n = 0 if hidden is None else hidden.shape[0]
     if hidden is not None:
         assert hidden.dtype in (bf16, torch.float32) and hidden.is_contiguous() and hidden.shape[1] == B * T and hidden.shape[2] == D
+    if nsplit is None:
+        nsplit = max(1, min(16, 512 // max(B, 1)))           # ~2 blocks of 8 waves per CU
     ds = torch.empty(B, R, NQ + T, device=dev, dtype=torch.float32)
     pp = torch.empty_like(ds)
-    du = torch.empty(B, R, D, device=dev, dtype=torch.float32)
-    dck = torch.empty(B, NQ, D, device=dev, dtype=torch.float32)
-    dalpha = torch.empty(B, n, device=dev, dtype=torch.float32) if n else None
-    check(lib().sc_cls_pool_bwd(ptr(x_rows), x_rows.stride(0), ptr(cls_tok), ptr(hidden), int(n > 0 and hidden.dtype == torch.float32), hidden.stride(0) if n else 0, n, int(normalize), ptr(p),
-                                ptr(dzbar), ptr(u), ptr(lens_i32), ptr(ds), ptr(pp), ptr(du), ptr(dck), ptr(dalpha), B, T, NQ, R, D, float(drop_p),
-                                int(seed) & 0xFFFFFFFF, stream()), "sc_cls_pool_bwd")
+    du = torch.empty(B * nsplit, R, D, device=dev, dtype=torch.float32)
+    dck = torch.empty(B * nsplit, NQ, D, device=dev, dtype=torch.float32)
+    dalpha = torch.empty(B * nsplit, n, device=dev, dtype=torch.float32) if n else None
+    check(lib().sc_cls_pool_bwd(ptr(x_rows), x_rows.stride(0), ptr(cls_tok), ptr(hidden), int(n > 0 and hidden.dtype == torch.float32), hidden.stride(0) if n else 0, n,
+                                int(normalize), ptr(p), ptr(dzbar), ptr(u), ptr(lens_i32), ptr(ds), ptr(pp), ptr(du), ptr(dck), ptr(dalpha), B, T, NQ, R, D,
+                                int(nsplit), float(drop_p), int(seed) & 0xFFFFFFFF, stream()), "sc_cls_pool_bwd")
     return du, dck, dalpha
 
 

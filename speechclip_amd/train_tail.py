@@ -54,20 +54,17 @@ class ParallelBranchTrainFn(torch.autograd.Function):
         Win, bin_ = _c(in_w), _c(in_b)
         # ---- parameter-only part: queries of the CLS token, u_r = scale Wk_h^T q_h, beta_r = scale q_h . bk_h
         qt = ops.sgemm(c, Win[:D], transb=True, bias=bin_[:D])                              # [NQ, D]
-        U = torch.empty(R, D, device=dev, dtype=torch.float32)
+        U = torch.empty(R, D, device=dev, dtype=torch.float32)                               # rows r = q*H + h
         beta = torch.empty(R, device=dev, dtype=torch.float32)
-        for h in range(H):
-            sl = slice(h * hd, (h + 1) * hd)
-            ops.sgemm(qt[:, sl], Win[D + h * hd:D + (h + 1) * hd], alpha=scale, out=U.view(NQ, H, D)[:, h, :])
-            ops.sgemm(qt[:, sl], bin_[D + h * hd:D + (h + 1) * hd].view(hd, 1), alpha=scale, out=beta.view(NQ, H)[:, h:h + 1])
+        Wk, bk, Wv, bv = Win[D:2 * D], bin_[D:2 * D], Win[2 * D:], bin_[2 * D:]
+        ops.sgemm_batched(NQ, D, hd, qt, D, hd, Wk, D, hd * D, U, H * D, D, H, alpha=scale)                      # U[q,h,:] = scale q_h^T Wk_h
+        ops.sgemm_batched(NQ, 1, hd, qt, D, hd, bk, 1, hd, beta, H, 1, H, alpha=scale)                             # beta[q,h] = scale q_h . bk_h
         # ---- frame scores on the MFMA GEMM (bf16 frames x bf16 u, fp32 accumulate/out), pooling in fp32
         scores = ops.gemm(rows, U.to(BF).contiguous(), beta, out_f32=True)                    # [B*Tp, R]
         cls_scores = ops.sgemm(c, U, transb=True, bias=beta)                                  # [NQ, R]
         p, zbar = ops.cls_pool_train_fwd(rows, c, scores, cls_scores, lens_i, B, Tp, NQ, R, D, pd, seed)
         att = torch.empty(B * NQ, D, device=dev, dtype=torch.float32)
-        for h in range(H):
-            ops.sgemm(zbar[:, h, :], Win[2 * D + h * hd:2 * D + (h + 1) * hd], transb=True, bias=bin_[2 * D + h * hd:2 * D + (h + 1) * hd],
-                      out=att[:, h * hd:(h + 1) * hd])
+        ops.sgemm_batched(B, hd, D, zbar, R * D, D, Wv, D, hd * D, att, D, hd, H, transb=True, bias=bv, stride_bias=hd)   # o_h = Wv_h zbar_h + bv_h
         # ---- rest of the encoder layer on the CLS rows (post-LN), final norm, projection
         sa = ops.sgemm(att, _c(out_w), transb=True, bias=_c(out_b))
         if pd > 0:
@@ -133,22 +130,19 @@ class ParallelBranchTrainFn(torch.autograd.Function):
         datt = ops.sgemm(dsa, Wo)
         dWin, dbin = z(3 * D, D), z(3 * D)
         dzbar = torch.empty(B, R, D, device=dev, dtype=torch.float32)
-        for h in range(H):
-            sl = slice(h * hd, (h + 1) * hd)
-            ops.sgemm(datt[:, sl], zbar[:, h, :], transa=True, out=dWin[2 * D + h * hd:2 * D + (h + 1) * hd])
-            ops.colsum(datt[:, sl], out=dbin[2 * D + h * hd:2 * D + (h + 1) * hd])
-            ops.sgemm(datt[:, sl], Win[2 * D + h * hd:2 * D + (h + 1) * hd], out=dzbar[:, h, :])
+        Wk, Wv = Win[D:2 * D], Win[2 * D:]
+        ops.sgemm_batched(hd, D, B, datt, D, hd, zbar, R * D, D, dWin[2 * D:], D, hd * D, H, transa=True)        # dWv_h = datt_h^T zbar_h
+        ops.colsum(datt, out=dbin[2 * D:])
+        ops.sgemm_batched(B, D, hd, datt, D, hd, Wv, D, hd * D, dzbar, R * D, D, H)                               # dzbar_h = datt_h Wv_h
         hid = ctx.hidden
         hid2 = hid.reshape(hid.shape[0], B * Tp, D) if (has_mix and hid is not None) else None
         du, dck, dalpha = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)), drop_p=pd, seed=seed)
-        dU = ops.colsum(du.view(B, R * D)).view(R, D)
-        ops.colsum(dck.view(B, NQ * D), out=dcls.view(NQ * D), accumulate=True)               # CLS token as a key / value
+        dU = ops.colsum(du.view(-1, R * D)).view(R, D)                                        # rows: B x key-splits
+        ops.colsum(dck.view(-1, NQ * D), out=dcls.view(NQ * D), accumulate=True)               # CLS token as a key / value
         # parameter-only chain: u_r = scale Wk_h^T q_h (beta carries no gradient: softmax is shift invariant)
         dqt = torch.empty(NQ, D, device=dev, dtype=torch.float32)
-        for h in range(H):
-            sl = slice(h * hd, (h + 1) * hd)
-            ops.sgemm(qt[:, sl], dU.view(NQ, H, D)[:, h, :], transa=True, alpha=scale, out=dWin[D + h * hd:D + (h + 1) * hd])
-            ops.sgemm(dU.view(NQ, H, D)[:, h, :], Win[D + h * hd:D + (h + 1) * hd], transb=True, alpha=scale, out=dqt[:, sl])
+        ops.sgemm_batched(hd, D, NQ, qt, D, hd, dU, H * D, D, dWin[D:2 * D], D, hd * D, H, transa=True, alpha=scale)   # dWk_h = scale q_h (x) dU_h
+        ops.sgemm_batched(NQ, hd, D, dU, H * D, D, Wk, D, hd * D, dqt, D, hd, H, transb=True, alpha=scale)             # dq_h = scale Wk_h dU_h
         ops.sgemm(dqt, c, transa=True, out=dWin[:D])
         ops.colsum(dqt, out=dbin[:D])
         ops.sgemm(dqt, Win[:D], beta=1.0, out=dcls)

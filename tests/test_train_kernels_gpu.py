@@ -166,7 +166,11 @@ def test_cls_pool_train_fwd_bwd_matches_autograd(B, T, D, NQ, H, n, normalize):
     # CLS tokens as keys: cls.grad of the reference = sum_b dz of the CLS key rows
     assert (dck.sum(0).cpu() - cls.grad).abs().max().item() < 5e-4 * max(1.0, cls.grad.abs().max().item())
     if n:
-        assert (dalpha.cpu() - dalpha_ref).abs().max().item() < 2e-3 * max(1.0, dalpha_ref.abs().max().item())
+        assert (dalpha.view(B, -1, n).sum(1).cpu() - dalpha_ref).abs().max().item() < 2e-3 * max(1.0, dalpha_ref.abs().max().item())
+        one = ops.cls_pool_bwd(x_rows, cls.detach().to(d).contiguous(), hid.reshape(n, B * T, D).to(d), p, dzbar.to(d), u.detach().to(d).contiguous(),
+                               lens_i, B, T, NQ, R, D, normalize=normalize, nsplit=1)
+        assert one[2].shape == (B, n) and (one[2].cpu() - dalpha_ref).abs().max().item() < 2e-3 * max(1.0, dalpha_ref.abs().max().item())
+        assert (one[0].sum(0) - du.sum(0)).abs().max().item() < 1e-3 * scale
 
 
 def test_cls_pool_dropout_is_consistent_between_forward_and_backward():
@@ -250,3 +254,46 @@ def test_adam_and_grad_clip_match_torch():
         assert abs(nc[0].item() - tn.item()) < 1e-3 * tn.item()
         ops.adam_step(p, gd, m, v, step, 1e-3, weight_decay=1e-6, clip_coef=nc)
         assert (p.cpu() - pt.detach()).abs().max().item() < 2e-6
+
+
+def test_sgemm_batched_heads():
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, H, hd, D = 37, 8, 96, 768
+    zbar = torch.randn(B, H, D, generator=g).to(dev())
+    Wv = torch.randn(D, D, generator=g).to(dev())
+    bv = torch.randn(D, generator=g).to(dev())
+    att = torch.empty(B, D, device=dev())
+    ops.sgemm_batched(B, hd, D, zbar, H * D, D, Wv, D, hd * D, att, D, hd, H, transb=True, bias=bv, stride_bias=hd)
+    ref = torch.einsum("bhd,hjd->bhj", zbar.double(), Wv.double().view(H, hd, D)).reshape(B, D) + bv.double()
+    assert (att.double() - ref).abs().max().item() < 2e-3
+    datt = torch.randn(B, D, generator=g).to(dev())
+    dW = torch.empty(D, D, device=dev())
+    ops.sgemm_batched(hd, D, B, datt, D, hd, zbar, H * D, D, dW, D, hd * D, H, transa=True)
+    refw = torch.einsum("bhj,bhd->hjd", datt.double().view(B, H, hd), zbar.double()).reshape(D, D)
+    assert (dW.double() - refw).abs().max().item() < 2e-3
+
+
+def test_train_mode_crop_pad_matches_per_utterance_path():
+    """The batched train-mode crop (sc_crop_pad) draws the same numpy offsets as the reference's per-utterance loop and yields the same batch."""
+    import numpy as np
+    from speechclip_amd import ops
+    from speechclip_amd.module.speech_encoder_plus import random_crop_max_length
+    g = torch.Generator().manual_seed(8)
+    lens = [9000, 2500, 6401, 6400, 12000]
+    wav = torch.zeros(len(lens), max(lens))
+    for i, l in enumerate(lens):
+        wav[i, :l] = torch.randn(l, generator=g)
+    max_len = 6400
+    np.random.seed(5)
+    ref = [random_crop_max_length(wav[i, :l], max_len, l) for i, l in enumerate(lens)]
+    np.random.seed(5)
+    starts, outl = [], []
+    for n in lens:
+        if n <= max_len:
+            starts.append(0); outl.append(n)
+        else:
+            starts.append(int(np.random.randint(n - max_len))); outl.append(max_len)
+    out = ops.crop_pad(wav.to(dev()), starts, outl, max(outl)).cpu()
+    for i, r in enumerate(ref):
+        assert torch.equal(out[i, :len(r)], r) and bool((out[i, len(r):] == 0).all())
