@@ -221,6 +221,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int a_base = wm * 128 * 128;
     const int b_base = 256 * 128 + wn * 64 * 128;
     const bool vec_ok = !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!RES || p.ldr % 8 == 0);
+    const bool f32_ok = p.out_f32 && (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!RES || p.ldr % 4 == 0);
 
     // Persistent: one block per CU walks the tile list (a new 512-thread / 144 KiB block per tile costs several us of
     // dispatch + an exposed prologue).  XCD-aware order: block b runs on XCD b % 8 and takes a contiguous chunk of the
@@ -448,6 +449,51 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     }
                 }
                 if (!RES && nhave && emode == 2) { issue_q(2 * i); issue_q(2 * i + 1); }
+            }
+        } else if (f32_ok) {
+            // fp32 outputs (the ViT / pre-LN residual streams): same quad rule as above.  Lane (frow, fk) holds 4 consecutive fp32 =
+            // 16 bytes of row frow; the 4 lanes (frow, 0..3) together own one 64-byte segment, so lane L fetches (crossbar) the
+            // value of lane (L >> 2) + 16 (L & 3): a store instruction then writes 16 rows x 64 contiguous bytes per 16-column block.
+            float* Cf = (float*)p.C;
+            const int srow = lane >> 2, schunk = lane & 3;
+            const int bperm = (srow + 16 * schunk) << 2;
+            const int64_t mrow0 = m0 + wm * 128 + srow;
+            const int ncol0 = n0 + wn * 64 + schunk * 4;
+            const bool full_tile = (m0 == m_lo) && (n0 == n_lo);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t m = mrow0 + i * 16;
+                f32x4_t rs[4];
+                if (RES) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = ncol0 + j * 16;
+                        rs[j] = (full_tile || (m >= m_lo && n >= n_lo)) ? *(const f32x4_t*)((const float*)p.residual + m * p.ldr + n) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                f32x4_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4_t v4 = acc[i][j];
+                    v4 += bias4[j];
+                    if (ACT == SC_ACT_GELU) {
+                        const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
+                        v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+                    } else if (ACT == SC_ACT_QUICKGELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float t = v4[r]; o[j][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm, __float_as_int(t))); }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = ncol0 + j * 16;
+                    if (full_tile || (m >= m_lo && n >= n_lo)) {
+                        if (RES) o[j] += rs[j];
+                        *(f32x4_t*)(Cf + m * p.ldc + n) = o[j];
+                    }
+                }
             }
         } else {
             char* Cb = (char*)p.C;
