@@ -19,10 +19,11 @@ def world():
     return 0, 1
 
 
-def gather_loss_feats(feats: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-    """{id [B] i64, image_feat [B,E], parallel_audio_feat / cascaded_audio_feat [B,E]} -> same keys, global batch."""
+def gather_loss_feats(feats: Dict[str, torch.Tensor], force: bool = False) -> Dict[str, torch.Tensor]:
+    """{id [B] i64, image_feat [B,E], parallel_audio_feat / cascaded_audio_feat [B,E]} -> same keys, global batch.
+    `force`: run the packed collective even at world size 1 (single-GPU check of the RCCL path)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return feats
     keys = [k for k in sorted(feats) if k != "id" and torch.is_tensor(feats[k])]
     ids = feats["id"].to(torch.int64).contiguous()

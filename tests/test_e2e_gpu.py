@@ -248,3 +248,30 @@ def test_full_size_properties():
     assert _cos(lf3["parallel_audio_feat"], a1[perm]).min().item() > 0.99999
     ref = masked_contrastive_loss(a1.cpu(), i1.cpu(), batch["id"].cpu()).item()
     assert abs(loss - ref) < 1e-4 and abs(loss_perm - loss) < 1e-4
+
+
+def test_rccl_packed_gather_on_one_gpu():
+    """The exchange step over RCCL (backend "nccl") on the real device: process group of size 1, packed all-gather of the features with the
+    int64 ids bit-cast into two fp32 lanes, plus the flat-gradient all-reduce of FusedAdam.  (N > 1 is covered by the gloo tests on CPU.)"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, os.getcwd())
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        from speechclip_amd import parallel
+        g = torch.Generator().manual_seed(0)
+        feats = {"id": torch.tensor([7, 2 ** 40 + 5, -3, 11]).cuda(), "image_feat": torch.randn(4, 512, generator=g).cuda(),
+                 "parallel_audio_feat": torch.randn(4, 512, generator=g).cuda()}
+        out = parallel.gather_loss_feats(feats, force=True)
+        assert all(torch.equal(out[k], feats[k]) for k in feats), "packed gather changed the payload"
+        assert out["id"].dtype == torch.int64
+        t = torch.arange(1000, device="cuda", dtype=torch.float32)
+        dist.all_reduce(t)
+        assert torch.equal(t, torch.arange(1000, device="cuda", dtype=torch.float32))
+        dist.destroy_process_group()
+        print("RCCL_OK")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
