@@ -10,6 +10,7 @@
 //      barrier per 64-key tile; tiles past the utterance's key length are skipped entirely.
 //  (2) cls_attn_kernel: the CLS-rows-only attention of the parallel / cascaded heads: NQ <= 8 learned
 //      query tokens against [CLS tokens ; valid frames] for any head_dim <= 1024 (VALU, HBM-bound).
+#include <type_traits>
 #include "common.h"
 #include "../../include/speechclip_hip.h"
 
@@ -31,7 +32,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 // consecutive key rows touched by one ds_read_b64_tr_b16 group on different bank groups.
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 3) << 1; }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+template <int NW>   // waves per block: NW x 32 query rows share one K/V ring (4: 128 rows, 8: 256 rows -- half the K/V traffic, 4 waves per SIMD)
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
                                                        const int32_t* __restrict__ klens, int T, int64_t ld_qkv,
                                                        int64_t ld_out, float scale_log2e, int causal, int B, int H, int nq) {
@@ -54,11 +56,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     klen = klen < 0 ? 0 : (klen > T ? T : klen);
     int nkv = (klen + KV - 1) / KV;
     if (causal) {  // keys beyond the block's last query are never needed
-        const int last_q = min(T, qblk * 128 + 128);
+        const int last_q = min(T, qblk * (NW * 32) + NW * 32);
         nkv = min(nkv, (last_q + KV - 1) / KV);
     }
 
-    const int qrow = qblk * 128 + wave * 32 + ql;
+    const int qrow = qblk * (NW * 32) + wave * 32 + ql;
     const int qrow_c = qrow < T ? qrow : T - 1;
 
     // Q fragments: B operand of S^T (col = query, k-slots = 8 dims)
@@ -67,19 +69,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int c = 0; c < 4; ++c)
         qf[c] = *(const bf16x8_t*)(q + (row_base + qrow_c) * ld_qkv + hoff + c * 16 + g * 8);
 
-    // K and V tiles both arrive by LDS-DMA (no VGPR staging): 2 + 2 instructions per thread per tile
+    // K and V tiles both arrive by LDS-DMA (no VGPR staging): 2 + 2 instructions per thread per tile.  Source addressing is kept
+    // cheap: a 64-bit per-thread base (row 0 of the unit, this thread's key row / chunk) + a 32-bit row offset per tile.
+    constexpr int NLD = 512 / (NW * 64);                            // row groups per thread per operand: 2 (NW = 4) or 1 (NW = 8)
+    const int key0 = tid >> 3, pos = tid & 7;                       // rows key0 (+ 32) of the tile, 16-byte chunk pos
+    const bf16_t* kbase = k + row_base * ld_qkv + hoff;
+    const bf16_t* vbase = v + row_base * ld_qkv + hoff;
+    const int kchunk0 = (pos ^ (key0 & 7)) << 3, vchunk0 = (pos ^ swz_v(key0)) << 3;          // (key0 + 32) has the same low bits
     auto stage = [&](int tile, int buf) {
         char* kb = smem + buf * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int cid = i * 256 + tid;
-            const int key = cid >> 3, pos = cid & 7;
-            int kr = tile * KV + key;
+        for (int i = 0; i < NLD; ++i) {
+            int kr = tile * KV + key0 + 32 * i;
             kr = kr < T ? kr : T - 1;
-            const int64_t rowoff = (row_base + kr) * ld_qkv + hoff;
-            glds16(k + rowoff + ((pos ^ (key & 7)) << 3), kb + (i * 256 + wave * 64) * 16);
-            glds16(v + rowoff + ((pos ^ swz_v(key)) << 3), kb + K_TILE_BYTES + (i * 256 + wave * 64) * 16);
+            const int64_t rowoff = (int64_t)kr * ld_qkv;
+            glds16(kbase + rowoff + kchunk0, kb + (i * 256 + wave * 64) * 16);
+            glds16(vbase + rowoff + vchunk0, kb + K_TILE_BYTES + (i * 256 + wave * 64) * 16);
         }
+    };
+    auto wait_stage = [&](bool keep_one) {    // all but the newest stage landed (2 * NLD DMA instructions per stage)
+        if (!keep_one) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (NLD == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     };
 
     f32x16_t o[2];
@@ -87,38 +98,65 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
-    // per-lane pieces of the V^T fragment address (ds_read_b64_tr_b16: within a 16-lane group, lane i points at key row i>>2,
-    // 4 consecutive d at (i&3)*4, and receives column (i) of the 4 x 16 block, i.e. V[k0..k0+3][d0 + i])
+    // Lane parts of the LDS fragment addresses (ring slot and kb / hb / +8-row terms are compile-time immediates below).
+    // K: key = kb*32 + ql, chunk (2c+g) ^ (key & 7) -- the XOR makes the four c distinct lane parts.
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned ka[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ka[c] = lds_base + ql * 128 + (((2 * c + g) ^ (ql & 7)) << 4);
+    // V^T (ds_read_b64_tr_b16: within a 16-lane group, lane i points at key row i>>2, 4 consecutive d at (i&3)*4, and receives column
+    // (i) of the 4 x 16 block, i.e. V[k0..k0+3][d0 + i]): k0 = kb*32 + hb*16 + 4g + v_row_in; rows k0 and k0+8 share their swizzle.
     const int ti = lane & 15;
     const int v_row_in = ti >> 2;                                  // key row within the group of 4
     const int v_chunk_in = (((lane >> 4) & 1) << 1) + ((ti & 3) >> 1);   // 16-B chunk within the 64-B d-block
     const int v_byte_in = (ti & 1) * 8;
+    const int vk0 = 4 * g + v_row_in;
+    unsigned va[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) va[db] = lds_base + K_TILE_BYTES + vk0 * 128 + (((db * 4 + v_chunk_in) ^ swz_v(vk0)) << 4) + v_byte_in;
 
     if (nkv > 0) {
         stage(0, 0);
         if (nkv > 1) stage(1, 1);
-        if (nkv > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_stage(nkv > 1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    for (int j = 0; j < nkv; ++j) {
-        if (j + 2 < nkv) stage(j + 2, (j + 2) % NSTAGE);    // that buffer held tile j-1: every wave passed the barrier after reading it
-        const char* kb_ = smem + (j % NSTAGE) * STAGE_BYTES;
-        const char* vb_ = kb_ + K_TILE_BYTES;
-        // ---- S^T = K . Q^T
+    // One KV tile; SLOT (ring slot of tile j) is a compile-time constant so every LDS address is lane part + immediate.
+    // All LDS reads are inline asm with hand-counted lgkmcnt: for a builtin / plain load the compiler cannot prove that the read does
+    // not alias the LDS-DMA writes in flight and guards it with s_waitcnt vmcnt(0), which would drain the prefetch of tile j+2.
+    auto tile_body = [&](int j, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        if (j + 2 < nkv) stage(j + 2, (SLOT + 2) % NSTAGE);   // that buffer held tile j-1: every wave passed the barrier after reading it
+        // ---- S^T = K . Q^T : all 8 K fragments are requested up front, the MFMAs then run back to back
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+        u32x4_t kf[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                const unsigned addr = ka[c];
+                u32x4_t t;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(addr), "i"(SLOT * STAGE_BYTES + kb * 4096));
+                kf[kb][c] = t;
+            }
         f32x16_t s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-            const int key = kb * 32 + ql;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                bf16x8_t kf = *(const bf16x8_t*)(kb_ + key * 128 + (((2 * c + g) ^ (key & 7)) << 4));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], s[kb], 0, 0, 0);
+                if (kb == 0) { if (c == 0) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); else if (c == 1) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); else if (c == 2) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
+                else { if (c == 0) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); else if (c == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); else if (c == 2) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+                u32x4_t t = kf[kb][c];
+                asm volatile("" : "+v"(t));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, t), qf[c], s[kb], 0, 0, 0);
             }
         }
+#if !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2)   // perf probe 2: no softmax arithmetic at all (MFMA + LDS + DMA skeleton)
         // ---- mask + online softmax (log2 domain).  Only a tile that crosses the key length (or the causal diagonal)
         //      pays for per-element masking; full tiles take the short path.
         float mx = -INFINITY;
@@ -146,57 +184,74 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
         m_run = m_new;
-        float psum = 0.f;
-        if (partial) {
+        f32x2_t psum2 = {0.f, 0.f};
+        const float sc = partial ? 1.0f : scale_log2e;               // partial tiles were scaled while masking
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-                    s[kb][r] = pv;
-                    psum += pv;
-                }
-        } else {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], scale_log2e, -m_new));
-                    s[kb][r] = pv;
-                    psum += pv;
-                }
-        }
-        l_run = l_run * alpha + psum;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2_t a2 = (f32x2_t){s[kb][r], s[kb][r + 1]} * sc - m_new;       // one v_pk_fma_f32 per pair
+#if defined(SC_ATTN_ABL) && SC_ATTN_ABL == 1
+                const f32x2_t p2 = a2 * 0.001f;                                            // perf probe: no transcendental
+#else
+                const f32x2_t p2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+#endif
+                s[kb][r] = p2[0]; s[kb][r + 1] = p2[1];
+                psum2 += p2;
+            }
+        l_run = l_run * alpha + (psum2[0] + psum2[1]);
         if (alpha != 1.0f) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
         }
+#endif
         // ---- O^T += V^T . P^T : V^T fragments come straight out of the row-major V tile via the transposing LDS read
+        u32x2_t vlo[2][2], vhi[2][2];                               // [parity of c4][db]
+        auto issue_v = [&](auto c4c) {
+            constexpr int c4 = decltype(c4c)::value;
+            constexpr int off = SLOT * STAGE_BYTES + (c4 >> 1) * 4096 + (c4 & 1) * 2048;
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-            const int kb = c4 >> 1, hb = c4 & 1;
+            for (int db = 0; db < 2; ++db) {
+                const unsigned addr = va[db];
+                u32x2_t t0, t1;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t0) : "v"(addr), "i"(off));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t1) : "v"(addr), "i"(off + 1024));
+                vlo[c4 & 1][db] = t0; vhi[c4 & 1][db] = t1;
+            }
+        };
+        auto pv = [&](auto c4c, bool more) {
+            constexpr int c4 = decltype(c4c)::value;
+            constexpr int kb = c4 >> 1, hb = c4 & 1;
             bf16x8_t pf;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)s[kb][hb * 8 + jj];
-            const int k0 = kb * 32 + hb * 16 + 4 * g + v_row_in;    // first group of 4 keys; the second is k0 + 8
+            if (more) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int ch = db * 4 + v_chunk_in;
-                const char* p0 = vb_ + k0 * 128 + ((ch ^ swz_v(k0)) << 4) + v_byte_in;
-                const char* p1 = vb_ + (k0 + 8) * 128 + ((ch ^ swz_v(k0 + 8)) << 4) + v_byte_in;
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
-                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-                const s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, both);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+                u32x2_t lo = vlo[c4 & 1][db], hi = vhi[c4 & 1][db];
+                asm volatile("" : "+v"(lo), "+v"(hi));                // valid only after the wait above: pin the use below it
+                const u32x4_t both = {lo[0], lo[1], hi[0], hi[1]};
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, both), pf, o[db], 0, 0, 0);
             }
-        }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // none of the compiler's own LDS traffic (the shuffle) outstanding
+        issue_v(I0{});
+        issue_v(I1{}); pv(I0{}, true);
+        issue_v(I2{}); pv(I1{}, true);
+        issue_v(I3{}); pv(I2{}, true);
+        pv(I3{}, false);
         // tile j+1 must have landed before anyone reads it; tile j+2 (just issued) stays in flight across the barrier
-        if (j + 2 < nkv) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        wait_stage(j + 2 < nkv);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    };
+    for (int j = 0; j < nkv; j += 3) {
+        tile_body(j, std::integral_constant<int, 0>{});
+        if (j + 1 < nkv) tile_body(j + 1, std::integral_constant<int, 1>{});
+        if (j + 2 < nkv) tile_body(j + 2, std::integral_constant<int, 2>{});
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -391,15 +446,24 @@ extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, voi
     SC_CHECK_ARG(ld_qkv % 8 == 0 && ld_out % 4 == 0, "sc_attention_fwd: ld_qkv must be a multiple of 8, ld_out of 4");
     SC_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "sc_attention_fwd: misaligned pointers");
     if (B <= 0 || T <= 0) return 0;
-    static bool attr = false;
     constexpr int lds = NSTAGE * STAGE_BYTES;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    const int nq = (T + 127) / 128;
+    // 8-wave blocks (256 query rows share the K/V ring) when there are at least 256 queries; SC_ATTN_NW=4 forces the 4-wave form
+    static const int force_nw = getenv("SC_ATTN_NW") ? atoi(getenv("SC_ATTN_NW")) : 0;
+    const int nw = force_nw ? force_nw : (T > 128 ? 8 : 4);
+    const int rows = nw * 32;
+    const int nq = (T + rows - 1) / rows;
     const int64_t units8 = ((int64_t)H * B + 7) / 8;
     SC_CHECK_ARG(units8 * 8 * nq < 0x7fffffff, "sc_attention_fwd: grid too large");
     dim3 grid((unsigned)(units8 * 8 * nq));
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq);
+    if (nw == 8) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                           (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq);
+    } else {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                           (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq);
+    }
     SC_CHECK_LAUNCH();
     return 0;
 }
