@@ -119,8 +119,9 @@ int sc_cls_pool_fwd(const void* x, int64_t ld_x, const void* cls_tok, const floa
 int64_t sc_conv0_stats_workspace_bytes(int B);
 int sc_conv0_gn_coef(const float* wav, int64_t ld, const float* w, const float* gamma, const float* beta, void* workspace,
                      float* coef, int B, int C, int T0, float eps, void* stream);
+int64_t sc_conv0_wfrag_workspace_bytes(int B);   /* scratch for the matrix-core form (C % 64 == 0): per-utterance weight fragments */
 int sc_conv0_fwd(const float* wav, int64_t ld, int64_t L, const float* w, const float* bias, const float* coef, void* out, int B,
-                 int C, int T0, int P, int mode, void* stream);
+                 int C, int T0, int P, int mode, void* wfrag_ws, void* stream);
 
 /* ---- HuBERT positional conv -- speech_encoder_plus.py:32-40 ------------------------------------
  * pack: zero padded frames (t >= valid[b]) and regroup x bf16 [B*Tp, D] into xg bf16

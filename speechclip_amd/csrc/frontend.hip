@@ -134,6 +134,110 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------- conv0 on the matrix cores
+// The VALU form above spends 40 packed FMAs per 8 channels per frame on the 10-tap dot products.  Here a 16-frame x 16-channel block
+// is ONE v_mfma_f32_16x16x32_bf16: the 32 k-slots carry  x_hi.w_hi (taps 0-9) + x_lo.w_hi (10-19) + x_hi.w_lo (20-29)  with x = x_hi +
+// x_lo and w' = w_hi + w_lo the bf16 splits of the fp32 samples / weights (w' = w * GroupNorm scale of this utterance and channel, so
+// only the shift remains for the epilogue).  The dropped x_lo.w_lo term is 2^-16 relative.  What is left on the VALU is the shift, the
+// GELU polynomial and the bf16 pack; the output leaves through the GEMM epilogue's quad-contiguous store (permlane swap + crossbar
+// transpose: 16 frames x 64 contiguous bytes per store instruction).  Block = one utterance x FB frames, 4 waves x 16-frame groups.
+// W fragments, built once per utterance: wfrag[b][cb][lane] (16 bytes) = channel cb*16 + (lane & 15), k-slots (lane >> 4)*8 .. +7
+// (slot -> (kind, tap): 0-9 w_hi, 10-19 w_hi, 20-29 w_lo, 30-31 zero), weights pre-multiplied by the GroupNorm scale of (b, channel).
+__global__ __launch_bounds__(256) void conv0_wfrag_kernel(const float* __restrict__ w, const float2* __restrict__ coef, bf16x8_t* __restrict__ wfrag, int C, int mode) {
+    const int b = blockIdx.x, ncb = C / 16;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int cb = i >> 6, lane = i & 63, frow = lane & 15, fk = lane >> 4;
+        const int c = cb * 16 + frow;
+        const float scl = (cb < ncb) ? (mode == 0 ? coef[(int64_t)b * C + c].x : 1.0f) : 0.f;
+        bf16x8_t f;
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) {
+            const int slot = fk * 8 + sidx;
+            const int tap = slot % CK, kind = slot / CK;
+            const float wv = (cb < ncb && slot < 30) ? w[c * CK + tap] * scl : 0.f;
+            const __bf16 hi = (__bf16)wv;
+            f[sidx] = kind == 2 ? (__bf16)(wv - (float)hi) : hi;
+        }
+        wfrag[((int64_t)b * 32 + cb) * 64 + lane] = f;
+    }
+}
+template <int FB>   // frames per block
+__global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict__ wav, int64_t ld, int64_t L, const bf16x8_t* __restrict__ wfrag,
+                                                         const float* __restrict__ bias, const float2* __restrict__ coef, bf16_t* __restrict__ out,
+                                                         int C, int T0, int P, int mode) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c0[];
+    bf16x8_t* wl = (bf16x8_t*)smem_c0;                    // [32][64] W fragments (32 KiB)
+    float* shs = (float*)(smem_c0 + 32 * 64 * 16);        // [512] per-channel shift (GroupNorm shift or conv bias)
+    float* xs = shs + 512;                                // FB * 5 + 8 samples
+    const int b = blockIdx.y, t0 = blockIdx.x * FB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = wav + (int64_t)b * ld;
+    const int nfr = min(FB, P - t0);
+    for (int i = tid; i < nfr * CS + CK; i += 256) {
+        const int64_t si = (int64_t)t0 * CS + i;
+        xs[i] = si < L ? x[si] : 0.f;
+    }
+    for (int i = tid; i < 32 * 64; i += 256) wl[i] = wfrag[(int64_t)b * 32 * 64 + i];
+    for (int c = tid; c < 512; c += 256) {
+        float sh = 0.f;
+        if (c < C) sh = mode == 0 ? coef[(int64_t)b * C + c].y : (bias ? bias[c] : 0.f);
+        shs[c] = sh;
+    }
+    const int frow = lane & 15, fk = lane >> 4;
+    const int ncb = C / 16;
+    const int srow = lane >> 2, schunk = lane & 3;       // epilogue lane geometry (as gemm256_kernel)
+    const int bperm = ((((schunk & 1) << 1) | (schunk >> 1)) * 16 + srow) << 2;
+    __syncthreads();
+    const int ngroups = nfr / 16;                         // P is a multiple of 64
+    for (int gidx = wave; gidx < ngroups; gidx += 4) {
+        const int tg = t0 + gidx * 16;                    // first frame of the group
+        // X fragment: frame tg + frow, slots fk*8..+7 (0-9 x_hi, 10-19 x_lo, 20-29 x_hi)
+        bf16x8_t xf;
+        const float* xr = xs + (gidx * 16 + frow) * CS;
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) {
+            const int slot = fk * 8 + sidx;
+            const int tap = slot % CK, kind = slot / CK;
+            const float xv = slot < 30 ? xr[tap] : 0.f;
+            const __bf16 hi = (__bf16)xv;
+            xf[sidx] = kind == 1 ? (__bf16)(xv - (float)hi) : hi;
+        }
+        const bool live_row = (tg + srow) < T0;           // frames in [T0, P) are written as zeros
+        bf16_t* orow = out + ((int64_t)b * P + tg + srow) * C + schunk * 8;
+        f32x4_t acc[2][4];                                // two 64-channel chunks in flight: MFMAs of chunk q+1 issue before the epilogue of q
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j * 64 + lane], xf, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {                     // 64 channels at a time
+            if (q * 4 >= ncb) break;
+            if ((q + 1) * 4 < ncb) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[(q + 1) & 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[((q + 1) * 4 + j) * 64 + lane], xf, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+            uint2 pk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4_t v4 = acc[q & 1][j] + *(const f32x4_t*)(shs + (q * 4 + j) * 16 + fk * 4);
+                if (mode == 0) {
+                    const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
+                    v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+                }
+                pk[j].x = pack2bf(v4[0], v4[1]);
+                pk[j].y = pack2bf(v4[2], v4[3]);
+            }
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const auto r0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].x, pk[2 * jp + 1].x, false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].y, pk[2 * jp + 1].y, false, false);
+                uint4 o = make_uint4(__builtin_amdgcn_ds_bpermute(bperm, r0[0]), __builtin_amdgcn_ds_bpermute(bperm, r1[0]),
+                                     __builtin_amdgcn_ds_bpermute(bperm, r0[1]), __builtin_amdgcn_ds_bpermute(bperm, r1[1]));
+                if (!live_row) o = make_uint4(0, 0, 0, 0);
+                *(uint4*)(orow + q * 64 + jp * 32) = o;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- pos-conv
 // xg[b][g][Kw/2 + t][c] = t < valid[b] ? x[b][t][g*cg + c] : 0, rows [0,Kw/2) and [Kw/2+Tp, Tp+Kw) zero.
 __global__ __launch_bounds__(256) void posconv_pack_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ valid, bf16_t* __restrict__ xg,
@@ -288,13 +392,30 @@ extern "C" int sc_conv0_gn_coef(const float* wav, int64_t ld, const float* w, co
     return 0;
 }
 
+extern "C" int64_t sc_conv0_wfrag_workspace_bytes(int B) { return (int64_t)B * 32 * 64 * 16; }
+
 extern "C" int sc_conv0_fwd(const float* wav, int64_t ld, int64_t L, const float* w, const float* bias, const float* coef, void* out, int B,
-                            int C, int T0, int P, int mode, void* stream) {
+                            int C, int T0, int P, int mode, void* wfrag_ws, void* stream) {
     SC_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= 512, "sc_conv0_fwd: C=%d must be a multiple of 8, <= 512", C);
     SC_CHECK_ARG(mode == 1 || coef != nullptr, "sc_conv0_fwd: GroupNorm mode needs coef");
     SC_CHECK_ARG(P >= T0 && B > 0 && B <= 65535, "sc_conv0_fwd: need P >= T0 and 0 < B <= 65535");
-    hipLaunchKernelGGL(conv0_fwd_kernel, dim3((P + TT - 1) / TT, B), dim3(256), 0, (hipStream_t)stream, wav, ld, L, w, bias, (const float2*)coef,
-                       (bf16_t*)out, C, T0, P, mode);
+    static const bool force_valu = getenv("SC_CONV0_VALU") != nullptr;
+    if (C % 64 == 0 && P % 64 == 0 && !force_valu) {      // matrix-core form (every shipped config: C = 512)
+        SC_CHECK_ARG(wfrag_ws != nullptr, "sc_conv0_fwd: the matrix-core form needs the W-fragment workspace (sc_conv0_wfrag_workspace_bytes)");
+        hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, w, (const float2*)coef, (bf16x8_t*)wfrag_ws, C, mode);
+        SC_CHECK_LAUNCH();
+        static const int fb = getenv("SC_CONV0_FB") ? atoi(getenv("SC_CONV0_FB")) : 256;   // measured 128..2048: 256 is the fastest
+#define CONV0_LAUNCH(FB_) do {                                                                                                                   \
+        const int lds = 32 * 64 * 16 + (512 + FB_ * CS + 16) * 4;                                                                                  \
+        (void)hipFuncSetAttribute((const void*)conv0_mfma_kernel<FB_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                           \
+        hipLaunchKernelGGL(conv0_mfma_kernel<FB_>, dim3((P + FB_ - 1) / FB_, B), dim3(256), lds, (hipStream_t)stream, wav, ld, L,                  \
+                           (const bf16x8_t*)wfrag_ws, bias, (const float2*)coef, (bf16_t*)out, C, T0, P, mode); } while (0)
+        if (fb == 128) CONV0_LAUNCH(128); else if (fb == 512) CONV0_LAUNCH(512); else if (fb == 1024) CONV0_LAUNCH(1024); else CONV0_LAUNCH(256);
+#undef CONV0_LAUNCH
+    } else {
+        hipLaunchKernelGGL(conv0_fwd_kernel, dim3((P + TT - 1) / TT, B), dim3(256), 0, (hipStream_t)stream, wav, ld, L, w, bias, (const float2*)coef,
+                           (bf16_t*)out, C, T0, P, mode);
+    }
     SC_CHECK_LAUNCH();
     return 0;
 }

@@ -27,7 +27,7 @@ struct GemmParams {
     unsigned long long* trace;   // debug: per-block s_memtime stamps (sc_debug_set_gemm_trace)
     int rot;                     // rotate the K loop per block (L2 channel de-correlation)
     int band;                    // N-tiles per column band of the persistent tile order (0/>=tiles_n: M-panel-major over all of N)
-    int epi_mode;                // next tile's first two stages: 0 issued before the epilogue, 2 interleaved with its stores (default), 3 after it
+    int epi_mode, epi_mode_res;                // next tile's first two stages: 0 issued before the epilogue, 2 interleaved with its stores (default), 3 after it
 };
 
 constexpr int BK = 64;  // 128 bytes of bf16 per tile row = 8 chunks of 16 B
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             if (g < 4) glds16(sa.ta + (g * lda64 + kofs(st)) + lane_a, slot + (g * 512 + wave * 64) * 16);
             else glds16(sa.tw + ((g - 4) * ldw64 + kofs(st)) + lane_w, slot + 256 * 128 + ((g - 4) * 512 + wave * 64) * 16);
         };
-        const int emode = RES ? 3 : p.epi_mode;
+        const int emode = RES ? p.epi_mode_res : p.epi_mode;
         if (nhave && emode == 0) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) issue_q(q);
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                         else asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
                     }
                 }
-                if (!RES && nhave && emode == 2) { issue_q(2 * i); issue_q(2 * i + 1); }
+                if (nhave && emode == 2) { issue_q(2 * i); issue_q(2 * i + 1); }
             }
         } else if (f32_ok) {
             // fp32 outputs (the ViT / pre-LN residual streams): same quad rule as above.  Lane (frow, fk) holds 4 consecutive fp32 =
@@ -644,6 +644,7 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     p.rot = getenv("SC_GEMM_NOROT") ? 0 : 1;
     p.band = getenv("SC_GEMM_BAND") ? atoi(getenv("SC_GEMM_BAND")) : -1;   // -1: chosen by the dispatcher
     p.epi_mode = getenv("SC_GEMM_EPI") ? atoi(getenv("SC_GEMM_EPI")) : 2;
+    p.epi_mode_res = getenv("SC_GEMM_EPI_RES") ? atoi(getenv("SC_GEMM_EPI_RES")) : 3;
     return gemm_dispatch(p, 1, (hipStream_t)stream);
 }
 

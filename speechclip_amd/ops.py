@@ -157,13 +157,14 @@ def conv0(wav, w, T0, P, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5, out=N
     assert wav.dtype == torch.float32 and wav.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
     buf = out if out is not None else torch.zeros(B * P + 8, C, device=wav.device, dtype=bf16)
     assert buf.dtype == bf16 and buf.is_contiguous() and buf.shape[0] >= B * P and buf.shape[1] == C
+    wfrag = torch.empty(lib().sc_conv0_wfrag_workspace_bytes(B), device=wav.device, dtype=torch.uint8)
     if gn_gamma is not None:
         ws = torch.empty(lib().sc_conv0_stats_workspace_bytes(B), device=wav.device, dtype=torch.uint8)
         coef = torch.empty(B, C, 2, device=wav.device, dtype=torch.float32)
         check(lib().sc_conv0_gn_coef(ptr(wav), L, ptr(w), ptr(gn_gamma), ptr(gn_beta), ptr(ws), ptr(coef), B, C, T0, eps, stream()), "sc_conv0_gn_coef")
-        check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), None, ptr(coef), ptr(buf), B, C, T0, P, 0, stream()), "sc_conv0_fwd")
+        check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), None, ptr(coef), ptr(buf), B, C, T0, P, 0, ptr(wfrag), stream()), "sc_conv0_fwd")
     else:
-        check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), ptr(bias), None, ptr(buf), B, C, T0, P, 1, stream()), "sc_conv0_fwd")
+        check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), ptr(bias), None, ptr(buf), B, C, T0, P, 1, ptr(wfrag), stream()), "sc_conv0_fwd")
     return buf
 
 
