@@ -161,6 +161,10 @@ int64_t sc_vq_workspace_bytes(int R, int V);
 int sc_vq_fwd(const float* scores, int64_t* targets, float* stats2, float* ent_per_t, void* workspace, int R, int K, int V,
               const int32_t* host_mask_ids, int n_mask, void* stream);
 int sc_gather_rows(const float* src, const int64_t* idx, float* out, int R, int E, void* stream);
+/* sc_retrieval_ranks: rank[i] = number of candidates ranked ahead of row i's best candidate carrying own_ids[i] (stable descending order;
+ *   m if no candidate matches): recall@K of mutualRetrieval (avssl/module/retrieval.py:45-121) is mean(rank < K), without sorting.
+ *   score f32 [n, m] (ld elements per row), own_ids i64 [n], cand_ids i64 [m]. */
+int sc_retrieval_ranks(const float* score, int64_t ld, const int64_t* own_ids, const int64_t* cand_ids, int32_t* rank, int n, int m, void* stream);
 
 /* ==== Trainable tail: forward-for-training and backward of the parallel branch, the layer-mix weights,
  * L2 normalisation and the masked InfoNCE loss, Adam and gradient clipping.  All fp32 (master weights), except the frozen encoder's bf16

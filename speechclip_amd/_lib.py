@@ -66,6 +66,7 @@ def _declare(L):
         "sc_vq_workspace_bytes": ([I, I], c_int64),
         "sc_vq_fwd": ([P, P, P, P, P, I, I, I, P, I, P], c_int),
         "sc_gather_rows": ([P, P, P, I, I, P], c_int),
+        "sc_retrieval_ranks": ([P, L64, P, P, P, I, I, P], c_int),
         "sc_sgemm": ([I, I, I, I, I, F, P, L64, P, L64, F, P, L64, P, P], c_int),
         "sc_sgemm_batched": ([I, I, I, I, I, F, P, L64, L64, P, L64, L64, F, P, L64, L64, P, L64, I, P], c_int),
         "sc_cls_pool_train_fwd": ([P, L64, P, P, P, P, P, P, I, I, I, I, I, F, U32, P], c_int),

@@ -230,3 +230,49 @@ extern "C" int sc_gather_rows(const float* src, const int64_t* idx, float* out, 
     SC_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ retrieval ranks (K15)
+// mutualRetrieval (avssl/module/retrieval.py:45-121) sorts every score row and asks whether a candidate carrying the row's answer id
+// sits among the first K.  Equivalent rank test, one pass over the row and no sort: rank_i = #{j : s_ij > best positive score of row i}
+// (ties resolved towards the lower column index, i.e. a stable descending sort); hit@K  <=>  rank_i < K.  Rows without any positive
+// candidate get rank = m.  One wave per row.
+namespace {
+__global__ __launch_bounds__(256) void retrieval_rank_kernel(const float* __restrict__ score, int64_t ld, const int64_t* __restrict__ own_ids,
+                                                             const int64_t* __restrict__ cand_ids, int32_t* __restrict__ rank, int n, int m) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* s = score + (int64_t)row * ld;
+    const int64_t id = own_ids[row];
+    float best = -INFINITY;
+    int best_j = m;
+    for (int j = lane; j < m; j += 64)
+        if (cand_ids[j] == id) {
+            const float v = s[j];
+            if (v > best || (v == best && j < best_j)) { best = v; best_j = j; }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oj = __shfl_xor(best_j, o, 64);
+        if (ob > best || (ob == best && oj < best_j)) { best = ob; best_j = oj; }
+    }
+    int cnt = 0;
+    if (best_j < m)
+        for (int j = lane; j < m; j += 64) {
+            const float v = s[j];
+            cnt += (v > best || (v == best && j < best_j)) ? 1 : 0;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) rank[row] = best_j < m ? cnt : m;
+}
+}  // namespace
+
+extern "C" int sc_retrieval_ranks(const float* score, int64_t ld, const int64_t* own_ids, const int64_t* cand_ids, int32_t* rank, int n, int m,
+                                  void* stream) {
+    SC_CHECK_ARG(n > 0 && m > 0 && ld >= m, "sc_retrieval_ranks: bad shape n=%d m=%d ld=%lld", n, m, (long long)ld);
+    hipLaunchKernelGGL(retrieval_rank_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, score, ld, own_ids, cand_ids, rank, n, m);
+    SC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,6 +1,6 @@
 """mutualRetrieval -- same signature and return triple as avssl/module/retrieval.py:6-121 (recall@K in percent,
 A->B, B->A and their mean).  Implemented with a rank test instead of a full argsort + Python row loops:
-item i is a hit@K iff some candidate carrying its answer id ranks among the K best scores of row i."""
+item i is a hit@K iff fewer than K candidates score above its best candidate carrying its answer id (sc_retrieval_ranks on the device)."""
 from typing import Sequence, Tuple
 
 import torch
@@ -8,15 +8,18 @@ import torch
 
 def _recall_one_way(score: torch.Tensor, own_ids: torch.Tensor, cand_ids: torch.Tensor, recall_at: Sequence[int]) -> dict:
     n, m = score.shape
-    kmax = min(max(recall_at), m)
-    top = torch.topk(score, kmax, dim=1, largest=True, sorted=True).indices          # [n, kmax]
-    hit = cand_ids.to(score.device)[top] == own_ids.to(score.device)[:, None]
+    if score.is_cuda:       # device path: sc_retrieval_ranks (one pass per row, no sort)
+        from .. import ops
+        rank = ops.retrieval_ranks(score.float().contiguous(), own_ids, cand_ids)
+    else:                   # host tensors (the Lightning hook hands CPU tensors to validation_epoch_end when no GPU is involved)
+        pos = cand_ids.to(score.device)[None, :] == own_ids.to(score.device)[:, None]
+        best = torch.where(pos, score, torch.full_like(score, float("-inf"))).max(dim=1, keepdim=True).values
+        rank = torch.where(pos.any(dim=1), (score > best).sum(dim=1), torch.full((n,), m, device=score.device))
     out = {}
     for k in recall_at:
-        kk = min(k, m)
         if k > m:
             print("recall@{} is not eligible for #{} samples".format(k, m))
-        out["recall@{}".format(k)] = hit[:, :kk].any(dim=1).float().mean().item() * 100
+        out["recall@{}".format(k)] = (rank < min(k, m)).float().mean().item() * 100
     return out
 
 

@@ -443,3 +443,16 @@ def adam_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0
     _f32c(p, g, m, v)
     check(lib().sc_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(clip_coef[1:] if clip_coef is not None else None), lr, betas[0], betas[1],
                              eps, weight_decay, int(step), stream()), "sc_adam_step")
+
+
+def retrieval_ranks(score, own_ids, cand_ids):
+    """score f32 [n, m] (device); own_ids i64 [n]; cand_ids i64 [m] -> int32 [n]: candidates ranked ahead of the row's best positive."""
+    _need_cuda(score)
+    assert score.dtype == torch.float32 and score.dim() == 2 and score.stride(1) == 1
+    n, m = score.shape
+    own = own_ids.to(score.device, torch.int64).contiguous()
+    cand = cand_ids.to(score.device, torch.int64).contiguous()
+    assert own.shape == (n,) and cand.shape == (m,)
+    rank = torch.empty(n, device=score.device, dtype=torch.int32)
+    check(lib().sc_retrieval_ranks(ptr(score), score.stride(0), ptr(own), ptr(cand), ptr(rank), n, m, stream()), "sc_retrieval_ranks")
+    return rank

@@ -250,3 +250,36 @@ def test_cls_pool_algebraic_equals_attention(NQ, H, D, T):
         s = torch.einsum("qhd,khd->hqk", q, k) * hd ** -0.5
         ref[b] = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), v).reshape(NQ, D)
     torch.testing.assert_close(y, ref, atol=3e-2, rtol=3e-2)
+
+
+def test_retrieval_ranks_golden_and_random():
+    """Device recall@K (similarity by sc_sgemm, ranks by sc_retrieval_ranks) against the reference's mutualRetrieval values
+    (tests/golden/retrieval.npz) and against the oracle's argsort formulation at the Flickr8k test-set shape (5000 x 1000, 5 captions/image)."""
+    import os
+    import numpy as np
+    from oracle.speechclip_ref import mutual_retrieval
+    from speechclip_amd import ops
+    from speechclip_amd.module import mutualRetrieval
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "retrieval.npz"))
+    aud, img = torch.from_numpy(g["aud"]).cuda(), torch.from_numpy(g["img"]).cuda()
+    s = ops.sgemm(aud.contiguous(), img.contiguous(), transb=True)
+    ab, ba, mean = mutualRetrieval(s, s.t().contiguous(), torch.from_numpy(g["aud_ids"]), torch.from_numpy(g["img_ids"]), [1, 5, 10])
+    for i, k in enumerate((1, 5, 10)):
+        assert abs(ab[f"recall@{k}"] - g["recall_ab"][i]) < 1e-4 and abs(ba[f"recall@{k}"] - g["recall_ba"][i]) < 1e-4
+        assert abs(mean[f"recall@{k}"] - g["recall_mean"][i]) < 1e-4
+    gen = _g(77)
+    n_img, cap, E = 1000, 5, 512
+    imgf = F.normalize(torch.randn(n_img, E, generator=gen), dim=-1)
+    audf = F.normalize(imgf.repeat_interleave(cap, 0) + 6.0 * F.normalize(torch.randn(n_img * cap, E, generator=gen), dim=-1), dim=-1)
+    aud_ids, img_ids = torch.arange(n_img).repeat_interleave(cap), torch.arange(n_img)
+    sc = audf @ imgf.t()
+    ref = mutual_retrieval(sc, sc.t().contiguous(), aud_ids, img_ids, [1, 5, 10])
+    sd = ops.sgemm(audf.cuda().contiguous(), imgf.cuda().contiguous(), transb=True)
+    got = mutualRetrieval(sd, sd.t().contiguous(), aud_ids, img_ids, [1, 5, 10])
+    for a, b_ in zip(ref, got):
+        for k in a:
+            assert abs(a[k] - b_[k]) < 0.05, (k, a[k], b_[k])      # a handful of near-ties may order differently in fp32
+    assert 1.0 < got[0]["recall@1"] < 99.0                          # the synthetic task is neither trivial nor impossible
+    # rows without any positive candidate rank last
+    r = ops.retrieval_ranks(sd[:8].contiguous(), torch.full((8,), 10 ** 9), img_ids)
+    assert bool((r == n_img).all())
