@@ -128,6 +128,9 @@ int sc_conv0_fwd(const float* wav, int64_t ld, int64_t L, const float* w, const 
  * [B][G][Tp+Kw][D/G] (Kw/2 zero rows each side) so that group g is an overlapping-row GEMM
  * (lda = D/G, K = Kw*D/G) via sc_gemm_bf16_batched -> conv bf16 [B*G][Tp][D/G].
  * finish: out = [LayerNorm]( mask(x) + gelu(conv + bias) ); gamma NULL = no LN (layer_norm_first). */
+/* sc_posconv_conv: the grouped conv itself on the matrix cores from an LDS-resident input window (no pack pass, no sliding-window
+ * re-streaming): conv bf16 [B][G][Tp][D/G].  Returns 1 without doing anything when D/G is not 32/48/64 (caller: pack + batched GEMM). */
+int sc_posconv_conv(const void* x, const int32_t* valid, const void* wg, void* conv, int B, int Tp, int D, int G, int Kw, void* stream);
 int sc_posconv_pack(const void* x, const int32_t* valid, void* xg, int B, int Tp, int D, int G, int Kw, void* stream);
 int sc_posconv_finish(const void* x, const int32_t* valid, const void* conv, const float* bias, const float* gamma, const float* beta,
                       void* out, int B, int Tp, int D, int G, int out_f32, float eps, void* stream);

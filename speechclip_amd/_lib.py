@@ -53,6 +53,7 @@ def _declare(L):
         "sc_conv0_gn_coef": ([P, L64, P, P, P, P, P, I, I, I, F, P], c_int),
         "sc_conv0_wfrag_workspace_bytes": ([I], c_int64),
         "sc_conv0_fwd": ([P, L64, L64, P, P, P, P, I, I, I, I, I, P, P], c_int),
+        "sc_posconv_conv": ([P, P, P, P, I, I, I, I, I, P], c_int),
         "sc_posconv_pack": ([P, P, P, I, I, I, I, I, P], c_int),
         "sc_posconv_finish": ([P, P, P, P, P, P, P, I, I, I, I, I, F, P], c_int),
         "sc_crop_pad": ([P, L64, P, P, P, I, I, P], c_int),

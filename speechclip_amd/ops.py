@@ -172,10 +172,14 @@ def posconv(x, valid_i32, wg, bias, gamma, beta, B, Tp, D, G, Kw, out=None, out_
     """x bf16 [B*Tp, D]; wg bf16 [G, D/G, Kw*D/G] (folded weight-norm, K index = tap*cg + c_in)."""
     _need_cuda(x, wg)
     cg = D // G
-    xg = torch.empty(B * G * (Tp + Kw) * cg + 64, device=x.device, dtype=bf16)
-    check(lib().sc_posconv_pack(ptr(x), ptr(valid_i32), ptr(xg), B, Tp, D, G, Kw, stream()), "sc_posconv_pack")
     conv = torch.empty(B * G * Tp * cg, device=x.device, dtype=bf16)
-    gemm_batched(xg, cg, (Tp + Kw) * cg, wg, cg * Kw * cg, G, conv, cg, Tp * cg, None, Tp, cg, Kw * cg, B * G)
+    rc = lib().sc_posconv_conv(ptr(x), ptr(valid_i32), ptr(wg), ptr(conv), B, Tp, D, G, Kw, stream())
+    if rc == 1:      # group width not covered by the windowed kernel: pack the sliding windows and use the batched GEMM
+        xg = torch.empty(B * G * (Tp + Kw) * cg + 64, device=x.device, dtype=bf16)
+        check(lib().sc_posconv_pack(ptr(x), ptr(valid_i32), ptr(xg), B, Tp, D, G, Kw, stream()), "sc_posconv_pack")
+        gemm_batched(xg, cg, (Tp + Kw) * cg, wg, cg * Kw * cg, G, conv, cg, Tp * cg, None, Tp, cg, Kw * cg, B * G)
+    else:
+        check(rc, "sc_posconv_conv")
     if out is None:
         out = torch.empty(B * Tp, D, device=x.device, dtype=torch.float32 if out_f32 else bf16)
     check(lib().sc_posconv_finish(ptr(x), ptr(valid_i32), ptr(conv), ptr(bias), ptr(gamma), ptr(beta), ptr(out), B, Tp, D, G,
