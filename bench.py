@@ -54,7 +54,8 @@ def algorithmic_gflop_per_pair(L=160000, d=768, ffn=3072, layers=12, vit_w=768, 
     # (score = x.u_r, value projection of 8 pooled vectors), so its K/V GEMM over all frames (1.18 GF/pair) is NOT executed and
     # is not credited to the kernel: 8 score columns + per-head value projection + out_proj + FFN + final projection.
     branch_gemm = 2 * T * d * 8 + 2 * d * d + 2 * (d * d + 2 * d * ffn) + 2 * d * E
-    gemm = cnn + proj + pos + lin + vit_lin + branch_gemm
+    # The grouped positional conv (`pos`, 4.7 GF/pair) runs in its own windowed MFMA kernel (csrc/posconv.hip), not in the GEMM kernel: not credited.
+    gemm = cnn + proj + lin + vit_lin + branch_gemm
     return total / 1e9, gemm / 1e9
 
 
