@@ -175,7 +175,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     pairs_per_s = world * B * args.steps / dt
-    total_gf, gemm_gf = algorithmic_gflop_per_pair(L)
+    # train mode crops every utterance to audio_encoder.max_audio_len (102400 samples, T = 319) exactly as the reference trains
+    mal = int(getattr(model.audio_encoder, "max_audio_len", -1))
+    L_eff = min(L, mal) if (args.train and mal > 0) else L
+    total_gf, gemm_gf = algorithmic_gflop_per_pair(L_eff)
     if rank == 0:
         roof = None
         if prof:
@@ -191,7 +194,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "Parallel SpeechCLIP base (HuBERT-base + ViT-B/32) forward + InfoNCE, 10 s/16 kHz audio + 224^2 images",
-                          "pairs_per_gpu": B, "global_batch": world * B, "audio_samples": L, "frames": conv_lens(L)[-1],
+                          "pairs_per_gpu": B, "global_batch": world * B, "audio_samples": L_eff, "frames": conv_lens(L_eff)[-1],
                           "parallelism": f"dp{world}" if world > 1 else "single", "weights": "random-init (no network)",
                           "algorithmic_gflop_per_pair": round(total_gf, 2), "mode": "train (tail: branch + layer-mix weights)" if args.train else "forward + loss"},
                "e2e_tflops_per_gpu": round(total_gf * 1e9 * pairs_per_s / world / 1e12, 1),
