@@ -186,8 +186,16 @@ def main():
             launches = len(prof)
             alg = gemm_gf * 1e9 * B * args.steps               # algorithmic GEMM FLOPs of this rank's launches
             ach = alg / (ms * 1e-3) / 1e12
+            # HBM traffic of the kernel cannot be measured from inside this process (PMC counters need rocprofv3 and their own passes):
+            # report the committed per-launch figure of the same command, with its source, or null if it is not there / not this workload
+            traffic, tsrc = None, None
+            tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
+            if os.path.exists(tf) and not args.train and B == 256 and L == 160000:
+                tj = json.load(open(tf))
+                traffic, tsrc = tj["bytes_per_launch"], tj["source"] + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2)"
             roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all launches of the step)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": launches // args.steps,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                    "launches_per_step": launches // args.steps,
                     "avg_launch_ms": round(ms / launches, 4), "gemm_ms_per_step": round(ms / args.steps, 3),
                     "executed_over_algorithmic": round(sum(e[2] for e in prof) / alg, 4)}
         out = {"metric": "speech-image pairs/sec/node (Parallel SpeechCLIP base)", "value": round(pairs_per_s, 2), "unit": "pairs/s",
