@@ -208,8 +208,8 @@ class KW_ParallelBranch(nn.Module):
             return self._forward_train(audio_feat, audio_len)
         out = self.self_att.forward_cls(self.cls, audio_feat, audio_len)            # bf16 [B, d]
         if hasattr(self, "linear_proj"):
-            out = ops.gemm(out, self.linear_proj.weight.detach().to(torch.bfloat16).contiguous(),
-                           self.linear_proj.bias.detach().float().contiguous(), out_f32=True)
+            out = ops.gemm(out, TransformerModels.cached_cast(self.linear_proj.weight, torch.bfloat16),
+                           TransformerModels.cached_cast(self.linear_proj.bias, torch.float32), out_f32=True)
         return out
 
 
@@ -266,8 +266,8 @@ class KW_CascadedBranch(nn.Module):
                                       "the CLIP text tower) is SURVEY.md section 8f work after the parallel tail; use eval() / no_grad() here")
         B, K = audio_feat.shape[0], self.keyword_num
         kw = self.self_att.forward_cls(self.cls, audio_feat, audio_len)                       # bf16 [B, K, d]
-        kw = ops.gemm(kw.view(B * K, -1), self.linear_proj.weight.detach().to(torch.bfloat16).contiguous(),
-                      self.linear_proj.bias.detach().float().contiguous(), out_f32=True).view(B, K, self.text_dim)
+        kw = ops.gemm(kw.view(B * K, -1), TransformerModels.cached_cast(self.linear_proj.weight, torch.bfloat16),
+                      TransformerModels.cached_cast(self.linear_proj.bias, torch.float32), out_f32=True).view(B, K, self.text_dim)
         if hasattr(self, "bn_layer"):
             kw = self.bn_layer(kw)
         emb = self.clip.model.token_embedding.weight

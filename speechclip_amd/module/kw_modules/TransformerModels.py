@@ -7,6 +7,8 @@
 [CLS ; frames] and then keeps only the CLS rows (kwClip.py:1099, :879); here only the CLS rows are computed
 (`forward_cls`): K/V for all frames, Q / attention / FFN / LayerNorm for the NQ learned tokens only.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -31,6 +33,22 @@ def _frames_view(audio_feat: torch.Tensor):
 
 
 _POOL_CACHE = {}
+_CAST_CACHE = {}
+
+
+def cached_cast(t: torch.Tensor, dtype) -> torch.Tensor:
+    """Detached, contiguous copy of parameter `t` in `dtype`, rebuilt only when the parameter changes (the in-place version counter moves
+    on optimizer steps / load_state_dict): the eval forward does not re-cast the frozen branch weights on every call."""
+    key = (t.data_ptr(), dtype)
+    ver = (t._version, t.device, tuple(t.shape))
+    hit = _CAST_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is t:      # same tensor OBJECT: a freed tensor's address can be reused
+        return hit[1]
+    out = t.detach().to(dtype).contiguous()
+    if len(_CAST_CACHE) > 4096:
+        _CAST_CACHE.clear()
+    _CAST_CACHE[key] = (ver, out, weakref.ref(t))
+    return out
 
 
 def _pool_operands(cls, in_w, in_b, heads):
@@ -39,7 +57,7 @@ def _pool_operands(cls, in_w, in_b, heads):
     key = (cls.data_ptr(), in_w.data_ptr(), in_b.data_ptr(), heads)
     ver = (cls._version, in_w._version, in_b._version, cls.device)
     hit = _POOL_CACHE.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and all(r() is o for r, o in zip(hit[2], (cls, in_w, in_b))):   # object identity, not just addresses
         return hit[1]
     with torch.no_grad():
         NQ, D = cls.shape[-2], cls.shape[-1]
@@ -52,7 +70,9 @@ def _pool_operands(cls, in_w, in_b, heads):
         c16 = c.to(BF)
         ops_ = dict(u16=u.to(BF).contiguous(), beta=beta, cls16=c16.contiguous(), wv=w[2 * D:].to(BF).contiguous(), bv=b[2 * D:].contiguous(),
                     cls_scores=(c16.float() @ u.to(BF).float().t() + beta).contiguous())                    # [NQ, R]
-    _POOL_CACHE[key] = (ver, ops_)
+    if len(_POOL_CACHE) > 256:
+        _POOL_CACHE.clear()
+    _POOL_CACHE[key] = (ver, ops_, tuple(weakref.ref(o) for o in (cls, in_w, in_b)))
     return ops_
 
 
@@ -98,8 +118,8 @@ class TransformerEncoder(nn.Module):
         sa = L.self_attn
         D = cls.shape[-1]
         att = _cls_attention_block(cls, audio_feat, audio_len, sa.in_proj_weight, sa.in_proj_bias, self.nhead)
-        f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
-        w16 = lambda t: t.detach().to(BF).contiguous()   # noqa: E731
+        f32 = lambda t: cached_cast(t, torch.float32)  # noqa: E731
+        w16 = lambda t: cached_cast(t, BF)             # noqa: E731
         y = ops.gemm(att, w16(sa.out_proj.weight), f32(sa.out_proj.bias), residual=f32(cls).reshape(1, D).expand(att.shape[0], D),
                      out_f32=True)                                                       # x + SA(x), CLS rows
         x1 = ops.layernorm(y, f32(L.norm1.weight), f32(L.norm1.bias), self.eps, out_f32=True)
@@ -131,10 +151,9 @@ class MultiheadAttentionAndNorm(nn.Module):
         B = audio_feat.shape[0]
         att = _cls_attention_block(cls, audio_feat, audio_len, m.in_proj_weight, m.in_proj_bias, self.nhead)
         res = cls.detach().float().reshape(1, NQ, D).expand(B, NQ, D).reshape(B * NQ, D).contiguous()
-        y = ops.gemm(att, m.out_proj.weight.detach().to(BF).contiguous(), m.out_proj.bias.detach().float().contiguous(), residual=res,
-                     out_f32=True)
+        y = ops.gemm(att, cached_cast(m.out_proj.weight, BF), cached_cast(m.out_proj.bias, torch.float32), residual=res, out_f32=True)
         n = self.attentionBlock_Norm
-        return ops.layernorm(y, n.weight.detach().float(), n.bias.detach().float(), self.eps).view(B, NQ, D)
+        return ops.layernorm(y, cached_cast(n.weight, torch.float32), cached_cast(n.bias, torch.float32), self.eps).view(B, NQ, D)
 
     def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
         raise NotImplementedError("full-row forward is off the hot path; use forward_cls (KW_CascadedBranch does)")
