@@ -197,9 +197,9 @@ def test_gather_loss_feats_gloo_world2():
     procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=300)
         assert p.exitcode == 0
     (_, out0, loc0, loss0), (_, out1, loc1, loss1) = res
     for k in ("id", "image_feat", "parallel_audio_feat"):
@@ -256,9 +256,9 @@ def test_training_gather_backward_keeps_local_rows_gloo_world2():
     procs = [ctx.Process(target=_train_gather_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=300)
         assert p.exitcode == 0
     A = torch.cat([r[1] for r in res]).requires_grad_(True)
     Bm, ids = torch.cat([r[2] for r in res]), torch.cat([r[3] for r in res])
