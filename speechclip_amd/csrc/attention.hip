@@ -31,6 +31,13 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 // K chunk swizzle (16-B chunk p of key row r holds d-chunk p ^ (r & 7)); V chunk swizzle ((r >> 1) & 3) << 1 keeps the four
 // consecutive key rows touched by one ds_read_b64_tr_b16 group on different bank groups.
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 3) << 1; }
+// K rows: a ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with (row >> 1) & 7 every group sees
+// each swizzle value exactly twice, once on an even and once on an odd row (the two 128-byte bank halves): conflict-free.  (row & 7
+// repeats inside a group on rows of equal parity: 2-way conflicts, measured SQ_LDS_BANK_CONFLICT = 48 % of the LDS cycles.)
+#ifndef SC_ATTN_KSWZ
+#define SC_ATTN_KSWZ 1
+#endif
+__device__ __forceinline__ int swz_k(int row) { return SC_ATTN_KSWZ ? ((row >> 1) & 7) : (row & 7); }
 
 template <int NW>   // waves per block: NW x 32 query rows share one K/V ring (4: 128 rows, 8: 256 rows -- half the K/V traffic, 4 waves per SIMD)
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     const int key0 = tid >> 3, pos = tid & 7;                       // rows key0 (+ 32) of the tile, 16-byte chunk pos
     const bf16_t* kbase = k + row_base * ld_qkv + hoff;
     const bf16_t* vbase = v + row_base * ld_qkv + hoff;
-    const int kchunk0 = (pos ^ (key0 & 7)) << 3, vchunk0 = (pos ^ swz_v(key0)) << 3;          // (key0 + 32) has the same low bits
+    const int kchunk0 = (pos ^ swz_k(key0)) << 3, vchunk0 = (pos ^ swz_v(key0)) << 3;          // (key0 + 32) has the same low bits
     auto stage = [&](int tile, int buf) {
         char* kb = smem + buf * STAGE_BYTES;
 #pragma unroll
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     unsigned ka[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) ka[c] = lds_base + ql * 128 + (((2 * c + g) ^ (ql & 7)) << 4);
+    for (int c = 0; c < 4; ++c) ka[c] = lds_base + ql * 128 + (((2 * c + g) ^ swz_k(ql)) << 4);
     // V^T (ds_read_b64_tr_b16: within a 16-lane group, lane i points at key row i>>2, 4 consecutive d at (i&3)*4, and receives column
     // (i) of the 4 x 16 block, i.e. V[k0..k0+3][d0 + i]): k0 = kb*32 + hb*16 + 4g + v_row_in; rows k0 and k0+8 share their swizzle.
     const int ti = lane & 15;

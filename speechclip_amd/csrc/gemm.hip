@@ -181,7 +181,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 //    (the direct fragment-shaped store is 32 x 8-byte stores per lane touching 16 lines each: issue-bound).
 constexpr int BK2 = 64;
 constexpr int SLOT_BYTES = 2 * 256 * BK2 * 2;  // 64 KiB: A [256][128 B] then B [256][128 B]
-constexpr int EPI_STRIDE = 144;                // bytes per row of the wave-private epilogue image (64 bf16 + 16 B pad)
 
 // Source addressing of one tile: two WAVE-UNIFORM tile base pointers (SGPRs) + two 32-bit per-lane offsets fixed for the whole
 // kernel.  (Per-lane 64-bit pointers kept across the tile were being spilled, and a scratch reload behind freshly issued LDS-DMA
@@ -575,8 +574,11 @@ int launch256(const GemmParams& p, hipStream_t s) {
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     const int ntiles = p.tiles_m * p.tiles_n;
     int grid = ntiles < n_cu ? ntiles : n_cu;
-    if (getenv("SC_GEMM_GRID")) grid = atoi(getenv("SC_GEMM_GRID")) < grid ? atoi(getenv("SC_GEMM_GRID")) : grid;
-    const char* abl = getenv("SC_GEMM_ABL");   // experiment switches: 1 = no LDS-DMA in the main loop, 2 = no MFMA, 3 = no epilogue stores
+    // instrumentation switches, read once: SC_GEMM_GRID caps the number of blocks (per-CU vs chip-wide limits), SC_GEMM_ABL ablates
+    // 1 = the LDS-DMA in the main loop, 2 = the MFMAs, 3 = the epilogue stores (results are garbage; timing only)
+    static const int grid_cap = getenv("SC_GEMM_GRID") ? atoi(getenv("SC_GEMM_GRID")) : 0;
+    static const char* abl = getenv("SC_GEMM_ABL");
+    if (grid_cap > 0 && grid_cap < grid) grid = grid_cap;
     if (p.trace && abl && abl[0] == '3') return launch256_var<3, true>(p, grid, s);
     if (p.trace && abl && abl[0] == '1') return launch256_var<1, true>(p, grid, s);
     if (p.trace && abl && abl[0] == '2') return launch256_var<2, true>(p, grid, s);
@@ -611,7 +613,8 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
     if (batch == 1 && p.N >= 256 && p.M >= 256 && p.K % 64 == 0) {
         const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         static const int min_tiles = getenv("SC_GEMM_MIN_TILES") ? atoi(getenv("SC_GEMM_MIN_TILES")) : 100;
-        if (t256 >= min_tiles && !getenv("SC_GEMM_V1")) {
+        static const bool force_v1 = getenv("SC_GEMM_V1") != nullptr;
+        if (t256 >= min_tiles && !force_v1) {
             p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (p.N + 255) / 256;
             if (p.band < 0) p.band = p.tiles_n >= 16 ? 4 : 0;   // measured: 8192^3 +20 %; N <= 3072 (the step's shapes) neutral
             return launch256(p, s);
@@ -641,10 +644,12 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     p.M = M; p.N = N; p.K = K;
     p.act = flags & SC_GEMM_ACT_MASK; p.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0;
     p.trace = g_gemm_trace;
-    p.rot = getenv("SC_GEMM_NOROT") ? 0 : 1;
-    p.band = getenv("SC_GEMM_BAND") ? atoi(getenv("SC_GEMM_BAND")) : -1;   // -1: chosen by the dispatcher
-    p.epi_mode = getenv("SC_GEMM_EPI") ? atoi(getenv("SC_GEMM_EPI")) : 2;
-    p.epi_mode_res = getenv("SC_GEMM_EPI_RES") ? atoi(getenv("SC_GEMM_EPI_RES")) : 3;
+    // tuning knobs kept for A/B timing (read once); the defaults are the measured best
+    static const int k_rot = getenv("SC_GEMM_NOROT") ? 0 : 1;
+    static const int k_band = getenv("SC_GEMM_BAND") ? atoi(getenv("SC_GEMM_BAND")) : -1;   // -1: chosen by the dispatcher
+    static const int k_epi = getenv("SC_GEMM_EPI") ? atoi(getenv("SC_GEMM_EPI")) : 2;
+    static const int k_epi_res = getenv("SC_GEMM_EPI_RES") ? atoi(getenv("SC_GEMM_EPI_RES")) : 3;
+    p.rot = k_rot; p.band = k_band; p.epi_mode = k_epi; p.epi_mode_res = k_epi_res;
     return gemm_dispatch(p, 1, (hipStream_t)stream);
 }
 
