@@ -266,3 +266,37 @@ def test_training_gather_backward_keeps_local_rows_gloo_world2():
     loss.backward()
     assert abs(res[0][5] - loss.item()) < 1e-6 and abs(res[1][5] - loss.item()) < 1e-6
     assert torch.allclose(torch.cat([r[4] for r in res]), A.grad, atol=1e-6)
+
+
+def test_pretrained_checkpoint_loaders_from_local_files(tmp_path, monkeypatch):
+    """`pretrained: true` loads a fairseq-format HuBERT checkpoint ({"model": state_dict, ...} with the extra
+    pre-training tensors) and an openai-format CLIP state_dict from local files by key name -- no network, no key mapping."""
+    import dataclasses
+    from oracle.clip_ref import ClipRef, ClipRefConfig
+    from oracle.hubert_ref import HubertModelRef, HubertRefConfig
+    from speechclip_amd.module import ClipModel, FairseqSpeechEncoder_Hubert
+    from speechclip_amd.module.clip_model import ClipConfig
+    from speechclip_amd.module.hubert import HubertConfig
+    torch.manual_seed(5)
+    hcfg, ccfg = HubertRefConfig.tiny(), ClipRefConfig.tiny()
+    src = HubertModelRef(hcfg)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    sd.update({"label_embs_concat": torch.randn(504, 256),
+               "final_proj.weight": torch.randn(256, hcfg.encoder_embed_dim), "final_proj.bias": torch.randn(256)})
+    hp = tmp_path / "hubert_tiny.pt"
+    torch.save({"model": sd, "cfg": {"model": {"_name": "hubert"}}, "args": None}, hp)
+    monkeypatch.setenv("SPEECHCLIP_HUBERT_CKPT", str(hp))
+    enc = FairseqSpeechEncoder_Hubert(name="hubert", pretrained=True, feat_select_idx="weighted_sum",
+                                      hubert_config=HubertConfig(**dataclasses.asdict(hcfg)))
+    got = enc.encoder.state_dict()
+    for k, v in src.state_dict().items():
+        assert k in got and torch.equal(got[k], v), k
+    assert all(not p.requires_grad for p in enc.encoder.parameters())
+    csrc = ClipRef(ccfg)
+    cp = tmp_path / "clip_tiny.pt"
+    torch.save(csrc.state_dict(), cp)
+    monkeypatch.setenv("SPEECHCLIP_CLIP_CKPT", str(cp))
+    clip = ClipModel(name="ViT-B/32", device="cpu", clip_config=ClipConfig(**dataclasses.asdict(ccfg)))
+    cgot = clip.model.state_dict()
+    for k, v in csrc.state_dict().items():
+        assert k in cgot and torch.equal(cgot[k].float(), v.float()), k
