@@ -275,3 +275,65 @@ def test_rccl_packed_gather_on_one_gpu():
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_validation_hooks_recall_vs_oracle_pipeline():
+    """Lightning's validation protocol end to end on the device (validation_step -> validation_step_end -> validation_epoch_end ->
+    mutualRetrieval through sc_sgemm + sc_retrieval_ranks) against the oracle's features + argsort-based recall on the same batches:
+    the score matrices must agree closely and recall@K may differ only by candidates whose scores are within that tolerance."""
+    from oracle.speechclip_ref import SpeechClipRef, mutual_retrieval
+    from oracle.clip_ref import ClipRefConfig
+    from oracle.hubert_ref import HubertRefConfig
+    g, model, _ = _load_model("tiny_base_p", False)
+    ref = SpeechClipRef(HubertRefConfig.tiny(), ClipRefConfig.tiny(), parallel=True, branch_heads=4).eval()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref.encoder.load_state_dict({k[len("audio_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("audio_encoder.encoder.")})
+    ref.clip.load_state_dict({k[len("clip.model."):]: v for k, v in sd.items() if k.startswith("clip.model.")})
+    ref.parallel_branch.load_state_dict({k[len("parallel_branch."):]: v for k, v in sd.items() if k.startswith("parallel_branch.")})
+    with torch.no_grad():
+        ref.ws_weights.copy_(sd["audio_encoder.weightedsum_layer.weights"])
+    gen = torch.Generator().manual_seed(31)
+    res = ClipRefConfig.tiny().image_resolution
+    n_img, cap = 6, 2
+    images = torch.randn(n_img, 3, res, res, generator=gen)
+    batches, oa, oi, oid = [], [], [], []
+    for bi in range(3):                                   # 3 batches x 4 captions; image j is paired with captions 2j, 2j+1
+        ids = torch.tensor([(bi * 4 + k) // cap for k in range(4)])
+        lens = [int(x) for x in torch.randint(3000, 8000, (4,), generator=gen)]
+        wav = torch.zeros(4, max(lens))
+        for i, l in enumerate(lens):
+            wav[i, :l] = 0.3 * torch.randn(l, generator=gen)
+        b = {"wav": wav, "wav_len": torch.tensor(lens), "image": images[ids], "id": ids}
+        batches.append(b)
+        o = ref(b)
+        oa.append(o["parallel_audio_feat"]); oi.append(o["image_feat"]); oid.append(ids)
+    outs = []
+    with torch.no_grad():
+        for i, b in enumerate(batches):
+            outs.append(model.validation_step_end(model.validation_step({k: v.cuda() for k, v in b.items()}, i)))
+        r_ab, r_ba, r_mean = model.validation_epoch_end(outs)
+    # oracle pipeline (dedupe images by id exactly as validation_epoch_end does: last occurrence wins, first-seen order)
+    all_ids = torch.cat(oid); all_img = torch.cat(oi); all_aud = torch.cat(oa)
+    first = {}
+    for i, _id in enumerate(all_ids.tolist()):
+        first[_id] = i
+    img_ids = torch.tensor(list(first.keys()))
+    img_f = all_img[torch.tensor(list(first.values()))]
+    score_ref = all_aud @ img_f.t()
+    o_ab, o_ba, o_mean = mutual_retrieval(score_ref, score_ref.t().contiguous(), all_ids, img_ids, [1, 5, 10])
+    # device scores recomputed from the hook outputs for the comparison of the matrices themselves
+    aud_d = torch.cat([x["audio_feat"] for x in outs]).float()
+    img_d = torch.cat([x["image_feat"] for x in outs]).float()[torch.tensor(list(first.values()))]
+    score_dev = aud_d @ img_d.t()
+    tol = (score_dev - score_ref).abs().max().item()
+    assert tol < 2e-2, tol
+    n_a, n_i = score_ref.shape
+    for k in ("recall@1", "recall@5", "recall@10"):
+        # a rank can only move if two candidates are closer than 2 * tol: bound the number of queries that may flip
+        srt = torch.sort(score_ref, dim=1, descending=True).values
+        flips_ab = ((srt[:, :-1] - srt[:, 1:]) < 2 * tol).any(dim=1).float().sum().item()
+        srt_b = torch.sort(score_ref.t(), dim=1, descending=True).values
+        flips_ba = ((srt_b[:, :-1] - srt_b[:, 1:]) < 2 * tol).any(dim=1).float().sum().item()
+        assert abs(r_ab[k] - o_ab[k]) <= 100.0 * flips_ab / n_a + 1e-4, (k, r_ab[k], o_ab[k], flips_ab)
+        assert abs(r_ba[k] - o_ba[k]) <= 100.0 * flips_ba / n_i + 1e-4, (k, r_ba[k], o_ba[k], flips_ba)
+    assert r_ab["recall@10"] == 100.0 and r_ba["recall@10"] == 100.0       # 6 images: everything is in the top 10
