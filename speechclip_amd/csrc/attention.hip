@@ -39,23 +39,33 @@ __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 3) << 1; }
 #endif
 __device__ __forceinline__ int swz_k(int row) { return SC_ATTN_KSWZ ? ((row >> 1) & 7) : (row & 7); }
 
-template <int NW>   // waves per block: NW x 32 query rows share one K/V ring (4: 128 rows, 8: 256 rows -- half the K/V traffic, 4 waves per SIMD)
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__device__ unsigned long long* g_attn_trace = nullptr;   // debug: per-block phase cycles (sc_debug_set_attn_trace)
+
+template <int NW, bool TRACE>   // waves per block: NW x 32 query rows share one K/V ring (4: 128 rows, 8: 256 rows -- half the K/V traffic, 4 waves per SIMD)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
                                                        const int32_t* __restrict__ klens, int T, int64_t ld_qkv,
-                                                       int64_t ld_out, float scale_log2e, int causal, int B, int H, int nq) {
+                                                       int64_t ld_out, float scale_log2e, int causal, int B, int H, int nq, int n_ids, int ipb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NSTAGE x (K 8 KiB + V 8 KiB)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware 1-D grid: blocks id, id+8, id+16.. share an XCD (and its L2); the nq query blocks of one (b, h) unit are made
     // consecutive on ONE XCD so K/V (128 KB per unit) is fetched from HBM once instead of once per query block.
-    const int id = blockIdx.x;
+    // A block can walk `ipb` ids (same XCD: ids bid%8 + 8*(...)).  tools/attn_trace.py shows ~25 % of the resident slots empty at any time
+    // with one id per block, but chaining ids inside a block (ipb 2..12, or fully persistent blocks) measured 4-6 % SLOWER: the empty
+    // time is the per-id prologue (Q load, first two K/V stages) + epilogue, which a fresh block overlaps with its neighbours just as
+    // well.  ipb = 1 by default; SC_ATTN_IPB is kept for that experiment.
+    for (int it = 0; it < ipb; ++it) {
+    const int id = (blockIdx.x >> 3) * (8 * ipb) + it * 8 + (blockIdx.x & 7);
+    if (id >= n_ids) break;
     const int unit = ((id >> 3) / nq) * 8 + (id & 7);
     const int qblk = (id >> 3) % nq;
-    if (unit >= H * B) return;
+    if (unit >= H * B) continue;
     const int b = unit / H, h = unit - b * H;
-    const int g = lane >> 5, ql = lane & 31;
+    int lane_i = lane;
+    asm volatile("" : "+v"(lane_i));        // per-id recomputation of the lane geometry: keeps the id loop's invariants out of VGPRs held across it
+    const int g = lane_i >> 5, ql = lane_i & 31;
     const int64_t row_base = (int64_t)b * T;
     const int hoff = h * 64;
 
@@ -79,7 +89,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     // K and V tiles both arrive by LDS-DMA (no VGPR staging): 2 + 2 instructions per thread per tile.  Source addressing is kept
     // cheap: a 64-bit per-thread base (row 0 of the unit, this thread's key row / chunk) + a 32-bit row offset per tile.
     constexpr int NLD = 512 / (NW * 64);                            // row groups per thread per operand: 2 (NW = 4) or 1 (NW = 8)
-    const int key0 = tid >> 3, pos = tid & 7;                       // rows key0 (+ 32) of the tile, 16-byte chunk pos
+    int tid_i = tid;
+    asm volatile("" : "+v"(tid_i));
+    const int key0 = tid_i >> 3, pos = tid_i & 7;                   // rows key0 (+ 32) of the tile, 16-byte chunk pos
     const bf16_t* kbase = k + row_base * ld_qkv + hoff;
     const bf16_t* vbase = v + row_base * ld_qkv + hoff;
     const int kchunk0 = (pos ^ swz_k(key0)) << 3, vchunk0 = (pos ^ swz_v(key0)) << 3;          // (key0 + 32) has the same low bits
@@ -113,9 +125,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     for (int c = 0; c < 4; ++c) ka[c] = lds_base + ql * 128 + (((2 * c + g) ^ swz_k(ql)) << 4);
     // V^T (ds_read_b64_tr_b16: within a 16-lane group, lane i points at key row i>>2, 4 consecutive d at (i&3)*4, and receives column
     // (i) of the 4 x 16 block, i.e. V[k0..k0+3][d0 + i]): k0 = kb*32 + hb*16 + 4g + v_row_in; rows k0 and k0+8 share their swizzle.
-    const int ti = lane & 15;
+    const int ti = lane_i & 15;
     const int v_row_in = ti >> 2;                                  // key row within the group of 4
-    const int v_chunk_in = (((lane >> 4) & 1) << 1) + ((ti & 3) >> 1);   // 16-B chunk within the 64-B d-block
+    const int v_chunk_in = (((lane_i >> 4) & 1) << 1) + ((ti & 3) >> 1);   // 16-B chunk within the 64-B d-block
     const int v_byte_in = (ti & 1) * 8;
     const int vk0 = 4 * g + v_row_in;
     unsigned va[2];
@@ -132,36 +144,44 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     // One KV tile; SLOT (ring slot of tile j) is a compile-time constant so every LDS address is lane part + immediate.
     // All LDS reads are inline asm with hand-counted lgkmcnt: for a builtin / plain load the compiler cannot prove that the read does
     // not alias the LDS-DMA writes in flight and guards it with s_waitcnt vmcnt(0), which would drain the prefetch of tile j+2.
+    unsigned long long* const trace = TRACE ? g_attn_trace : nullptr;
+    unsigned long long tr_qk = 0, tr_sm = 0, tr_pv = 0, tr_bar = 0, tr_t = TRACE ? __builtin_readcyclecounter() : 0;
+    const unsigned long long tr_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, chip-wide
+    auto stamp = [&](unsigned long long& acc_) { if (TRACE) { const unsigned long long t = __builtin_readcyclecounter(); acc_ += t - tr_t; tr_t = t; } };
     auto tile_body = [&](int j, auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
         if (j + 2 < nkv) stage(j + 2, (SLOT + 2) % NSTAGE);   // that buffer held tile j-1: every wave passed the barrier after reading it
         // ---- S^T = K . Q^T : all 8 K fragments are requested up front, the MFMAs then run back to back
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-        u32x4_t kf[2][4];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-            {
-                const unsigned addr = ka[c];
-                u32x4_t t;
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(addr), "i"(SLOT * STAGE_BYTES + kb * 4096));
-                kf[kb][c] = t;
-            }
+        // 6 of the 8 K fragments are requested up front, the last two once the first two MFMAs have consumed theirs (their registers are
+        // free again): 24 instead of 32 VGPRs at the peak of the kernel's register pressure -- what keeps it at <= 128 with the
+        // persistent-block loop around it.  lgkmcnt bookkeeping: R0..R5 out -> wait 5,4 -> R6,R7 out -> wait 5,4,3,2,1,0.
         f32x16_t s[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (kb == 0) { if (c == 0) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); else if (c == 1) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); else if (c == 2) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
-                else { if (c == 0) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); else if (c == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); else if (c == 2) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-                u32x4_t t = kf[kb][c];
-                asm volatile("" : "+v"(t));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, t), qf[c], s[kb], 0, 0, 0);
-            }
+        for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
+        auto kread = [&](int kb, int c) -> u32x4_t {
+            const unsigned addr = ka[c];
+            u32x4_t t;
+            if (kb == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(addr), "i"(SLOT * STAGE_BYTES));
+            else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(addr), "i"(SLOT * STAGE_BYTES + 4096));
+            return t;
+        };
+        auto kmma = [&](int kb, int c, u32x4_t t) {
+            asm volatile("" : "+v"(t));
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, t), qf[c], s[kb], 0, 0, 0);
+        };
+        {
+            u32x4_t k00 = kread(0, 0), k01 = kread(0, 1), k02 = kread(0, 2), k03 = kread(0, 3), k10 = kread(1, 0), k11 = kread(1, 1);
+            asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); kmma(0, 0, k00);
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); kmma(0, 1, k01);
+            u32x4_t k12 = kread(1, 2), k13 = kread(1, 3);
+            asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); kmma(0, 2, k02);
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); kmma(0, 3, k03);
+            asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); kmma(1, 0, k10);
+            asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); kmma(1, 1, k11);
+            asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); kmma(1, 2, k12);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); kmma(1, 3, k13);
         }
 #if !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2)   // perf probe 2: no softmax arithmetic at all (MFMA + LDS + DMA skeleton)
         // ---- mask + online softmax (log2 domain).  Only a tile that crosses the key length (or the causal diagonal)
@@ -188,10 +208,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
             mx *= scale_log2e;   // scale > 0: max commutes with the scaling
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        asm volatile("" :: "v"(mx));   // phase boundary (also keeps the scheduler from interleaving the phases into a register-pressure peak)
+        if (TRACE) stamp(tr_qk);           // S complete (the max depends on every MFMA result)
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
         m_run = m_new;
         f32x2_t psum2 = {0.f, 0.f};
+        unsigned ppk[2][8];
         const float sc = partial ? 1.0f : scale_log2e;               // partial tiles were scaled while masking
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -203,7 +226,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
 #else
                 const f32x2_t p2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
 #endif
-                s[kb][r] = p2[0]; s[kb][r + 1] = p2[1];
+                ppk[kb][r >> 1] = pack2bf(p2[0], p2[1]);       // P leaves the fp32 registers right here: 16 VGPRs instead of 32 through the PV phase
                 psum2 += p2;
             }
         l_run = l_run * alpha + (psum2[0] + psum2[1]);
@@ -229,9 +252,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
         auto pv = [&](auto c4c, bool more) {
             constexpr int c4 = decltype(c4c)::value;
             constexpr int kb = c4 >> 1, hb = c4 & 1;
-            bf16x8_t pf;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)s[kb][hb * 8 + jj];
+            const u32x4_t pfu = {ppk[kb][hb * 4 + 0], ppk[kb][hb * 4 + 1], ppk[kb][hb * 4 + 2], ppk[kb][hb * 4 + 3]};
+            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pfu);
             if (more) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -242,6 +264,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, both), pf, o[db], 0, 0, 0);
             }
         };
+        asm volatile("" :: "v"(l_run));
+        if (TRACE) stamp(tr_sm);
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // none of the compiler's own LDS traffic (the shuffle) outstanding
@@ -251,9 +275,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
         issue_v(I3{}); pv(I2{}, true);
         pv(I3{}, false);
         // tile j+1 must have landed before anyone reads it; tile j+2 (just issued) stays in flight across the barrier
+        asm volatile("" :: "v"(o[0][0]), "v"(o[1][0]));
+        if (TRACE) stamp(tr_pv);
         wait_stage(j + 2 < nkv);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        stamp(tr_bar);
     };
     for (int j = 0; j < nkv; j += 3) {
         tile_body(j, std::integral_constant<int, 0>{});
@@ -261,6 +288,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
         if (j + 2 < nkv) tile_body(j + 2, std::integral_constant<int, 2>{});
     }
 
+    if (TRACE && trace && tid == 0) {
+        unsigned long long* tr = trace + (size_t)id * 8;
+        tr[0] = tr_qk; tr[1] = tr_sm; tr[2] = tr_pv; tr[3] = tr_bar; tr[4] = nkv; tr[5] = tr_start; tr[6] = __builtin_amdgcn_s_memrealtime();
+    }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qrow < T) {
@@ -275,6 +306,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
                 *(uint2*)(orow + db * 32 + rq * 8 + g * 4) = p;
             }
     }
+    }   // id loop (every wave passed the last tile's barrier: the ring is free for the next id)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -447,6 +479,13 @@ __global__ __launch_bounds__(256) void cls_pool_kernel(const bf16_t* __restrict_
 
 }  // namespace
 
+static bool g_attn_trace_host = false;
+extern "C" void sc_debug_set_attn_trace(void* dev_buf) {     // per-block [8] u64: QK / softmax / PV / wait cycles, tiles, start, end (100 MHz)
+    unsigned long long* p = (unsigned long long*)dev_buf;
+    g_attn_trace_host = dev_buf != nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &p, sizeof(p));
+}
+
 extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H,
                                 int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, int causal, void* stream) {
     SC_CHECK_ARG(head_dim == 64, "sc_attention_fwd: head_dim=%d unsupported (64 only; use sc_cls_attention_fwd for pooling heads)", head_dim);
@@ -461,16 +500,22 @@ extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, voi
     const int nq = (T + rows - 1) / rows;
     const int64_t units8 = ((int64_t)H * B + 7) / 8;
     SC_CHECK_ARG(units8 * 8 * nq < 0x7fffffff, "sc_attention_fwd: grid too large");
-    dim3 grid((unsigned)(units8 * 8 * nq));
-    if (nw == 8) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                           (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq);
-    } else {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                           (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq);
-    }
+    const int n_ids = (int)(units8 * 8 * nq);
+    static const int ipb_env = getenv("SC_ATTN_IPB") ? atoi(getenv("SC_ATTN_IPB")) : 0;
+    int ipb = ipb_env > 0 ? ipb_env : 1;
+    ipb = ipb < 1 ? 1 : (ipb > 16 ? 16 : ipb);
+    const int groups8 = (n_ids / 8 + ipb - 1) / ipb;           // n_ids is a multiple of 8
+    dim3 grid((unsigned)(groups8 * 8));
+#define ATTN_LAUNCH(NW_, TR_)                                                                                                               \
+    do {                                                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NW_, TR_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                 \
+        hipLaunchKernelGGL((attn_fwd_kernel<NW_, TR_>), grid, dim3(NW_ * 64), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, \
+                           (const bf16_t*)v, (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq, n_ids, ipb); \
+    } while (0)
+    if (g_attn_trace_host) { if (nw == 8) ATTN_LAUNCH(8, true); else ATTN_LAUNCH(4, true); }
+    else if (nw == 8) ATTN_LAUNCH(8, false);
+    else ATTN_LAUNCH(4, false);
+#undef ATTN_LAUNCH
     SC_CHECK_LAUNCH();
     return 0;
 }
