@@ -183,7 +183,8 @@ def _gather_worker(rank, world, port, q):
     out = parallel.gather_loss_feats(feats)
     loss = masked_contrastive_loss(torch.nn.functional.normalize(out["parallel_audio_feat"], dim=-1),
                                    torch.nn.functional.normalize(out["image_feat"], dim=-1), out["id"]).item()
-    q.put((rank, {k: v.clone() for k, v in out.items()}, {k: v.clone() for k, v in feats.items()}, loss))
+    # numpy payloads: pickled by value (torch tensors travel as shared-memory handles that die with this process)
+    q.put((rank, {k: v.numpy().copy() for k, v in out.items()}, {k: v.numpy().copy() for k, v in feats.items()}, loss))
     dist.destroy_process_group()
 
 
@@ -202,6 +203,7 @@ def test_gather_loss_feats_gloo_world2():
         p.join(timeout=300)
         assert p.exitcode == 0
     (_, out0, loc0, loss0), (_, out1, loc1, loss1) = res
+    out0, out1, loc0, loc1 = [{k: torch.from_numpy(v) for k, v in d.items()} for d in (out0, out1, loc0, loc1)]
     for k in ("id", "image_feat", "parallel_audio_feat"):
         assert torch.equal(out0[k], out1[k])
         assert torch.equal(out0[k], torch.cat([loc0[k], loc1[k]], 0))
@@ -241,7 +243,7 @@ def _train_gather_worker(rank, world, port, q):
     out = gather_loss_feats_train(feats)
     loss = masked_contrastive_loss(out["parallel_audio_feat"], out["image_feat"], out["id"])
     loss.backward()
-    q.put((rank, a.detach().clone(), feats["image_feat"].clone(), feats["id"].clone(), a.grad.clone(), loss.item()))
+    q.put((rank, a.detach().numpy().copy(), feats["image_feat"].numpy().copy(), feats["id"].numpy().copy(), a.grad.numpy().copy(), loss.item()))
     dist.destroy_process_group()
 
 
@@ -260,6 +262,7 @@ def test_training_gather_backward_keeps_local_rows_gloo_world2():
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
+    res = [tuple(torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in r) for r in res]
     A = torch.cat([r[1] for r in res]).requires_grad_(True)
     Bm, ids = torch.cat([r[2] for r in res]), torch.cat([r[3] for r in res])
     loss = masked_contrastive_loss(A, Bm, ids)
