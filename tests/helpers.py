@@ -33,7 +33,7 @@ def make_config(d_model=768, branch_heads=8, parallel=True, cascaded=False, hube
                           "normalize_hiddenstates": normalize_hiddenstates,
                           "optim": {"name": "Adam", "args": {"lr": 1e-4, "weight_decay": 1e-6}},
                           "scheduler": {"name": "linear_warmup_decay", "warmup": 5000, "max_step": 50000, "final_lr": 1e-8}},
-        "trainer": {"max_steps": 50000, "precision": 16},
+        "trainer": {"max_steps": 50000, "gradient_clip_val": 4, "precision": 16},
         "log_setting": {"log_detokenize_results": False},
     }
     if hubert_config is not None:
