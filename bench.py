@@ -206,7 +206,7 @@ def main():
             if os.path.exists(tf) and not args.train and not large and B == 256 and L == 160000:
                 tj = json.load(open(tf))
                 traffic, tsrc = tj["bytes_per_launch"], tj["source"] + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2)"
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all launches of the step)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+            roof = {"bound": "mfma", "kernel": "sc_gemm_bf16 entry (all launches of the step): gemm256_kernel for fused epilogues / overlapping rows, hipBLASLt for the plain QKV / out-proj / fc2 GEMMs", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                     "launches_per_step": launches // args.steps,
                     "avg_launch_ms": round(ms / launches, 4), "gemm_ms_per_step": round(ms / args.steps, 3),

@@ -40,6 +40,7 @@ def _declare(L):
     P, I, L64, F, U32 = c_void_p, c_int, c_int64, c_float, c_uint32
     sigs = {
         "sc_abi_version": ([], c_int),
+        "sc_set_gemm_workspace": ([P, L64], c_int),
         "sc_gemm_bf16": ([P, L64, P, L64, P, L64, P, P, L64, L64, I, I, I, P], c_int),
         "sc_gemm_bf16_batched": ([P, L64, L64, P, L64, L64, I, P, L64, L64, P, L64, I, I, I, I, P], c_int),
         "sc_layernorm": ([P, L64, P, P, P, L64, L64, I, F, I, P], c_int),

@@ -16,6 +16,17 @@ bf16 = torch.bfloat16
 # sc_gemm_bf16 launch appends (start_event, end_event, flops, shape_tag) recorded on the launch stream.
 PROFILE = None
 
+_GEMM_WS = {}
+
+
+def _ensure_gemm_workspace(dev):
+    """One 64 MiB scratch buffer per process (one process per GPU) for the plain-GEMM library path (sc_set_gemm_workspace)."""
+    if dev not in _GEMM_WS:
+        ws = torch.empty(64 << 20, device=dev, dtype=torch.uint8)
+        check(lib().sc_set_gemm_workspace(ptr(ws), ws.numel()), "sc_set_gemm_workspace")
+        _GEMM_WS.clear()          # the library keeps ONE registration: a process that hops devices re-registers
+        _GEMM_WS[dev] = ws
+
 
 def _need_cuda(*ts):
     for t in ts:
@@ -44,6 +55,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    _ensure_gemm_workspace(a.device)
     check(lib().sc_gemm_bf16(ptr(a), lda, ptr(w), w.stride(0), ptr(out), out.stride(-2), ptr(bias), ptr(residual),
                              residual.stride(-2) if residual is not None else 0, M, N, K, flags, stream()), "sc_gemm_bf16")
     if PROFILE is not None:
