@@ -631,7 +631,7 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
 }  // namespace
 
 int sc_vendor_gemm_try(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* residual,
-                       int64_t ldr, int64_t M, int N, int K, hipStream_t s);   // vendor_gemm.hip
+                       int64_t ldr, int64_t M, int N, int K, int out_f32, hipStream_t s);   // vendor_gemm.hip
 
 static unsigned long long* g_gemm_trace = nullptr;
 extern "C" void sc_debug_set_gemm_trace(void* dev_buf) { g_gemm_trace = (unsigned long long*)dev_buf; }
@@ -639,9 +639,9 @@ extern "C" void sc_debug_set_gemm_trace(void* dev_buf) { g_gemm_trace = (unsigne
 extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                             const float* bias, const void* residual, int64_t ldr, int64_t M, int N, int K,
                             int flags, void* stream) {
-    if ((flags & (SC_GEMM_ACT_MASK | SC_GEMM_OUT_F32)) == 0 && lda >= K && !g_gemm_trace && A && W && C && M > 0 && N > 0 && K > 0 && K % 64 == 0) {
-        // plain bf16 GEMM (+ bias, + residual): the vendor library's kernel when a workspace is registered (vendor_gemm.hip)
-        const int rc = sc_vendor_gemm_try(A, lda, W, ldw, C, ldc, bias, residual, ldr, M, N, K, (hipStream_t)stream);
+    if ((flags & SC_GEMM_ACT_MASK) == 0 && lda >= K && !g_gemm_trace && A && W && C && M > 0 && N > 0 && K > 0 && K % 64 == 0) {
+        // plain GEMM (+ bias, + residual; bf16 or fp32 out): the vendor library's kernel when a workspace is registered (vendor_gemm.hip)
+        const int rc = sc_vendor_gemm_try(A, lda, W, ldw, C, ldc, bias, residual, ldr, M, N, K, (flags & SC_GEMM_OUT_F32) ? 1 : 0, (hipStream_t)stream);
         if (rc <= 0) return rc;
     }
     GemmParams p{};

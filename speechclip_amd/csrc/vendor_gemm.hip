@@ -25,9 +25,10 @@ hipblasLtHandle_t g_handle = nullptr;
 void* g_ws = nullptr;
 size_t g_ws_bytes = 0;
 std::mutex g_mu;
-std::map<std::tuple<int64_t, int, int, int64_t, int64_t, int64_t, int>, Plan> g_plans;
+std::map<std::tuple<int64_t, int, int, int64_t, int64_t, int64_t, int, int>, Plan> g_plans;
 
-bool build_plan(Plan& p, int64_t M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, bool has_res) {
+bool build_plan(Plan& p, int64_t M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, bool has_res, bool out_f32) {
+    const hipDataType ct = out_f32 ? HIP_R_32F : HIP_R_16BF;   // C (residual) and D (output) share the type, as in sc_gemm_bf16
     // Row-major C[M,N] = A[M,K] . W[N,K]^T   <=>   column-major C^T[N,M] = op_T(W_cm[K,N]) . A_cm[K,M]
     if (hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return false;
     const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
@@ -39,8 +40,8 @@ bool build_plan(Plan& p, int64_t M, int N, int K, int64_t lda, int64_t ldc, int6
     hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
     if (hipblasLtMatrixLayoutCreate(&p.la, HIP_R_16BF, K, N, K) != HIPBLAS_STATUS_SUCCESS) return false;       // W as [K, N] col-major, ld = K
     if (hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_16BF, K, M, lda) != HIPBLAS_STATUS_SUCCESS) return false;     // A as [K, M] col-major, ld = lda
-    if (hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_16BF, N, M, has_res ? ldr : ldc) != HIPBLAS_STATUS_SUCCESS) return false;
-    if (hipblasLtMatrixLayoutCreate(&p.ld, HIP_R_16BF, N, M, ldc) != HIPBLAS_STATUS_SUCCESS) return false;
+    if (hipblasLtMatrixLayoutCreate(&p.lc, ct, N, M, has_res ? ldr : ldc) != HIPBLAS_STATUS_SUCCESS) return false;
+    if (hipblasLtMatrixLayoutCreate(&p.ld, ct, N, M, ldc) != HIPBLAS_STATUS_SUCCESS) return false;
     hipblasLtMatmulPreference_t pref;
     if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return false;
     const uint64_t maxws = g_ws_bytes;
@@ -68,16 +69,16 @@ extern "C" int sc_set_gemm_workspace(void* ws, int64_t bytes) {
 
 // returns 0 done, 1 not applicable (caller uses its own kernel), < 0 error
 int sc_vendor_gemm_try(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* residual,
-                       int64_t ldr, int64_t M, int N, int K, hipStream_t s) {
+                       int64_t ldr, int64_t M, int N, int K, int out_f32, hipStream_t s) {
     static const bool disabled = getenv("SC_GEMM_NO_VENDOR") != nullptr;
     if (disabled || !g_ws || !bias || ldw != K || M < 8192 || N < 256 || K < 256) return 1;
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) { g_handle = nullptr; return 1; }
-    const auto key = std::make_tuple(M, N, K, lda, ldc, residual ? ldr : (int64_t)-1, residual ? 1 : 0);
+    const auto key = std::make_tuple(M, N, K, lda, ldc, residual ? ldr : (int64_t)-1, residual ? 1 : 0, out_f32);
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
         Plan p;
-        p.ok = build_plan(p, M, N, K, lda, ldc, ldr, residual != nullptr);
+        p.ok = build_plan(p, M, N, K, lda, ldc, ldr, residual != nullptr, out_f32 != 0);
         it = g_plans.emplace(key, p).first;
     }
     Plan& p = it->second;
