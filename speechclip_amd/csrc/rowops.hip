@@ -153,6 +153,54 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const bf16_t* __restr
     }
 }
 
+// Fast path for the HuBERT-large feature extractor (extractor_mode = layer_norm: LayerNorm over the 512 channels + GELU after every conv,
+// 8.3 GB per 64-utterance step): D = 512 bf16 -> bf16, a row is exactly one 16-byte chunk per lane; a wave owns four consecutive rows and
+// issues their loads up front.
+template <bool GELU>
+__global__ __launch_bounds__(256) void layernorm512_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           bf16_t* __restrict__ out, int64_t rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (row0 >= rows) return;
+    uint4 u[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+        u[r] = *(const uint4*)(x + row * 512 + lane * 8);
+    }
+    const f32x4_t g0 = *(const f32x4_t*)(gamma + lane * 8), g1 = *(const f32x4_t*)(gamma + lane * 8 + 4);
+    const f32x4_t b0 = *(const f32x4_t*)(beta + lane * 8), b1 = *(const f32x4_t*)(beta + lane * 8 + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (row0 + r >= rows) break;
+        float v[8] = {lo2f(u[r].x), hi2f(u[r].x), lo2f(u[r].y), hi2f(u[r].y), lo2f(u[r].z), hi2f(u[r].z), lo2f(u[r].w), hi2f(u[r].w)};
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += v[k];
+        const float mean = wave_sum(t) * (1.0f / 512.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[k] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / 512.0f) + eps);
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[k] = (v[k] - mean) * rstd * g0[k] + b0[k];
+            o[4 + k] = (v[4 + k] - mean) * rstd * g1[k] + b1[k];
+        }
+        if (GELU) {
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const f32x2_t y = gelu_poly2((f32x2_t){o[k], o[k + 1]});
+                o[k] = y[0]; o[k + 1] = y[1];
+            }
+        }
+        uint4 w;
+        w.x = pack2bf(o[0], o[1]); w.y = pack2bf(o[2], o[3]); w.z = pack2bf(o[4], o[5]); w.w = pack2bf(o[6], o[7]);
+        *(uint4*)(out + (row0 + r) * 512 + lane * 8) = w;
+    }
+}
+
 // out[m,:] = sum_i softmax(w)_i * (normalize ? LN_noaffine(h_i[m,:]) : h_i[m,:])
 template <bool IN_F32>
 __global__ __launch_bounds__(256) void weighted_sum_kernel(const void* __restrict__ hidden, int64_t layer_stride, const float* __restrict__ w,
@@ -257,6 +305,13 @@ extern "C" int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, co
     const int gelu = (flags & SC_LN_GELU) ? 1 : 0;
     if (D == 768 && flags == 0 && gamma && ld_in == 768 && ld_out == 768 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
         hipLaunchKernelGGL(layernorm768_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, rows, eps);
+        SC_CHECK_LAUNCH();
+        return 0;
+    }
+    if (D == 512 && (flags & ~SC_LN_GELU) == 0 && gamma && ld_in == 512 && ld_out == 512 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+        const dim3 g512((unsigned)((rows + 15) / 16));
+        if (gelu) hipLaunchKernelGGL((layernorm512_kernel<true>), g512, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, rows, eps);
+        else hipLaunchKernelGGL((layernorm512_kernel<false>), g512, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, rows, eps);
         SC_CHECK_LAUNCH();
         return 0;
     }

@@ -42,6 +42,20 @@ def test_layernorm_768_fast_path_odd_rows():
         torch.testing.assert_close(y.float(), F.layer_norm(x.float(), (768,), gamma, beta, 1e-5), atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("gelu", [False, True])
+def test_layernorm_512_fast_path(gelu):
+    """HuBERT-large extractor LayerNorm(+GELU) over 512 channels: the 16-byte-per-lane kernel, ragged row counts."""
+    from speechclip_amd import ops
+    g = _g(512 + gelu)
+    for rows in (1, 3, 16, 17, 4099):
+        x = (torch.randn(rows, 512, generator=g) * 3 - 1).to("cuda", BF)
+        gamma, beta = (1 + 0.3 * torch.randn(512, generator=g)).cuda(), (0.3 * torch.randn(512, generator=g)).cuda()
+        y = ops.layernorm(x, gamma, beta, gelu=gelu)
+        ref = F.layer_norm(x.float(), (512,), gamma, beta, 1e-5)
+        ref = F.gelu(ref) if gelu else ref
+        torch.testing.assert_close(y.float(), ref, atol=2e-2, rtol=2e-2)
+
+
 def test_layernorm_strided_rows():
     from speechclip_amd import ops
     x = torch.randn(6, 5, 768, generator=_g(1)).cuda()
