@@ -211,6 +211,25 @@ int sc_l2norm_bwd(const float* x, const float* dy, float* dx, int rows, int D, v
 int sc_dropout_f32(const float* x, float* y, int64_t n, float drop_p, uint32_t seed, void* stream);
 int sc_add_rows_f32(const float* a, const float* b, float* out, int rows, int cols, int b_rows, float alpha, void* stream);   /* out = alpha*a + b[r % b_rows] */
 int sc_mix_softmax_bwd(const float* w, const float* dalpha_b, int B, int n, float* dw, void* stream);
+/* Cascaded tail, training (kwClip.py:868-916 under loss.backward(); gradients reach the keyword branch THROUGH the frozen CLIP text tower).
+ * sc_attn_small_bwd: causal self-attention backward over L <= 16 live positions (clip_official.py:220-264: only SOT, K keywords, EOT matter
+ *   under the causal mask), qkv bf16 [B*L, 3W] as saved by the forward, dout f32 [B*L, W] -> dqkv f32 [B*L, 3W]; head_dim 64.
+ * sc_quickgelu_f32: backward=0: y = z sigmoid(1.702 z) (f32, or bf16 when out_bf16); backward=1: y_or_dh (f32) *= d/dz.
+ * sc_vq_st_bwd: straight-through estimator of SimpleVectorQuantizer (my_vector_quantizer.py:133-141, hard, no gumbel):
+ *   dprob_inout f32 [R,V] (d loss / d subword_prob) -> d loss / d cos_scores = p (dprob - sum p dprob) / temp, p = softmax(cos / temp) over the
+ *   unmasked sub-words (masked columns get 0); rowdot[r] = sum_v dcos cos.
+ * sc_cosine_bwd_finish: da = (G - rowdot a/|a|) / |a| with G = dcos @ (emb/|emb|) (one sc_sgemm): backward of F.cosine_similarity (kwClip.py:889-897).
+ * sc_kw_bn_train_fwd / sc_kw_bn_bwd: Kw_BatchNorm eachKw+parallel in train mode (kw_bn.py:122-131): batch statistics over the B rows of
+ *   x f32 [B,K,E]; gamma/beta/running_* are indexed e*K + k (the reference flattens (B,E,K)); running statistics updated in place with
+ *   `momentum` (unbiased variance), NULL: not tracked.  mean_out / rstd_out f32 [K*E] (data order) feed the backward. */
+int sc_attn_small_bwd(const void* qkv, const float* dout, float* dqkv, int B, int L, int heads, int head_dim, int causal, void* stream);
+int sc_quickgelu_f32(const float* z, void* y_or_dh, int64_t n, int backward, int out_bf16, void* stream);
+int sc_vq_st_bwd(const float* cos_scores, float* dprob_inout, float* rowdot, int R, int V, float temp, const int* mask_ids, int n_mask, void* stream);
+int sc_cosine_bwd_finish(const float* a, const float* G, const float* rowdot, float* da, int R, int E, float eps, void* stream);
+int sc_kw_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_out, float* rstd_out, float* running_mean,
+                       float* running_var, int B, int K, int E, float momentum, float eps, void* stream);
+int sc_kw_bn_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                 int B, int K, int E, void* stream);
 /* sc_infonce_bwd: G[Bg,Bg] = d loss / d logits and dinv_out[0] = d loss / d inv_temperature (losses.py:161,:219 trainable temperature),
  *   from the workspace sc_infonce_fwd filled for the same inputs; d loss / d feat_a = inv_temperature * G . feat_b (one sc_sgemm). */
 int64_t sc_infonce_bwd_workspace_bytes(int Bg);

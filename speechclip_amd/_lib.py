@@ -75,6 +75,12 @@ def _declare(L):
         "sc_cls_pool_bwd": ([P, L64, P, P, I, L64, I, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, U32, P], c_int),
         "sc_layernorm_bwd": ([P, P, P, P, P, P, P, I, I, F, I, P], c_int),
         "sc_gelu_f32": ([P, P, L64, I, P], c_int),
+        "sc_attn_small_bwd": ([P, P, P, I, I, I, I, I, P], c_int),
+        "sc_quickgelu_f32": ([P, P, L64, I, I, P], c_int),
+        "sc_vq_st_bwd": ([P, P, P, I, I, F, P, I, P], c_int),
+        "sc_cosine_bwd_finish": ([P, P, P, P, I, I, F, P], c_int),
+        "sc_kw_bn_train_fwd": ([P, P, P, P, P, P, P, P, I, I, I, F, F, P], c_int),
+        "sc_kw_bn_bwd": ([P, P, P, P, P, P, P, P, I, I, I, P], c_int),
         "sc_colsum": ([P, L64, I, I, P, I, P], c_int),
         "sc_l2norm_bwd": ([P, P, P, I, I, P], c_int),
         "sc_dropout_f32": ([P, P, L64, F, U32, P], c_int),

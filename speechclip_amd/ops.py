@@ -472,3 +472,72 @@ def retrieval_ranks(score, own_ids, cand_ids):
     rank = torch.empty(n, device=score.device, dtype=torch.int32)
     check(lib().sc_retrieval_ranks(ptr(score), score.stride(0), ptr(own), ptr(cand), ptr(rank), n, m, stream()), "sc_retrieval_ranks")
     return rank
+
+
+# ---- cascaded tail, training (train_cascaded.hip) ----
+def attn_small_bwd(qkv16, dout, B, L, H, causal=True):
+    """qkv bf16 [B*L, 3*H*64] (saved by the forward), dout f32 [B*L, H*64] -> dqkv f32 [B*L, 3*H*64]."""
+    _need_cuda(qkv16, dout)
+    W = H * 64
+    assert qkv16.dtype == bf16 and qkv16.shape == (B * L, 3 * W) and qkv16.is_contiguous()
+    _f32c(dout)
+    dqkv = torch.empty(B * L, 3 * W, device=dout.device, dtype=torch.float32)
+    check(lib().sc_attn_small_bwd(ptr(qkv16), ptr(dout), ptr(dqkv), B, L, H, 64, int(causal), stream()), "sc_attn_small_bwd")
+    return dqkv
+
+
+def quickgelu_f32(z, out_bf16=False):
+    _f32c(z)
+    y = torch.empty(z.shape, device=z.device, dtype=bf16 if out_bf16 else torch.float32)
+    check(lib().sc_quickgelu_f32(ptr(z), ptr(y), z.numel(), 0, int(out_bf16), stream()), "sc_quickgelu_f32")
+    return y
+
+
+def quickgelu_bwd_(z, dh):
+    """dh *= quickgelu'(z) in place."""
+    _f32c(z, dh)
+    check(lib().sc_quickgelu_f32(ptr(z), ptr(dh), z.numel(), 1, 0, stream()), "sc_quickgelu_f32")
+    return dh
+
+
+def vq_st_bwd_(cos, dprob, temp, mask_ids=(0, 2, 3)):
+    """dprob f32 [R,V] becomes d loss / d cos in place; returns rowdot f32 [R] = sum_v dcos cos."""
+    import ctypes
+    _f32c(cos, dprob)
+    R, V = cos.shape
+    rowdot = torch.empty(R, device=cos.device, dtype=torch.float32)
+    ids = (ctypes.c_int32 * max(1, len(mask_ids)))(*[int(i) for i in mask_ids])
+    check(lib().sc_vq_st_bwd(ptr(cos), ptr(dprob), ptr(rowdot), R, V, float(temp), ctypes.cast(ids, ctypes.c_void_p), len(mask_ids), stream()),
+          "sc_vq_st_bwd")
+    return rowdot
+
+
+def cosine_bwd_finish(a, G, rowdot, eps=1e-8):
+    _f32c(a, G, rowdot)
+    da = torch.empty_like(a)
+    check(lib().sc_cosine_bwd_finish(ptr(a), ptr(G), ptr(rowdot), ptr(da), a.shape[0], a.shape[1], eps, stream()), "sc_cosine_bwd_finish")
+    return da
+
+
+def kw_bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps):
+    """x f32 [B,K,E]; gamma/beta/running_* f32 [E*K] in the reference's (e, k) order -> (y, mean [K*E], rstd [K*E]); running stats updated in place."""
+    _f32c(x, gamma, beta)
+    B, K, E = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(K * E, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(K * E, device=x.device, dtype=torch.float32)
+    if running_mean is not None:
+        _f32c(running_mean, running_var)
+    check(lib().sc_kw_bn_train_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), B, K, E,
+                                   float(momentum), float(eps), stream()), "sc_kw_bn_train_fwd")
+    return y, mean, rstd
+
+
+def kw_bn_bwd(x, dy, gamma, mean, rstd, want_param_grads=True):
+    _f32c(x, dy, gamma, mean, rstd)
+    B, K, E = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(K * E, device=x.device, dtype=torch.float32) if want_param_grads else None
+    db = torch.empty(K * E, device=x.device, dtype=torch.float32) if want_param_grads else None
+    check(lib().sc_kw_bn_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db), B, K, E, stream()), "sc_kw_bn_bwd")
+    return dx, dg, db

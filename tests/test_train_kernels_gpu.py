@@ -297,3 +297,89 @@ def test_train_mode_crop_pad_matches_per_utterance_path():
     out = ops.crop_pad(wav.to(dev()), starts, outl, max(outl)).cpu()
     for i, r in enumerate(ref):
         assert torch.equal(out[i, :len(r)], r) and bool((out[i, len(r):] == 0).all())
+
+
+# ---------------------------------------------------------------- cascaded tail (train_cascaded.hip)
+@pytest.mark.parametrize("B,L,H,causal", [(5, 10, 8, True), (3, 16, 12, True), (2, 7, 8, False), (1, 1, 8, True)])
+def test_attn_small_bwd(B, L, H, causal):
+    """dqkv of softmax(q k^T / 8 [+ causal mask]) v over the K+2 live text positions vs torch autograd on the same bf16 qkv."""
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + L)
+    W = H * 64
+    qkv16 = (0.7 * torch.randn(B * L, 3 * W, generator=g)).to(dev(), torch.bfloat16)
+    dout = torch.randn(B * L, W, generator=g).to(dev())
+    x = qkv16.float().requires_grad_(True)
+    q, k, v = [t.view(B, L, H, 64).transpose(1, 2) for t in x.split(W, dim=1)]
+    s = q @ k.transpose(-1, -2) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device=dev()).triu(1)
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * L, W)
+    o.backward(dout)
+    got = ops.attn_small_bwd(qkv16, dout, B, L, H, causal)
+    torch.testing.assert_close(got, x.grad, atol=2e-5, rtol=1e-4)
+
+
+def test_quickgelu_fwd_bwd():
+    from speechclip_amd import ops
+    z = (3 * torch.randn(1000, 37, generator=torch.Generator().manual_seed(5))).to(dev()).requires_grad_(True)
+    ref = z * torch.sigmoid(1.702 * z)
+    dh = torch.randn(1000, 37, generator=torch.Generator().manual_seed(6)).to(dev())
+    ref.backward(dh)
+    torch.testing.assert_close(ops.quickgelu_f32(z.detach()), ref.detach(), atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(ops.quickgelu_f32(z.detach(), out_bf16=True).float(), ref.detach(), atol=2e-2, rtol=1e-2)
+    torch.testing.assert_close(ops.quickgelu_bwd_(z.detach(), dh.clone()), z.grad, atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("R,V,E,temp", [(48, 1000, 64, 0.1), (16, 49408, 512, 0.1), (7, 333, 32, 1.0)])
+def test_vq_straight_through_and_cosine_bwd(R, V, E, temp):
+    """keywords = (hard + soft - soft.detach()) @ emb with soft = softmax(masked cos / temp), cos = F.cosine_similarity(a, emb):
+    d loss / d a from sc_sgemm + sc_vq_st_bwd + sc_sgemm + sc_cosine_bwd_finish vs autograd of exactly that graph
+    (my_vector_quantizer.py:75-141, kwClip.py:889-911)."""
+    import torch.nn.functional as F
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(R + V)
+    emb = torch.randn(V, E, generator=g).to(dev())
+    a = (torch.randn(R, E, generator=g) + 0.3).to(dev()).requires_grad_(True)
+    dkw = torch.randn(R, E, generator=g).to(dev())
+    cos = F.cosine_similarity(a.unsqueeze(2), emb.t().unsqueeze(0), dim=1)          # [R, V]
+    x = cos.clone()
+    for i in (0, 2, 3):
+        x[:, i] += float("-inf")
+    hard = torch.zeros_like(x).scatter_(-1, x.argmax(-1, keepdim=True), 1.0)
+    soft = torch.softmax(x / temp, -1)
+    kw = (hard + soft - soft.detach()) @ emb
+    kw.backward(dkw)
+    cos_mine = ops.cosine_scores(a.detach(), emb)
+    torch.testing.assert_close(cos_mine, cos.detach(), atol=2e-6, rtol=1e-5)
+    dprob = ops.sgemm(dkw, emb, transb=True)                                         # d loss / d subword_prob
+    rowdot = ops.vq_st_bwd_(cos_mine, dprob, temp)
+    G = ops.sgemm(dprob, ops.l2norm(emb))
+    da = ops.cosine_bwd_finish(a.detach(), G, rowdot)
+    scale = a.grad.abs().max().item()
+    assert (da - a.grad).abs().max().item() < 2e-4 * max(scale, 1e-3), ((da - a.grad).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("B,K,E", [(6, 8, 16), (256, 8, 512), (3, 1, 5)])
+def test_kw_batchnorm_train_fwd_bwd(B, K, E):
+    """Kw_BatchNorm eachKw+parallel in train mode = nn.BatchNorm1d(E*K) over the (B, E, K)-flattened keywords (kw_bn.py:122-131)."""
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(B + K + E)
+    bn = torch.nn.BatchNorm1d(E * K).to(dev()).train()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(E * K, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(E * K, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(E * K, generator=g))
+        bn.running_var.copy_(1 + 0.1 * torch.rand(E * K, generator=g))
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    x = (2 * torch.randn(B, K, E, generator=g) + 0.5).to(dev()).requires_grad_(True)
+    dy = torch.randn(B, K, E, generator=g).to(dev())
+    ref = bn(x.permute(0, 2, 1).reshape(B, -1)).reshape(B, E, K).permute(0, 2, 1)
+    ref.backward(dy)
+    y, mean, rstd = ops.kw_bn_train_fwd(x.detach().contiguous(), bn.weight.detach(), bn.bias.detach(), rm, rv, bn.momentum, bn.eps)
+    torch.testing.assert_close(y, ref.detach(), atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(rm, bn.running_mean, atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(rv, bn.running_var, atol=1e-5, rtol=1e-5)
+    dx, dg, db = ops.kw_bn_bwd(x.detach().contiguous(), dy, bn.weight.detach(), mean, rstd)
+    torch.testing.assert_close(dx, x.grad, atol=5e-5, rtol=1e-4)
+    torch.testing.assert_close(dg, bn.weight.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(db, bn.bias.grad, atol=1e-4, rtol=1e-4)
