@@ -62,11 +62,13 @@ def algorithmic_gflop_per_pair(L=160000, d=768, ffn=3072, layers=12, vit_w=768, 
 LARGE = dict(d=1024, ffn=4096, layers=24, vit_w=1024, vit_layers=24, patch=14, E=768)   # HuBERT-large + ViT-L/14 (BASELINE configs[4])
 
 
-def build_model(seed=7122, large=False):
+def build_model(seed=7122, large=False, cascaded=False):
     from helpers import make_config
     from speechclip_amd.model import KWClip_GeneralTransformer
     torch.manual_seed(seed)
-    if large:
+    if cascaded:      # C-base (BASELINE configs[2]): 8 keyword queries -> BatchNorm -> VQ over the 49408 sub-words -> CLIP text tower
+        cfg = make_config(parallel=False, cascaded=True)
+    elif large:
         cfg = make_config(d_model=1024, branch_heads=8, hubert_name="hubert_large_ll60k", clip_name="ViT-L/14", normalize_hiddenstates=True,
                           temperature_trainable=True)
     else:
@@ -119,7 +121,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default 256; 64 with --model large)")
-    ap.add_argument("--model", choices=["base", "large"], default="base", help="base = the headline workload (BASELINE configs[1]); large = "
+    ap.add_argument("--model", choices=["base", "large", "cascaded"], default="base", help="base = the headline workload (BASELINE configs[1]); large = "
                     "HuBERT-large + ViT-L/14 (configs[4]), informational")
     ap.add_argument("--audio-len", type=int, default=160000)
     ap.add_argument("--cpu-pairs", type=int, default=32, help="pairs for the CPU baseline sample (0 = skip)")
@@ -142,8 +144,9 @@ def main():
     large = args.model == "large"
     if args.batch is None:
         args.batch = 64 if large else 256
-    model = build_model(large=large)
-    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_pairs > 0 and world == 1 and not args.train and not large) else None
+    casc = args.model == "cascaded"
+    model = build_model(large=large, cascaded=casc)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_pairs > 0 and world == 1 and not args.train and not large and not casc) else None
     model = model.to(dev)
     B, L = args.batch, args.audio_len
     g = torch.Generator(device="cpu").manual_seed(7122 + rank)
@@ -203,7 +206,7 @@ def main():
             # report the committed per-launch figure of the same command, with its source, or null if it is not there / not this workload
             traffic, tsrc = None, None
             tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
-            if os.path.exists(tf) and not args.train and not large and B == 256 and L == 160000:
+            if os.path.exists(tf) and not args.train and not large and not casc and B == 256 and L == 160000:
                 tj = json.load(open(tf))
                 traffic, tsrc = tj["bytes_per_launch"], tj["source"] + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2)"
             roof = {"bound": "mfma", "kernel": "sc_gemm_bf16 entry (all launches of the step): gemm256_kernel for fused epilogues / overlapping rows, hipBLASLt for the plain QKV / out-proj / fc2 GEMMs", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
@@ -211,10 +214,11 @@ def main():
                     "launches_per_step": launches // args.steps,
                     "avg_launch_ms": round(ms / launches, 4), "gemm_ms_per_step": round(ms / args.steps, 3),
                     "executed_over_algorithmic": round(sum(e[2] for e in prof) / alg, 4)}
-        out = {"metric": "speech-image pairs/sec/node (Parallel SpeechCLIP %s)" % args.model, "value": round(pairs_per_s, 2), "unit": "pairs/s",
+        out = {"metric": "speech-image pairs/sec/node (%s)" % ("Cascaded SpeechCLIP base" if casc else "Parallel SpeechCLIP %s" % args.model), "value": round(pairs_per_s, 2), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": ("Parallel SpeechCLIP large (HuBERT-large + ViT-L/14)" if large else "Parallel SpeechCLIP base (HuBERT-base + ViT-B/32)")
+               "config": {"workload": ("Cascaded SpeechCLIP base (HuBERT-base + ViT-B/32 + CLIP text tower; flop model = the encoders' GEMMs, the keyword head adds < 1 %)" if casc else
+                                       "Parallel SpeechCLIP large (HuBERT-large + ViT-L/14)" if large else "Parallel SpeechCLIP base (HuBERT-base + ViT-B/32)")
                           + " forward + InfoNCE, 10 s/16 kHz audio + 224^2 images",
                           "pairs_per_gpu": B, "global_batch": world * B, "audio_samples": L_eff, "frames": conv_lens(L_eff)[-1],
                           "parallelism": f"dp{world}" if world > 1 else "single", "weights": "random-init (no network)",

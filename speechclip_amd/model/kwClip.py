@@ -261,9 +261,8 @@ class KW_CascadedBranch(nn.Module):
                                          parallel=bn.parallel if hasattr(bn, "parallel") else False)
 
     def forward(self, audio_feat: torch.Tensor, audio_len: torch.Tensor):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training the cascaded branch (train-mode Kw_BatchNorm statistics, straight-through VQ, gradients through "
-                                      "the CLIP text tower) is SURVEY.md section 8f work after the parallel tail; use eval() / no_grad() here")
+        if self.training and torch.is_grad_enabled() and self.cls.requires_grad:
+            return self._forward_train(audio_feat, audio_len)
         B, K = audio_feat.shape[0], self.keyword_num
         kw = self.self_att.forward_cls(self.cls, audio_feat, audio_len)                       # bf16 [B, K, d]
         kw = ops.gemm(kw.view(B * K, -1), TransformerModels.cached_cast(self.linear_proj.weight, torch.bfloat16),
@@ -277,6 +276,36 @@ class KW_CascadedBranch(nn.Module):
         keywords = self.vector_quantizer.embed(vq_results, emb)
         feat = self.clip.encode_keywords(keywords, K)
         return feat, vq_results, keywords
+
+
+def _kw_cascaded_forward_train(self, audio_feat: torch.Tensor, audio_len: torch.Tensor):
+    """Differentiable train-mode path (kwClip.py:868-916 under loss.backward()): train_tail.CascadedPoolTrainFn -> Kw_BatchNorm (batch
+    statistics) -> cosine / straight-through VQ (KeywordSTFn) -> frozen CLIP text tower with input gradients (TextTowerTrainFn)."""
+    from ..train_tail import CascadedPoolTrainFn, KeywordSTFn
+    B, K = audio_feat.shape[0], self.keyword_num
+    mha = self.self_att.multihead_attn_layer
+    src = getattr(audio_feat, "_mix_src", None)
+    hidden, mixw, normalize = (src[0], src[1].weights, src[1].normalize_features) if src is not None else (None, None, False)
+    drop_p = float(mha.dropout)
+    seed = int(torch.randint(0, 2 ** 31 - 8, (1,)).item()) if drop_p > 0 else 0
+    meta = dict(heads=self.self_att.nhead, eps=self.self_att.eps, drop_p=drop_p, seed=seed, normalize=normalize)
+    n = self.self_att.attentionBlock_Norm
+    kw = CascadedPoolTrainFn.apply(meta, hidden, audio_feat.detach(), audio_len, mixw, self.cls, mha.in_proj_weight, mha.in_proj_bias,
+                                   mha.out_proj.weight, mha.out_proj.bias, n.weight, n.bias, self.linear_proj.weight,
+                                   self.linear_proj.bias).view(B, K, self.text_dim)
+    if hasattr(self, "bn_layer"):
+        kw = self.bn_layer(kw)
+    emb = self.clip.model.token_embedding.weight
+    assert emb.requires_grad is False
+    cos = ops.cosine_scores(kw.detach().reshape(B * K, self.text_dim), emb)                     # fp32 [B*K, V]
+    vq_results = self.vector_quantizer(x=cos.view(B, K, emb.shape[0]))
+    keywords = KeywordSTFn.apply(kw.reshape(B * K, self.text_dim), cos, vq_results["targets"].reshape(-1), emb,
+                                 float(self.vector_quantizer.curr_temp.item()), (0, 2, 3)).view(B, K, emb.shape[1])
+    feat = self.clip.encode_keywords(keywords, K)
+    return feat, vq_results, keywords
+
+
+KW_CascadedBranch._forward_train = _kw_cascaded_forward_train
 
 
 class KWClip_GeneralTransformer(KWClipBase):
@@ -328,7 +357,11 @@ class KWClip_GeneralTransformer(KWClipBase):
         c_feat = p_feat = vq = kw = None
         if self.cascaded_branch is not None:
             c_feat, vq, kw = self.cascaded_branch(audio_feat=audio_feat, audio_len=audio_len)
-            c_feat = ops.l2norm(c_feat)
+            if c_feat.requires_grad:
+                from ..train_tail import L2NormFn
+                c_feat = L2NormFn.apply(c_feat)
+            else:
+                c_feat = ops.l2norm(c_feat)
         if self.parallel_branch is not None:
             p_feat = self.parallel_branch(audio_feat=audio_feat, audio_len=audio_len)
             if self.p_branch_proj_net is not None:

@@ -146,13 +146,27 @@ class CLIP(nn.Module):
         nn.init.normal_(self.positional_embedding, std=0.01)
         nn.init.normal_(self.text_projection, std=cfg.text_width ** -0.5)
         self._packed = None
+        self._packed_f32 = None
         self.register_load_state_dict_post_hook(lambda module, keys: module.invalidate_packed())
 
     def invalidate_packed(self):
         self._packed = None
+        self._packed_f32 = None
+
+    def packed_f32(self, dev):
+        """fp32 copies of the (frozen) text-tower weights for the backward pass of the cascaded tail (train_tail.TextTowerTrainFn)."""
+        if getattr(self, "_packed_f32", None) is None:
+            f32 = torch.float32
+            c = lambda t: t.detach().to(dev, f32).contiguous()   # noqa: E731
+            self._packed_f32 = dict(
+                txt=[dict(g1=c(b.ln_1.weight), wqkv=c(b.attn.in_proj_weight), wo=c(b.attn.out_proj.weight), g2=c(b.ln_2.weight),
+                          w1=c(b.mlp.c_fc.weight), w2=c(b.mlp.c_proj.weight)) for b in self.transformer.resblocks],
+                ln_final_g=c(self.ln_final.weight), txt_proj_t=c(self.text_projection.t()))
+        return self._packed_f32
 
     def _apply(self, fn, *a, **k):
         self._packed = None
+        self._packed_f32 = None
         return super()._apply(fn, *a, **k)
 
     @property
@@ -196,12 +210,21 @@ class CLIP(nn.Module):
         cls = ops.layernorm(x, *P["ln_post"], rows=B, D=W, ld_in=ntok * W)
         return ops.gemm(cls, P["proj_t"], out_f32=True)
 
-    @torch.no_grad()
     def encode_text_embeddings(self, emb: torch.Tensor, take_pos: torch.Tensor) -> torch.Tensor:
         """emb: f32 [B, L, tw] token embeddings (before positional add), L <= context_length.  Runs the causal text
         transformer on the first L positions (positions > max(take_pos) cannot influence it) and returns
-        ln_final(x)[b, take_pos[b]] @ text_projection as f32 [B, embed_dim]."""
+        ln_final(x)[b, take_pos[b]] @ text_projection as f32 [B, embed_dim].  When `emb` carries a gradient (training the cascaded
+        branch through the frozen tower) the differentiable path runs; all rows must then share one take position."""
         assert emb.is_cuda
+        if torch.is_grad_enabled() and emb.requires_grad:
+            from ..train_tail import TextTowerTrainFn
+            pos = int(take_pos[0].item())
+            assert bool((take_pos == pos).all()), "training path: one EOT position for the whole batch (K keywords => K + 1)"
+            return TextTowerTrainFn.apply(self, emb, pos)
+        with torch.no_grad():
+            return self._encode_text_embeddings_eval(emb, take_pos)
+
+    def _encode_text_embeddings_eval(self, emb: torch.Tensor, take_pos: torch.Tensor) -> torch.Tensor:
         P = self.packed(emb.device)
         B, L, tw = emb.shape
         x = (emb.float() + P["txt_pos"][:L]).reshape(B * L, tw).contiguous()

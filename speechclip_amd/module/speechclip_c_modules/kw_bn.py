@@ -1,7 +1,7 @@
 """Kw_BatchNorm (avssl/module/speechclip_c_modules/kw_bn.py:8-164), shipped mode: `eachKw` + `parallel` = one
 BatchNorm1d over the flattened (dim, keyword) features, initialised from the CLIP token-embedding mean/std.
-Eval mode (running statistics) is an affine map executed by sc_kw_affine; train-mode batch statistics are
-per-rank (not synced), as under the reference's DataParallel."""
+Eval mode (running statistics) is an affine map executed by sc_kw_affine; train mode (sc_kw_bn_train_fwd / sc_kw_bn_bwd) uses the batch
+statistics of this rank's rows (not synced), as each replica does under the reference's DataParallel."""
 import torch
 from torch import nn
 
@@ -25,9 +25,14 @@ class Kw_BatchNorm(nn.Module):
 
     def forward(self, keywords: torch.Tensor, seq_lens: torch.Tensor = None) -> torch.Tensor:
         assert keywords.dim() == 3 and keywords.shape[2] == self.kw_dim and keywords.shape[1] == self.kw_num
-        if self.training:
-            raise NotImplementedError("train-mode keyword BatchNorm (batch statistics + backward) is SURVEY.md section 8f rank 1")
         bn = self.bn_layer
+        if self.training:       # batch statistics of this rank's rows + running-stat update (train_tail.KwBatchNormTrainFn)
+            from ...train_tail import KwBatchNormTrainFn
+            if not (bn.track_running_stats and bn.momentum is not None):
+                raise NotImplementedError("Kw_BatchNorm training path expects nn.BatchNorm1d defaults (tracked running stats, momentum 0.1)")
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+            return KwBatchNormTrainFn.apply(keywords, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps))
         # flattened feature index of (k, d) is d*K + k  (kw_bn.py:122-131: permute(0,2,1).reshape(B,-1))
         K, D = self.kw_num, self.kw_dim
         scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).view(D, K).t().contiguous().float()

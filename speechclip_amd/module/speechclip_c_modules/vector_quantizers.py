@@ -1,4 +1,4 @@
-"""SimpleVectorQuantizer (avssl/module/speechclip_c_modules/my_vector_quantizer.py:12-165), eval (hard) mode on HIP:
+"""SimpleVectorQuantizer (avssl/module/speechclip_c_modules/my_vector_quantizer.py:12-165), hard (non-gumbel) mode on HIP:
 special-token masking, arg-max one-hot, code/prob perplexities and per-keyword entropy in one pass over the
 [B*K, V] score matrix (sc_vq_fwd).  `subword_prob` is returned lazily (a dense one-hot is only materialised if read)."""
 import ast
@@ -44,8 +44,10 @@ class SimpleVectorQuantizer(nn.Module):
         pass
 
     def forward(self, x, prob_msk=[0, 2, 3], produce_targets=True):
-        if self.training:
-            raise NotImplementedError("train-mode straight-through VQ needs the backward path (SURVEY.md section 8f rank 1)")
+        # train mode: same statistics and hard targets; the straight-through gradient (softmax(x / temp), :133-141) is applied where the
+        # sub-word embeddings are formed (train_tail.KeywordSTFn via KW_CascadedBranch), `subword_prob` stays the hard one-hot value.
+        if self.training and self.temp_type == "learnable":
+            raise NotImplementedError("training a learnable VQ temperature is not supported (no shipped config uses it)")
         B, K, V = x.shape
         targets, stats, ent = ops.vq_fwd(x.reshape(B * K, V), K, prob_msk)
         res = _LazyOneHot()

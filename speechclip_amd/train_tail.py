@@ -9,6 +9,10 @@ parameters the reference optimises and any torch optimizer -- or `FusedAdam` bel
 -- can step them.
 
   ParallelBranchTrainFn : hidden states -> layer mix -> [CLS; frames] encoder layer (CLS row only) -> final LN -> Linear  [B, E]
+  CascadedPoolTrainFn   : hidden states -> layer mix -> K keyword queries over [CLS_1..K; frames] -> LN(MHA + CLS) -> Linear          [B*K, E_txt]
+  KwBatchNormTrainFn    : train-mode keyword BatchNorm (batch statistics, running-stat update)     (kw_bn.py:122-131)
+  KeywordSTFn           : cosine scores -> straight-through VQ -> sub-word embeddings              (kwClip.py:889-911)
+  TextTowerTrainFn      : frozen CLIP text tower with the gradient w.r.t. its input embeddings     (clip_official.py:220-264)
   L2NormFn              : x / |x|                                                      (kwClip.py:1436)
   MaskedContrastiveFn   : masked InfoNCE on the gathered global batch                  (losses.py:185-245)
   GatherFeatsFn         : RCCL all-gather whose backward keeps the local rows           (replaces DP's gather, kwClip.py:147-191)
@@ -152,6 +156,193 @@ class ParallelBranchTrainFn(torch.autograd.Function):
             ops.mix_softmax_bwd(mixw, dalpha, dmix)
         return (None, None, None, None, dmix, dcls.view(1, NQ, D), dWin, dbin, dWo, dbo, dn1w, dn1b, dl1w, dl1b, dl2w, dl2b, dn2w, dn2b, dnfw, dnfb,
                 dpw, dpb)
+
+
+# ================================================================= cascaded tail (kwClip.py:697-916)
+def _pool_params(c, Win, bin_, NQ, D, H, hd, scale, dev):
+    """Parameter-only operands of the algebraic CLS pooling: queries qt [NQ,D], U [R,D] (u_r = scale Wk_h^T q_h), beta [R]."""
+    R = NQ * H
+    qt = ops.sgemm(c, Win[:D], transb=True, bias=bin_[:D])
+    U = torch.empty(R, D, device=dev, dtype=torch.float32)
+    beta = torch.empty(R, device=dev, dtype=torch.float32)
+    Wk, bk = Win[D:2 * D], bin_[D:2 * D]
+    ops.sgemm_batched(NQ, D, hd, qt, D, hd, Wk, D, hd * D, U, H * D, D, H, alpha=scale)
+    ops.sgemm_batched(NQ, 1, hd, qt, D, hd, bk, 1, hd, beta, H, 1, H, alpha=scale)
+    return qt, U, beta
+
+
+class CascadedPoolTrainFn(torch.autograd.Function):
+    """kp f32 [B*K, E] = linear_proj(LN(MHA([CLS_1..K ; frames])[:, :K] + CLS))   (kwClip.py:870-884, TransformerModels.py:99-124).
+    Same algebraic pooling as the parallel branch with K query tokens; attention-probability dropout from the hash RNG.
+
+    args: meta (heads, eps, drop_p, seed, normalize), hidden bf16 [n,B,Tp,D] | None, x16 bf16 [B,T,D], lens, mixw [n] | None,
+          cls [1,K,D], in_w [3D,D], in_b [3D], out_w, out_b, nw, nb (attentionBlock_Norm), pw [E,D], pb [E]."""
+
+    @staticmethod
+    def forward(ctx, meta, hidden, x16, lens, mixw, cls, in_w, in_b, out_w, out_b, nw, nb, pw, pb):
+        from .module.kw_modules.TransformerModels import _frames_view
+        H, eps, pd, seed = meta["heads"], meta["eps"], float(meta["drop_p"]), int(meta["seed"])
+        B, T, D = x16.shape
+        NQ = cls.shape[-2]
+        hd, R = D // H, NQ * H
+        scale = hd ** -0.5
+        rows, Tp = _frames_view(x16)
+        dev = rows.device
+        lens_i = lens.to(device=dev, dtype=torch.int32).contiguous()
+        c = _c(cls).view(NQ, D)
+        Win, bin_ = _c(in_w), _c(in_b)
+        qt, U, beta = _pool_params(c, Win, bin_, NQ, D, H, hd, scale, dev)
+        scores = ops.gemm(rows, U.to(BF).contiguous(), beta, out_f32=True)                    # [B*Tp, R]
+        cls_scores = ops.sgemm(c, U, transb=True, bias=beta)                                  # [NQ, R]
+        p, zbar = ops.cls_pool_train_fwd(rows, c, scores, cls_scores, lens_i, B, Tp, NQ, R, D, pd, seed)
+        att = torch.empty(B * NQ, D, device=dev, dtype=torch.float32)
+        Wv, bv = Win[2 * D:], bin_[2 * D:]
+        ops.sgemm_batched(B * NQ, hd, D, zbar, H * D, D, Wv, D, hd * D, att, D, hd, H, transb=True, bias=bv, stride_bias=hd)
+        sa = ops.sgemm(att, _c(out_w), transb=True, bias=_c(out_b))
+        y = ops.add_rows(sa, c)                                                               # + src rows (the CLS tokens)
+        kn = ops.layernorm(y, _c(nw), _c(nb), eps, out_f32=True)
+        kp = ops.sgemm(kn, _c(pw), transb=True, bias=_c(pb))
+        ctx.meta = dict(meta, B=B, Tp=Tp, D=D, NQ=NQ, R=R, hd=hd, scale=scale)
+        ctx.hidden = hidden
+        ctx.has_mix = mixw is not None
+        ctx.save_for_backward(rows, lens_i, c, Win, qt, U, p, zbar, att, y, kn, _c(out_w), _c(nw), _c(pw), _c(mixw) if mixw is not None else c)
+        return kp
+
+    @staticmethod
+    def backward(ctx, dkp):
+        rows, lens_i, c, Win, qt, U, p, zbar, att, y, kn, Wo, gn, Wp, mixw = ctx.saved_tensors
+        m = ctx.meta
+        B, Tp, D, NQ, R, hd, H, scale, eps, pd, seed = m["B"], m["Tp"], m["D"], m["NQ"], m["R"], m["hd"], m["heads"], m["scale"], m["eps"], float(m["drop_p"]), int(m["seed"])
+        dev = rows.device
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)   # noqa: E731
+        dkp = dkp.float().contiguous()
+        dpw = ops.sgemm(dkp, kn, transa=True)
+        dpb = ops.colsum(dkp)
+        dkn = ops.sgemm(dkp, Wp)
+        dnw, dnb = z(D), z(D)
+        dy = ops.layernorm_bwd(y, dkn, gn, dnw, dnb, eps)
+        dcls = ops.colsum(dy.view(B, NQ * D)).view(NQ, D).contiguous()                        # residual path: src rows are the CLS tokens
+        dWo = ops.sgemm(dy, att, transa=True)
+        dbo = ops.colsum(dy)
+        datt = ops.sgemm(dy, Wo)
+        dWin, dbin = z(3 * D, D), z(3 * D)
+        dzbar = torch.empty(B, R, D, device=dev, dtype=torch.float32)
+        Wk, Wv = Win[D:2 * D], Win[2 * D:]
+        ops.sgemm_batched(hd, D, B * NQ, datt, D, hd, zbar, H * D, D, dWin[2 * D:], D, hd * D, H, transa=True)   # dWv_h = datt_h^T zbar_h
+        ops.colsum(datt, out=dbin[2 * D:])
+        ops.sgemm_batched(B * NQ, D, hd, datt, D, hd, Wv, D, hd * D, dzbar, H * D, D, H)                          # dzbar_h = datt_h Wv_h
+        hid = ctx.hidden
+        hid2 = hid.reshape(hid.shape[0], B * Tp, D) if (ctx.has_mix and hid is not None) else None
+        du, dck, dalpha = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)), drop_p=pd, seed=seed)
+        dU = ops.colsum(du.view(-1, R * D)).view(R, D)
+        ops.colsum(dck.view(-1, NQ * D), out=dcls.view(NQ * D), accumulate=True)
+        dqt = torch.empty(NQ, D, device=dev, dtype=torch.float32)
+        ops.sgemm_batched(hd, D, NQ, qt, D, hd, dU, H * D, D, dWin[D:2 * D], D, hd * D, H, transa=True, alpha=scale)
+        ops.sgemm_batched(NQ, hd, D, dU, H * D, D, Wk, D, hd * D, dqt, D, hd, H, transb=True, alpha=scale)
+        ops.sgemm(dqt, c, transa=True, out=dWin[:D])
+        ops.colsum(dqt, out=dbin[:D])
+        ops.sgemm(dqt, Win[:D], beta=1.0, out=dcls)
+        dmix = None
+        if ctx.has_mix and dalpha is not None:
+            dmix = z(mixw.shape[0])
+            ops.mix_softmax_bwd(mixw, dalpha, dmix)
+        return None, None, None, None, dmix, dcls.view(1, NQ, D), dWin, dbin, dWo, dbo, dnw, dnb, dpw, dpb
+
+
+class KwBatchNormTrainFn(torch.autograd.Function):
+    """Train-mode Kw_BatchNorm (eachKw + parallel): y = BN_{batch stats}(x), x f32 [B,K,E]; the running statistics (buffers, (e,k) order) are
+    updated in place by the forward kernel, as nn.BatchNorm1d does (kw_bn.py:122-131)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        x = x.float().contiguous()
+        w = _c(weight)
+        y, mean, rstd = ops.kw_bn_train_fwd(x, w, _c(bias), running_mean, running_var, momentum, eps)
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.want = weight.requires_grad or bias.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.kw_bn_bwd(x, dy.float().contiguous(), w, mean, rstd, want_param_grads=ctx.want)
+        return dx, dg, db, None, None, None, None
+
+
+class KeywordSTFn(torch.autograd.Function):
+    """keywords [R,E] = subword_prob @ emb with the straight-through estimator of SimpleVectorQuantizer in train mode
+    (hard one-hot forward, softmax(cos/temp) backward; my_vector_quantizer.py:133-141, kwClip.py:909-911) and the cosine similarity behind it
+    (kwClip.py:889-897).  Forward = a row gather; backward = sc_sgemm -> sc_vq_st_bwd -> sc_sgemm -> sc_cosine_bwd_finish."""
+
+    @staticmethod
+    def forward(ctx, kb, cos, targets, emb, temp, mask_ids):
+        ctx.save_for_backward(kb.detach().float().contiguous(), cos, emb)
+        ctx.temp, ctx.mask_ids = float(temp), tuple(int(i) for i in mask_ids)
+        return ops.gather_rows(emb, targets.reshape(-1))
+
+    @staticmethod
+    def backward(ctx, dkw):
+        kb, cos, emb = ctx.saved_tensors
+        embf = emb.detach().float().contiguous()
+        dprob = ops.sgemm(dkw.float().contiguous(), embf, transb=True)                       # d loss / d subword_prob  [R, V]
+        rowdot = ops.vq_st_bwd_(cos, dprob, ctx.temp, ctx.mask_ids)                           # dprob is now d loss / d cos
+        G = ops.sgemm(dprob, ops.l2norm(embf))
+        return ops.cosine_bwd_finish(kb, G, rowdot), None, None, None, None, None
+
+
+class TextTowerTrainFn(torch.autograd.Function):
+    """feat f32 [B, E] = (ln_final(text_transformer(emb + pos))[:, pos_index]) @ text_projection with the gradient w.r.t. the token
+    embeddings `emb` f32 [B, L, W] (the tower itself is frozen: clip_official.py:220-264 under loss.backward()).  Forward on the bf16 MFMA
+    kernels (the eval path's rounding points), saving x / qkv / x_mid / pre-activation per layer; backward in fp32."""
+
+    @staticmethod
+    def forward(ctx, clip, emb, pos_index):
+        dev = emb.device
+        P = clip.packed(dev)
+        B, L, W = emb.shape
+        H = clip.transformer.heads
+        x = (emb.detach().float() + P["txt_pos"][:L]).reshape(B * L, W).contiguous()
+        saved = []
+        for Ly in P["txt"]:
+            n = ops.layernorm(x, *Ly["ln1"])
+            qkv = ops.gemm(n, Ly["wqkv"], Ly["bqkv"])
+            att = ops.attention(qkv, B, L, H, None, causal=True)
+            xm = ops.gemm(att, Ly["wo"], Ly["bo"], residual=x, out_f32=True)
+            n2 = ops.layernorm(xm, *Ly["ln2"])
+            u = ops.gemm(n2, Ly["w1"], Ly["b1"], out_f32=True)
+            h = ops.quickgelu_f32(u, out_bf16=True)
+            xo = ops.gemm(h, Ly["w2"], Ly["b2"], residual=xm, out_f32=True)
+            saved += [x, qkv, xm, u]
+            x = xo
+        rows = x.view(B, L, W)[:, pos_index].contiguous()
+        n = ops.layernorm(rows, *P["ln_final"])
+        feat = ops.gemm(n, P["txt_proj_t"], out_f32=True)
+        ctx.clip, ctx.dims = clip, (B, L, W, H, int(pos_index))
+        ctx.save_for_backward(rows, *saved)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        rows, *saved = ctx.saved_tensors
+        B, L, W, H, pos = ctx.dims
+        dev = rows.device
+        F = ctx.clip.packed_f32(dev)
+        dn = ops.sgemm(dfeat.float().contiguous(), F["txt_proj_t"])                           # [B, W]
+        drows = ops.layernorm_bwd(rows, dn, F["ln_final_g"], eps=1e-5)
+        dx = torch.zeros(B * L, W, device=dev, dtype=torch.float32)
+        dx.view(B, L, W)[:, pos] = drows
+        for li in range(len(F["txt"]) - 1, -1, -1):
+            Ly = F["txt"][li]
+            x, qkv, xm, u = saved[4 * li:4 * li + 4]
+            dh = ops.sgemm(dx, Ly["w2"])                                                     # [M, 4W]
+            ops.quickgelu_bwd_(u, dh)
+            dn2 = ops.sgemm(dh, Ly["w1"])
+            ops.layernorm_bwd(xm, dn2, Ly["g2"], eps=1e-5, dx=dx, accumulate_dx=True)         # dx is now d loss / d x_mid
+            datt = ops.sgemm(dx, Ly["wo"])
+            dqkv = ops.attn_small_bwd(qkv, datt, B, L, H, True)
+            dn1 = ops.sgemm(dqkv, Ly["wqkv"])
+            ops.layernorm_bwd(x, dn1, Ly["g1"], eps=1e-5, dx=dx, accumulate_dx=True)
+        return None, dx.view(B, L, W), None
 
 
 class L2NormFn(torch.autograd.Function):

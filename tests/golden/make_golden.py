@@ -342,6 +342,51 @@ def gen_end_to_end(kwclip_mod, OrderedNamespace, tag, hubert_cfg, clip_cfg, casc
         for k, prm in sc.parallel_branch.named_parameters():
             assert torch.allclose(prm.grad, torch.from_numpy(arrays["grad/parallel_branch." + k]), atol=2e-5, rtol=1e-3), k
         assert torch.allclose(sc.ws_weights.grad, torch.from_numpy(arrays["grad/audio_encoder.weightedsum_layer.weights"]), atol=2e-5, rtol=1e-3)
+    if cascaded and not parallel:
+        # TRAIN-mode gradients of the cascaded tail from the reference's own modules: batch-statistics Kw_BatchNorm, straight-through VQ
+        # (my_vector_quantizer.py:133-141), gradients through the frozen CLIP text tower.  Attention dropout is set to 0 (its RNG stream is
+        # not reproducible elsewhere); HuBERT / CLIP stay in eval mode and frozen.
+        cb = model.cascaded_branch
+        bn_before = {k: getattr(cb.bn_layer.bn_layer, k).clone() for k in ("running_mean", "running_var", "num_batches_tracked")}
+        cb.train()
+        model.clip.eval()
+        cb.self_att.multihead_attn_layer.dropout = 0.0
+        model.zero_grad()
+        losses_g, _, others_g = model.forward(batch)
+        loss_g = model.compute_loss(losses_g)["loss"]
+        loss_g.backward()
+        arrays["train/cascaded_audio_feat"] = losses_g["cascaded_audio_feat"].detach().numpy().copy()
+        arrays["train/loss"] = np.float64(loss_g.item())
+        arrays["train/vq_targets"] = others_g["vq_results"]["targets"].numpy().copy()
+        n_grad = 0
+        for k, prm in model.named_parameters():
+            if prm.grad is not None and ((k.startswith("cascaded_branch.") and not k.startswith("cascaded_branch.clip.")) or
+                                         k == "audio_encoder.weightedsum_layer.weights"):
+                arrays["grad/" + k] = prm.grad.detach().numpy().copy()
+                n_grad += 1
+        assert n_grad == 12, n_grad   # cls, in_proj w/b, out_proj w/b, norm w/b, linear_proj w/b, bn w/b + the layer-mix weights
+        for k in ("running_mean", "running_var", "num_batches_tracked"):
+            arrays["train/bn_" + k] = getattr(cb.bn_layer.bn_layer, k).detach().numpy().copy()
+            getattr(cb.bn_layer.bn_layer, k).copy_(bn_before[k])      # state_dict() aliases the live buffers: keep the saved "sd/" arrays pre-step
+        # the oracle's autograd in train mode (same weights, BN buffers as BEFORE the reference's step) must agree
+        sc.zero_grad()
+        sc.cascaded_branch.train()
+        sc.clip.eval()
+        sc.cascaded_branch.load_state_dict({k[len("cascaded_branch."):]: v for k, v in sd.items()
+                                            if k.startswith("cascaded_branch.") and not k.startswith("cascaded_branch.clip.")
+                                            and "vector_quantizer" not in k})
+        feat_o = speechclip_ref.weighted_sum([h.detach() for h in sc.forward_audio(batch["wav"], batch["wav_len"])[2]], sc.ws_weights, normalize_hiddenstates)
+        ca, _, _ = sc.cascaded_branch(feat_o, o["audio_len"])
+        loss_o = speechclip_ref.masked_contrastive_loss(speechclip_ref.l2_normalize(ca), o["image_feat"], batch["id"], sc.inv_temperature)
+        assert abs(loss_o.item() - loss_g.item()) < 1e-5, (loss_o.item(), loss_g.item())
+        loss_o.backward()
+        for k, prm in sc.cascaded_branch.named_parameters():
+            if k.startswith("clip.") or prm.grad is None:
+                continue
+            ref_g = torch.from_numpy(arrays["grad/cascaded_branch." + k])
+            assert torch.allclose(prm.grad, ref_g, atol=2e-5 + 1e-3 * ref_g.abs().max().item(), rtol=1e-3), (k, (prm.grad - ref_g).abs().max())
+        sc.cascaded_branch.eval()
+        cb.eval()
     for k, v in np_state(sd).items():
         if k.startswith("criterion.") or k.startswith("cascaded_branch.clip."):
             continue
