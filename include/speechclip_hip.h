@@ -222,6 +222,9 @@ int sc_mix_softmax_bwd(const float* w, const float* dalpha_b, int B, int n, floa
  * sc_kw_bn_train_fwd / sc_kw_bn_bwd: Kw_BatchNorm eachKw+parallel in train mode (kw_bn.py:122-131): batch statistics over the B rows of
  *   x f32 [B,K,E]; gamma/beta/running_* are indexed e*K + k (the reference flattens (B,E,K)); running statistics updated in place with
  *   `momentum` (unbiased variance), NULL: not tracked.  mean_out / rstd_out f32 [K*E] (data order) feed the backward. */
+/* sc_split_hilo_bf16: out bf16 [M, 2K] = (bf16(a) | bf16(a - bf16(a))): a @ W^T = out @ [W | W]^T keeps ~16 mantissa bits of an fp32 gradient on the
+ *   bf16 MFMA GEMM (the dX products against the frozen text tower / sub-word table). */
+int sc_split_hilo_bf16(const float* a, int64_t lda, void* out, int64_t M, int K, void* stream);
 int sc_attn_small_bwd(const void* qkv, const float* dout, float* dqkv, int B, int L, int heads, int head_dim, int causal, void* stream);
 int sc_quickgelu_f32(const float* z, void* y_or_dh, int64_t n, int backward, int out_bf16, void* stream);
 int sc_vq_st_bwd(const float* cos_scores, float* dprob_inout, float* rowdot, int R, int V, float temp, const int* mask_ids, int n_mask, void* stream);

@@ -79,7 +79,7 @@ struct MaskIds { int n; int id[8]; };
 
 // one block per row: arg-max (first index on ties), row max, log-sum-exp, entropy -sum p log(p + 1e-9)
 __global__ __launch_bounds__(256) void vq_row_kernel(const float* __restrict__ x, int64_t* __restrict__ targets, float* __restrict__ rmax,
-                                                     float* __restrict__ rsum, float* __restrict__ rent, int V, MaskIds mk) {
+                                                     float* __restrict__ rsum, float* __restrict__ rent, int* __restrict__ hist, int V, MaskIds mk) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ float s_red[4];
@@ -119,21 +119,34 @@ __global__ __launch_bounds__(256) void vq_row_kernel(const float* __restrict__ x
     __syncthreads();
     if (tid == 0) {
         targets[r] = bi;
+        atomicAdd(&hist[bi], 1);       // code usage counts (integer: order-independent)
         rmax[r] = best;
         rsum[r] = tot;
         rent[r] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     }
 }
 
-// avg_probs[v] = mean_r softmax(x[r,:])[v]; partial[b] = sum over this block's v of avg*log(avg + 1e-7)
+// avg_probs[v] = mean_r softmax(x[r,:])[v].  The rows are split over blockIdx.y (a column per thread alone leaves 193 blocks walking 2048
+// rows each); the per-split sums go to colpart [nsplit, V] and are added in a fixed order by vq_col_finish_kernel (deterministic).
 __global__ __launch_bounds__(256) void vq_col_kernel(const float* __restrict__ x, const float* __restrict__ rmax, const float* __restrict__ rsum,
-                                                     float* __restrict__ partial, int R, int V, MaskIds mk) {
+                                                     float* __restrict__ colpart, int R, int V, int rows_per_split) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const int r0 = blockIdx.y * rows_per_split, r1 = min(R, r0 + rows_per_split);
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += __expf(x[(int64_t)r * V + v] - rmax[r]) / rsum[r];
+    colpart[(int64_t)blockIdx.y * V + v] = acc;
+}
+
+// partial[b] = sum over this block's v of avg*log(avg + 1e-7)
+__global__ __launch_bounds__(256) void vq_col_finish_kernel(const float* __restrict__ colpart, float* __restrict__ partial, int nsplit, int R, int V,
+                                                            MaskIds mk) {
     __shared__ float s_red[4];
     const int v = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float term = 0.f;
     if (v < V && !is_masked(v, mk.id, mk.n)) {
         float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc += __expf(x[(int64_t)r * V + v] - rmax[r]) / rsum[r];
+        for (int i = 0; i < nsplit; ++i) acc += colpart[(int64_t)i * V + v];
         const float avg = acc / (float)R;
         term = avg * logf(avg + 1e-7f);
     }
@@ -144,15 +157,14 @@ __global__ __launch_bounds__(256) void vq_col_kernel(const float* __restrict__ x
 }
 
 // stats[0] = code perplexity, stats[1] = prob perplexity; ent_per_t[k] = mean_b rent[b*K + k]
-__global__ __launch_bounds__(256) void vq_final_kernel(const int64_t* __restrict__ targets, const float* __restrict__ rent, const float* __restrict__ partial,
-                                                       int nparts, float* __restrict__ stats, float* __restrict__ ent_per_t, int R, int K) {
+__global__ __launch_bounds__(256) void vq_final_kernel(const int64_t* __restrict__ targets, const int* __restrict__ hist, const float* __restrict__ rent,
+                                                       const float* __restrict__ partial, int nparts, float* __restrict__ stats,
+                                                       float* __restrict__ ent_per_t, int R, int K) {
     __shared__ float s_red[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float acc = 0.f;
     for (int r = tid; r < R; r += 256) {
-        const int64_t t = targets[r];
-        int cnt = 0;
-        for (int q = 0; q < R; ++q) cnt += (targets[q] == t);
+        const int cnt = hist[targets[r]];
         acc += logf((float)cnt / (float)R + 1e-7f);      // sum_v hp log(hp + eps) = (1/R) sum_r log(cnt_r/R + eps)
     }
     acc = wave_sum(acc);
@@ -202,7 +214,8 @@ extern "C" int sc_cosine_scores(const float* a, const float* emb, void* workspac
     return 0;
 }
 
-extern "C" int64_t sc_vq_workspace_bytes(int R, int V) { return ((int64_t)3 * R + (V + 255) / 256) * 4; }
+static int vq_nsplit(int R) { return R >= 1024 ? 32 : (R >= 64 ? 8 : 1); }
+extern "C" int64_t sc_vq_workspace_bytes(int R, int V) { return ((int64_t)3 * R + (V + 255) / 256 + (int64_t)V * (1 + vq_nsplit(R))) * 4; }
 
 extern "C" int sc_vq_fwd(const float* scores, int64_t* targets, float* stats2, float* ent_per_t, void* workspace, int R, int K, int V,
                          const int32_t* host_mask_ids, int n_mask, void* stream) {
@@ -215,11 +228,15 @@ extern "C" int sc_vq_fwd(const float* scores, int64_t* targets, float* stats2, f
     float* rsum = rmax + R;
     float* rent = rsum + R;
     float* partial = rent + R;
-    const int nparts = (V + 255) / 256;
+    const int nparts = (V + 255) / 256, nsplit = vq_nsplit(R), rps = (R + nsplit - 1) / nsplit;
+    int* hist = (int*)(partial + nparts);
+    float* colpart = (float*)(hist + V);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(vq_row_kernel, dim3(R), dim3(256), 0, s, scores, targets, rmax, rsum, rent, V, mk);
-    hipLaunchKernelGGL(vq_col_kernel, dim3(nparts), dim3(256), 0, s, scores, rmax, rsum, partial, R, V, mk);
-    hipLaunchKernelGGL(vq_final_kernel, dim3(1), dim3(256), 0, s, targets, rent, partial, nparts, stats2, ent_per_t, R, K);
+    SC_CHECK_ARG(hipMemsetAsync(hist, 0, (size_t)V * 4, s) == hipSuccess, "sc_vq_fwd: hipMemsetAsync failed");
+    hipLaunchKernelGGL(vq_row_kernel, dim3(R), dim3(256), 0, s, scores, targets, rmax, rsum, rent, hist, V, mk);
+    hipLaunchKernelGGL(vq_col_kernel, dim3(nparts, nsplit), dim3(256), 0, s, scores, rmax, rsum, colpart, R, V, rps);
+    hipLaunchKernelGGL(vq_col_finish_kernel, dim3(nparts), dim3(256), 0, s, colpart, partial, nsplit, R, V, mk);
+    hipLaunchKernelGGL(vq_final_kernel, dim3(1), dim3(256), 0, s, targets, hist, rent, partial, nparts, stats2, ent_per_t, R, K);
     SC_CHECK_LAUNCH();
     return 0;
 }

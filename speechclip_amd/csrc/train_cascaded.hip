@@ -1,7 +1,7 @@
 // Training kernels of the cascaded tail (kwClip.py:697-916): the backward path from the CLIP text feature to
 // the keyword embeddings -- causal attention backward over the K+2 live positions, QuickGELU, the straight-through VQ
 // (my_vector_quantizer.py:133-141), the cosine-similarity backward and the train-mode keyword BatchNorm (kw_bn.py:122-131).  All fp32;
-// every dense product around them is sc_sgemm.  Sizes: B x (K+2) = 2560 text rows, B x K = 2048 keyword rows, V <= 49408 sub-words.
+// the dense products around them run on the MFMA GEMM with the fp32 gradient split into (hi | lo) bf16 terms (split_hilo_kernel).  Sizes: B x (K+2) = 2560 text rows, B x K = 2048 keyword rows, V <= 49408 sub-words.
 #include "common.h"
 
 namespace {
@@ -75,6 +75,23 @@ __global__ __launch_bounds__(256) void quickgelu_kernel(const float* __restrict_
     } else {
         ((float*)y)[i] = x * s;
     }
+}
+
+// out bf16 [M, 2K] = (hi | lo) with hi = bf16(a), lo = bf16(a - hi): the two-term operand of the backward products (a @ W^T = [hi|lo] @ [W|W]^T,
+// ~16 mantissa bits of the gradient survive the bf16 MFMA GEMM).  K % 4 == 0.
+__global__ __launch_bounds__(256) void split_hilo_kernel(const float* __restrict__ a, int64_t lda, bf16_t* __restrict__ out, int64_t M, int K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int kq = K / 4;
+    if (i >= M * kq) return;
+    const int64_t r = i / kq;
+    const int c = (int)(i % kq) * 4;
+    const f32x4_t v = *(const f32x4_t*)(a + r * lda + c);
+    uint2 h, l;
+    h.x = pack2bf(v[0], v[1]); h.y = pack2bf(v[2], v[3]);
+    l.x = pack2bf(v[0] - lo2f(h.x), v[1] - hi2f(h.x));
+    l.y = pack2bf(v[2] - lo2f(h.y), v[3] - hi2f(h.y));
+    *(uint2*)(out + r * 2 * K + c) = h;
+    *(uint2*)(out + r * 2 * K + K + c) = l;
 }
 
 struct MaskIds { int n; int id[8]; };
@@ -239,6 +256,15 @@ extern "C" int sc_kw_bn_bwd(const float* x, const float* dy, const float* gamma,
                             int B, int K, int E, void* stream) {
     SC_CHECK_ARG(B >= 1 && K >= 1 && E >= 1, "sc_kw_bn_bwd: bad shape B=%d K=%d E=%d", B, K, E);
     hipLaunchKernelGGL(kw_bn_bwd_kernel, dim3((K * E + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, dy, gamma, mean, rstd, dx, dgamma, dbeta, B, K, E);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_split_hilo_bf16(const float* a, int64_t lda, void* out, int64_t M, int K, void* stream) {
+    SC_CHECK_ARG(K > 0 && K % 4 == 0 && lda % 4 == 0, "sc_split_hilo_bf16: K=%d and lda must be multiples of 4", K);
+    if (M <= 0) return 0;
+    const int64_t n = M * (K / 4);
+    hipLaunchKernelGGL(split_hilo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, lda, (bf16_t*)out, M, K);
     SC_CHECK_LAUNCH();
     return 0;
 }

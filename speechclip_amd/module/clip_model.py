@@ -146,27 +146,32 @@ class CLIP(nn.Module):
         nn.init.normal_(self.positional_embedding, std=0.01)
         nn.init.normal_(self.text_projection, std=cfg.text_width ** -0.5)
         self._packed = None
-        self._packed_f32 = None
+        self._packed_bwd = None
         self.register_load_state_dict_post_hook(lambda module, keys: module.invalidate_packed())
 
     def invalidate_packed(self):
         self._packed = None
-        self._packed_f32 = None
+        self._packed_bwd = None
 
-    def packed_f32(self, dev):
-        """fp32 copies of the (frozen) text-tower weights for the backward pass of the cascaded tail (train_tail.TextTowerTrainFn)."""
-        if getattr(self, "_packed_f32", None) is None:
-            f32 = torch.float32
-            c = lambda t: t.detach().to(dev, f32).contiguous()   # noqa: E731
-            self._packed_f32 = dict(
-                txt=[dict(g1=c(b.ln_1.weight), wqkv=c(b.attn.in_proj_weight), wo=c(b.attn.out_proj.weight), g2=c(b.ln_2.weight),
-                          w1=c(b.mlp.c_fc.weight), w2=c(b.mlp.c_proj.weight)) for b in self.transformer.resblocks],
-                ln_final_g=c(self.ln_final.weight), txt_proj_t=c(self.text_projection.t()))
-        return self._packed_f32
+    def packed_bwd(self, dev):
+        """Operands of the text tower's input-gradient pass (train_tail.TextTowerTrainFn): [W^T | W^T] as bf16 [in, 2 out] for dX = dY @ W on
+        the MFMA GEMM with hi+lo split gradients (frozen weights, built once), fp32 LayerNorm gains."""
+        if getattr(self, "_packed_bwd", None) is None:
+            f32, bf = torch.float32, torch.bfloat16
+            c = lambda t: t.detach().to(dev, f32).contiguous()          # noqa: E731
+            def t16(t):       # [W^T | W^T] bf16 [in, 2*out]: pairs with the (hi | lo) split of the incoming gradient
+                wt = t.detach().to(dev, f32).t().contiguous().to(bf)
+                return torch.cat([wt, wt], dim=1).contiguous()
+
+            self._packed_bwd = dict(
+                txt=[dict(g1=c(b.ln_1.weight), wqkvt=t16(b.attn.in_proj_weight), wot=t16(b.attn.out_proj.weight), g2=c(b.ln_2.weight),
+                          w1t=t16(b.mlp.c_fc.weight), w2t=t16(b.mlp.c_proj.weight)) for b in self.transformer.resblocks],
+                ln_final_g=c(self.ln_final.weight), txt_proj=t16(self.text_projection.t()))
+        return self._packed_bwd
 
     def _apply(self, fn, *a, **k):
         self._packed = None
-        self._packed_f32 = None
+        self._packed_bwd = None
         return super()._apply(fn, *a, **k)
 
     @property

@@ -486,6 +486,16 @@ def attn_small_bwd(qkv16, dout, B, L, H, causal=True):
     return dqkv
 
 
+def split_hilo(a):
+    """a f32 [M,K] (row stride allowed) -> bf16 [M, 2K] = (hi | lo), hi + lo = a to ~16 bits."""
+    _need_cuda(a)
+    assert a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1
+    M, K = a.shape
+    out = torch.empty(M, 2 * K, device=a.device, dtype=bf16)
+    check(lib().sc_split_hilo_bf16(ptr(a), a.stride(0), ptr(out), M, K, stream()), "sc_split_hilo_bf16")
+    return out
+
+
 def quickgelu_f32(z, out_bf16=False):
     _f32c(z)
     y = torch.empty(z.shape, device=z.device, dtype=bf16 if out_bf16 else torch.float32)

@@ -34,128 +34,20 @@ def _c(t):
     return t.detach().float().contiguous()
 
 
-class ParallelBranchTrainFn(torch.autograd.Function):
-    """out f32 [B, E (or D)] = linear_proj(norm(layer([CLS; mix(hidden)]))[:, 0]).
+def _dup_k(w16: torch.Tensor) -> torch.Tensor:
+    """[W | W] bf16 [N, 2K]: the weight operand that pairs with ops.split_hilo."""
+    return torch.cat([w16, w16], dim=1).contiguous()
 
-    args: meta (dict: heads, eps, drop_p, seed, normalize), hidden bf16 [n, B, Tp, D] (frozen encoder states) or None,
-          x16 bf16 [B, T<=Tp, D] view of the mixed frames (what WeightedSumLayer produced from `hidden`), lens int [B],
-          then tensors: mixw [n] | None, cls [1,1,D], in_w [3D,D], in_b [3D], out_w, out_b, n1w, n1b, l1w, l1b, l2w, l2b, n2w, n2b,
-          nfw, nfb, pw [E,D] | None, pb [E] | None."""
 
-    @staticmethod
-    def forward(ctx, meta, hidden, x16, lens, mixw, cls, in_w, in_b, out_w, out_b, n1w, n1b, l1w, l1b, l2w, l2b, n2w, n2b, nfw, nfb, pw, pb):
-        from .module.kw_modules.TransformerModels import _frames_view
-        H, eps, pd, seed = meta["heads"], meta["eps"], float(meta["drop_p"]), int(meta["seed"])
-        B, T, D = x16.shape
-        NQ = cls.shape[-2]
-        assert NQ == 1, "the parallel branch has one CLS token (kwClip.py:1040-1047)"
-        hd, R = D // H, NQ * H
-        scale = hd ** -0.5
-        rows, Tp = _frames_view(x16)
-        dev = rows.device
-        lens_i = lens.to(device=dev, dtype=torch.int32).contiguous()
-        c = _c(cls).view(NQ, D)
-        Win, bin_ = _c(in_w), _c(in_b)
-        # ---- parameter-only part: queries of the CLS token, u_r = scale Wk_h^T q_h, beta_r = scale q_h . bk_h
-        qt = ops.sgemm(c, Win[:D], transb=True, bias=bin_[:D])                              # [NQ, D]
-        U = torch.empty(R, D, device=dev, dtype=torch.float32)                               # rows r = q*H + h
-        beta = torch.empty(R, device=dev, dtype=torch.float32)
-        Wk, bk, Wv, bv = Win[D:2 * D], bin_[D:2 * D], Win[2 * D:], bin_[2 * D:]
-        ops.sgemm_batched(NQ, D, hd, qt, D, hd, Wk, D, hd * D, U, H * D, D, H, alpha=scale)                      # U[q,h,:] = scale q_h^T Wk_h
-        ops.sgemm_batched(NQ, 1, hd, qt, D, hd, bk, 1, hd, beta, H, 1, H, alpha=scale)                             # beta[q,h] = scale q_h . bk_h
-        # ---- frame scores on the MFMA GEMM (bf16 frames x bf16 u, fp32 accumulate/out), pooling in fp32
-        scores = ops.gemm(rows, U.to(BF).contiguous(), beta, out_f32=True)                    # [B*Tp, R]
-        cls_scores = ops.sgemm(c, U, transb=True, bias=beta)                                  # [NQ, R]
-        p, zbar = ops.cls_pool_train_fwd(rows, c, scores, cls_scores, lens_i, B, Tp, NQ, R, D, pd, seed)
-        att = torch.empty(B * NQ, D, device=dev, dtype=torch.float32)
-        ops.sgemm_batched(B, hd, D, zbar, R * D, D, Wv, D, hd * D, att, D, hd, H, transb=True, bias=bv, stride_bias=hd)   # o_h = Wv_h zbar_h + bv_h
-        # ---- rest of the encoder layer on the CLS rows (post-LN), final norm, projection
-        sa = ops.sgemm(att, _c(out_w), transb=True, bias=_c(out_b))
-        if pd > 0:
-            ops.dropout_f32(sa, pd, seed + 1, out=sa)
-        y = ops.add_rows(sa, c)                                                               # x + dropout1(SA(x)), x = CLS token
-        x1 = ops.layernorm(y, _c(n1w), _c(n1b), eps, out_f32=True)
-        z1 = ops.sgemm(x1, _c(l1w), transb=True, bias=_c(l1b))
-        hm = ops.gelu_f32(z1)
-        if pd > 0:
-            ops.dropout_f32(hm, pd, seed + 2, out=hm)
-        ff = ops.sgemm(hm, _c(l2w), transb=True, bias=_c(l2b))
-        if pd > 0:
-            ops.dropout_f32(ff, pd, seed + 3, out=ff)
-        y2 = ops.add_rows(ff, x1)
-        x2 = ops.layernorm(y2, _c(n2w), _c(n2b), eps, out_f32=True)
-        x3 = ops.layernorm(x2, _c(nfw), _c(nfb), 1e-5, out_f32=True)
-        out = ops.sgemm(x3, _c(pw), transb=True, bias=_c(pb)) if pw is not None else x3.clone()
-        ctx.meta = dict(meta, B=B, Tp=Tp, D=D, NQ=NQ, R=R, hd=hd, scale=scale)
-        ctx.hidden = hidden
-        ctx.has = (mixw is not None, pw is not None)
-        ctx.save_for_backward(rows, lens_i, c, Win, qt, U, p, zbar, att, y, x1, z1, hm, y2, x2, x3,
-                              _c(out_w), _c(n1w), _c(l1w), _c(l2w), _c(n2w), _c(nfw), _c(pw) if pw is not None else c,
-                              _c(mixw) if mixw is not None else c)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        (rows, lens_i, c, Win, qt, U, p, zbar, att, y, x1, z1, hm, y2, x2, x3, Wo, g1, W1, W2, g2, gf, Wp, mixw) = ctx.saved_tensors
-        m = ctx.meta
-        B, Tp, D, NQ, R, hd, H, scale, eps, pd, seed = m["B"], m["Tp"], m["D"], m["NQ"], m["R"], m["hd"], m["heads"], m["scale"], m["eps"], float(m["drop_p"]), int(m["seed"])
-        has_mix, has_proj = ctx.has
-        dev = rows.device
-        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)   # noqa: E731
-        dout = dout.float().contiguous()
-        # projection, final norm, norm2
-        if has_proj:
-            dpw = ops.sgemm(dout, x3, transa=True)
-            dpb = ops.colsum(dout)
-            dx3 = ops.sgemm(dout, Wp)
-        else:
-            dpw = dpb = None
-            dx3 = dout
-        dnfw, dnfb, dn2w, dn2b, dn1w, dn1b = z(D), z(D), z(D), z(D), z(D), z(D)
-        dx2 = ops.layernorm_bwd(x2, dx3, gf, dnfw, dnfb, 1e-5)
-        dy2 = ops.layernorm_bwd(y2, dx2, g2, dn2w, dn2b, eps)
-        # FFN
-        dff = ops.dropout_f32(dy2, pd, seed + 3) if pd > 0 else dy2
-        dl2w = ops.sgemm(dff, hm, transa=True)
-        dl2b = ops.colsum(dff)
-        dhm = ops.sgemm(dff, W2)
-        if pd > 0:
-            ops.dropout_f32(dhm, pd, seed + 2, out=dhm)
-        ops.gelu_bwd_(z1, dhm)                                                              # dhm is now dz1
-        dl1w = ops.sgemm(dhm, x1, transa=True)
-        dl1b = ops.colsum(dhm)
-        dx1 = ops.sgemm(dhm, W1, beta=1.0, out=dy2.clone())                                   # residual + through linear1
-        dy = ops.layernorm_bwd(y, dx1, g1, dn1w, dn1b, eps)
-        # attention block: y = c + dropout1(att Wo^T + bo)
-        dcls = ops.colsum(dy).view(NQ, D)
-        dsa = ops.dropout_f32(dy, pd, seed + 1) if pd > 0 else dy
-        dWo = ops.sgemm(dsa, att, transa=True)
-        dbo = ops.colsum(dsa)
-        datt = ops.sgemm(dsa, Wo)
-        dWin, dbin = z(3 * D, D), z(3 * D)
-        dzbar = torch.empty(B, R, D, device=dev, dtype=torch.float32)
-        Wk, Wv = Win[D:2 * D], Win[2 * D:]
-        ops.sgemm_batched(hd, D, B, datt, D, hd, zbar, R * D, D, dWin[2 * D:], D, hd * D, H, transa=True)        # dWv_h = datt_h^T zbar_h
-        ops.colsum(datt, out=dbin[2 * D:])
-        ops.sgemm_batched(B, D, hd, datt, D, hd, Wv, D, hd * D, dzbar, R * D, D, H)                               # dzbar_h = datt_h Wv_h
-        hid = ctx.hidden
-        hid2 = hid.reshape(hid.shape[0], B * Tp, D) if (has_mix and hid is not None) else None
-        du, dck, dalpha = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)), drop_p=pd, seed=seed)
-        dU = ops.colsum(du.view(-1, R * D)).view(R, D)                                        # rows: B x key-splits
-        ops.colsum(dck.view(-1, NQ * D), out=dcls.view(NQ * D), accumulate=True)               # CLS token as a key / value
-        # parameter-only chain: u_r = scale Wk_h^T q_h (beta carries no gradient: softmax is shift invariant)
-        dqt = torch.empty(NQ, D, device=dev, dtype=torch.float32)
-        ops.sgemm_batched(hd, D, NQ, qt, D, hd, dU, H * D, D, dWin[D:2 * D], D, hd * D, H, transa=True, alpha=scale)   # dWk_h = scale q_h (x) dU_h
-        ops.sgemm_batched(NQ, hd, D, dU, H * D, D, Wk, D, hd * D, dqt, D, hd, H, transb=True, alpha=scale)             # dq_h = scale Wk_h dU_h
-        ops.sgemm(dqt, c, transa=True, out=dWin[:D])
-        ops.colsum(dqt, out=dbin[:D])
-        ops.sgemm(dqt, Win[:D], beta=1.0, out=dcls)
-        dmix = None
-        if has_mix and dalpha is not None:
-            dmix = z(mixw.shape[0])
-            ops.mix_softmax_bwd(mixw, dalpha, dmix)
-        return (None, None, None, None, dmix, dcls.view(1, NQ, D), dWin, dbin, dWo, dbo, dn1w, dn1b, dl1w, dl1b, dl2w, dl2b, dn2w, dn2b, dnfw, dnfb,
-                dpw, dpb)
+def _mfma_f32(a: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """f32 [M,N] = a f32 [M,K] @ W^T on the MFMA GEMM, W given as w2 = [W | W] bf16 [N, 2K] (frozen): a is split into two bf16 terms
+    (hi | lo) by sc_split_hilo_bf16 and ONE GEMM of depth 2K adds both products (the gradient keeps ~16 mantissa bits; a single bf16
+    term would put 0.4 % noise on every backward product).  Shapes the GEMM kernel does not take (2K % 64, N % 4: reduced test
+    vocabularies) go to the fp32 SIMT sgemm."""
+    N, K2 = w2.shape
+    if K2 % 64 or N % 4:
+        return ops.sgemm(a, w2[:, :K2 // 2].float().contiguous(), transb=True)
+    return ops.gemm(ops.split_hilo(a), w2, out_f32=True)
 
 
 # ================================================================= cascaded tail (kwClip.py:697-916)
@@ -269,6 +161,24 @@ class KwBatchNormTrainFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None
 
 
+_VQ_TABLES = {}
+
+
+def _vq_tables(emb):
+    """GEMM operands of the VQ backward for the frozen sub-word table (rebuilt if the table object or its version changes):
+    [emb | emb] bf16 [V, 2E] and [(emb/|emb|)^T | same] bf16 [E, 2V]."""
+    import weakref
+    key = emb.data_ptr()
+    hit = _VQ_TABLES.get(key)
+    if hit is not None and hit[0] == (emb._version, tuple(emb.shape)) and hit[2]() is emb:
+        return hit[1]
+    e = emb.detach().float().contiguous()
+    out = (_dup_k(e.to(BF)), _dup_k(ops.l2norm(e).t().contiguous().to(BF)))
+    _VQ_TABLES.clear()
+    _VQ_TABLES[key] = ((emb._version, tuple(emb.shape)), out, weakref.ref(emb))
+    return out
+
+
 class KeywordSTFn(torch.autograd.Function):
     """keywords [R,E] = subword_prob @ emb with the straight-through estimator of SimpleVectorQuantizer in train mode
     (hard one-hot forward, softmax(cos/temp) backward; my_vector_quantizer.py:133-141, kwClip.py:909-911) and the cosine similarity behind it
@@ -283,17 +193,18 @@ class KeywordSTFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dkw):
         kb, cos, emb = ctx.saved_tensors
-        embf = emb.detach().float().contiguous()
-        dprob = ops.sgemm(dkw.float().contiguous(), embf, transb=True)                       # d loss / d subword_prob  [R, V]
+        E2, U2 = _vq_tables(emb)
+        dprob = _mfma_f32(dkw.float().contiguous(), E2)                                       # d loss / d subword_prob = dkw @ emb^T  [R, V]
         rowdot = ops.vq_st_bwd_(cos, dprob, ctx.temp, ctx.mask_ids)                           # dprob is now d loss / d cos
-        G = ops.sgemm(dprob, ops.l2norm(embf))
+        G = _mfma_f32(dprob, U2)                                                              # dcos @ (emb / |emb|)  [R, E]
         return ops.cosine_bwd_finish(kb, G, rowdot), None, None, None, None, None
 
 
 class TextTowerTrainFn(torch.autograd.Function):
     """feat f32 [B, E] = (ln_final(text_transformer(emb + pos))[:, pos_index]) @ text_projection with the gradient w.r.t. the token
     embeddings `emb` f32 [B, L, W] (the tower itself is frozen: clip_official.py:220-264 under loss.backward()).  Forward on the bf16 MFMA
-    kernels (the eval path's rounding points), saving x / qkv / x_mid / pre-activation per layer; backward in fp32."""
+    kernels (the eval path's rounding points), saving x / qkv / x_mid / pre-activation per layer; backward: fp32 row ops, the dX products on
+    the MFMA GEMM against transposed bf16 copies of the frozen weights with hi+lo split gradients (_mfma_f32)."""
 
     @staticmethod
     def forward(ctx, clip, emb, pos_index):
@@ -326,21 +237,21 @@ class TextTowerTrainFn(torch.autograd.Function):
         rows, *saved = ctx.saved_tensors
         B, L, W, H, pos = ctx.dims
         dev = rows.device
-        F = ctx.clip.packed_f32(dev)
-        dn = ops.sgemm(dfeat.float().contiguous(), F["txt_proj_t"])                           # [B, W]
+        F = ctx.clip.packed_bwd(dev)
+        dn = _mfma_f32(dfeat.float().contiguous(), F["txt_proj"])                             # [B, W] = dfeat @ text_projection^T
         drows = ops.layernorm_bwd(rows, dn, F["ln_final_g"], eps=1e-5)
         dx = torch.zeros(B * L, W, device=dev, dtype=torch.float32)
         dx.view(B, L, W)[:, pos] = drows
         for li in range(len(F["txt"]) - 1, -1, -1):
             Ly = F["txt"][li]
             x, qkv, xm, u = saved[4 * li:4 * li + 4]
-            dh = ops.sgemm(dx, Ly["w2"])                                                     # [M, 4W]
+            dh = _mfma_f32(dx, Ly["w2t"])                                                    # [M, 4W] = dx @ W2
             ops.quickgelu_bwd_(u, dh)
-            dn2 = ops.sgemm(dh, Ly["w1"])
+            dn2 = _mfma_f32(dh, Ly["w1t"])
             ops.layernorm_bwd(xm, dn2, Ly["g2"], eps=1e-5, dx=dx, accumulate_dx=True)         # dx is now d loss / d x_mid
-            datt = ops.sgemm(dx, Ly["wo"])
+            datt = _mfma_f32(dx, Ly["wot"])
             dqkv = ops.attn_small_bwd(qkv, datt, B, L, H, True)
-            dn1 = ops.sgemm(dqkv, Ly["wqkv"])
+            dn1 = _mfma_f32(dqkv, Ly["wqkvt"])
             ops.layernorm_bwd(x, dn1, Ly["g1"], eps=1e-5, dx=dx, accumulate_dx=True)
         return None, dx.view(B, L, W), None
 

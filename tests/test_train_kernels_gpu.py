@@ -383,3 +383,62 @@ def test_kw_batchnorm_train_fwd_bwd(B, K, E):
     torch.testing.assert_close(dx, x.grad, atol=5e-5, rtol=1e-4)
     torch.testing.assert_close(dg, bn.weight.grad, atol=1e-4, rtol=1e-4)
     torch.testing.assert_close(db, bn.bias.grad, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("R,V,E", [(64, 1024, 64), (16, 49408, 512)])
+def test_keyword_st_fn_mfma_path(R, V, E):
+    """train_tail.KeywordSTFn end to end (the two [R,V] products on the MFMA GEMM with hi+lo split gradients) vs autograd of
+    (hard + soft - soft.detach()) @ emb, soft = softmax(masked cosine / 0.1)."""
+    import torch.nn.functional as F
+    from speechclip_amd import ops
+    from speechclip_amd.train_tail import KeywordSTFn
+    g = torch.Generator().manual_seed(R + V + 1)
+    emb = torch.nn.Parameter(torch.randn(V, E, generator=g).to(dev()), requires_grad=False)
+    a = (torch.randn(R, E, generator=g) + 0.3).to(dev()).requires_grad_(True)
+    dkw = torch.randn(R, E, generator=g).to(dev())
+    cos = F.cosine_similarity(a.unsqueeze(2), emb.t().unsqueeze(0), dim=1)
+    x = cos.clone()
+    x[:, [0, 2, 3]] = float("-inf")
+    tgt = x.argmax(-1)
+    soft = torch.softmax(x / 0.1, -1)
+    kw = (torch.zeros_like(x).scatter_(-1, tgt[:, None], 1.0) + soft - soft.detach()) @ emb
+    kw.backward(dkw)
+    a2 = a.detach().clone().requires_grad_(True)
+    cos2 = ops.cosine_scores(a2.detach(), emb)
+    kw2 = KeywordSTFn.apply(a2, cos2, tgt, emb, 0.1, (0, 2, 3))
+    torch.testing.assert_close(kw2, kw.detach(), atol=1e-5, rtol=1e-5)
+    kw2.backward(dkw)
+    scale = a.grad.abs().max().item()
+    err = (a2.grad - a.grad).abs().max().item()
+    assert err < 2e-3 * scale, (err, scale)          # bf16 sub-word table inside the two products (hi+lo split on the gradient side)
+
+
+def test_text_tower_input_gradient_vit_b32_dims():
+    """TextTowerTrainFn at the real ViT-B/32 text-tower size (12 layers, width 512, 8 heads; K + 2 = 10 live positions): feature and
+    d feature / d token-embeddings vs the fp32 oracle tower (oracle/clip_ref.py) on the same weights."""
+    from oracle import clip_ref
+    from speechclip_amd.module.clip_model import CLIP, ClipConfig
+    torch.manual_seed(11)
+    mine = CLIP(ClipConfig.from_name("ViT-B/32")).eval()
+    ref = clip_ref.ClipRef(clip_ref.ClipRefConfig.vit_b32()).eval()
+    ref.load_state_dict(mine.state_dict())
+    mine = mine.to(dev())
+    B, L, W = 5, 10, 512
+    g = torch.Generator().manual_seed(3)
+    emb = (0.05 * torch.randn(B, L, W, generator=g))
+    dfeat = torch.randn(B, 512, generator=g)
+    e_ref = emb.clone().requires_grad_(True)
+    x = torch.zeros(B, 77, W)
+    x = torch.cat([e_ref, x[:, L:]], dim=1) + ref.positional_embedding
+    x = ref.ln_final(ref.transformer(x.permute(1, 0, 2)).permute(1, 0, 2))
+    f_ref = x[:, L - 1] @ ref.text_projection
+    f_ref.backward(dfeat)
+    e_mine = emb.clone().to(dev()).requires_grad_(True)
+    f = mine.encode_text_embeddings(e_mine, torch.full((B,), L - 1, device=dev(), dtype=torch.long))
+    assert f.requires_grad
+    cos = torch.nn.functional.cosine_similarity(f.detach().cpu().double(), f_ref.detach().double(), dim=-1).min().item()
+    assert cos > 0.999, cos
+    f.backward(dfeat.to(dev()))
+    gm, gr = e_mine.grad.cpu().double(), e_ref.grad.double()
+    assert torch.nn.functional.cosine_similarity(gm.reshape(1, -1), gr.reshape(1, -1)).item() > 0.999
+    assert abs(gm.norm().item() / gr.norm().item() - 1) < 0.02
