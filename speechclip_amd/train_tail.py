@@ -50,6 +50,130 @@ def _mfma_f32(a: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     return ops.gemm(ops.split_hilo(a), w2, out_f32=True)
 
 
+class ParallelBranchTrainFn(torch.autograd.Function):
+    """out f32 [B, E (or D)] = linear_proj(norm(layer([CLS; mix(hidden)]))[:, 0]).
+
+    args: meta (dict: heads, eps, drop_p, seed, normalize), hidden bf16 [n, B, Tp, D] (frozen encoder states) or None,
+          x16 bf16 [B, T<=Tp, D] view of the mixed frames (what WeightedSumLayer produced from `hidden`), lens int [B],
+          then tensors: mixw [n] | None, cls [1,1,D], in_w [3D,D], in_b [3D], out_w, out_b, n1w, n1b, l1w, l1b, l2w, l2b, n2w, n2b,
+          nfw, nfb, pw [E,D] | None, pb [E] | None."""
+
+    @staticmethod
+    def forward(ctx, meta, hidden, x16, lens, mixw, cls, in_w, in_b, out_w, out_b, n1w, n1b, l1w, l1b, l2w, l2b, n2w, n2b, nfw, nfb, pw, pb):
+        from .module.kw_modules.TransformerModels import _frames_view
+        H, eps, pd, seed = meta["heads"], meta["eps"], float(meta["drop_p"]), int(meta["seed"])
+        B, T, D = x16.shape
+        NQ = cls.shape[-2]
+        assert NQ == 1, "the parallel branch has one CLS token (kwClip.py:1040-1047)"
+        hd, R = D // H, NQ * H
+        scale = hd ** -0.5
+        rows, Tp = _frames_view(x16)
+        dev = rows.device
+        lens_i = lens.to(device=dev, dtype=torch.int32).contiguous()
+        c = _c(cls).view(NQ, D)
+        Win, bin_ = _c(in_w), _c(in_b)
+        # ---- parameter-only part: queries of the CLS token, u_r = scale Wk_h^T q_h, beta_r = scale q_h . bk_h
+        qt = ops.sgemm(c, Win[:D], transb=True, bias=bin_[:D])                              # [NQ, D]
+        U = torch.empty(R, D, device=dev, dtype=torch.float32)                               # rows r = q*H + h
+        beta = torch.empty(R, device=dev, dtype=torch.float32)
+        Wk, bk, Wv, bv = Win[D:2 * D], bin_[D:2 * D], Win[2 * D:], bin_[2 * D:]
+        ops.sgemm_batched(NQ, D, hd, qt, D, hd, Wk, D, hd * D, U, H * D, D, H, alpha=scale)                      # U[q,h,:] = scale q_h^T Wk_h
+        ops.sgemm_batched(NQ, 1, hd, qt, D, hd, bk, 1, hd, beta, H, 1, H, alpha=scale)                             # beta[q,h] = scale q_h . bk_h
+        # ---- frame scores on the MFMA GEMM (bf16 frames x bf16 u, fp32 accumulate/out), pooling in fp32
+        scores = ops.gemm(rows, U.to(BF).contiguous(), beta, out_f32=True)                    # [B*Tp, R]
+        cls_scores = ops.sgemm(c, U, transb=True, bias=beta)                                  # [NQ, R]
+        p, zbar = ops.cls_pool_train_fwd(rows, c, scores, cls_scores, lens_i, B, Tp, NQ, R, D, pd, seed)
+        att = torch.empty(B * NQ, D, device=dev, dtype=torch.float32)
+        ops.sgemm_batched(B, hd, D, zbar, R * D, D, Wv, D, hd * D, att, D, hd, H, transb=True, bias=bv, stride_bias=hd)   # o_h = Wv_h zbar_h + bv_h
+        # ---- rest of the encoder layer on the CLS rows (post-LN), final norm, projection
+        sa = ops.sgemm(att, _c(out_w), transb=True, bias=_c(out_b))
+        if pd > 0:
+            ops.dropout_f32(sa, pd, seed + 1, out=sa)
+        y = ops.add_rows(sa, c)                                                               # x + dropout1(SA(x)), x = CLS token
+        x1 = ops.layernorm(y, _c(n1w), _c(n1b), eps, out_f32=True)
+        z1 = ops.sgemm(x1, _c(l1w), transb=True, bias=_c(l1b))
+        hm = ops.gelu_f32(z1)
+        if pd > 0:
+            ops.dropout_f32(hm, pd, seed + 2, out=hm)
+        ff = ops.sgemm(hm, _c(l2w), transb=True, bias=_c(l2b))
+        if pd > 0:
+            ops.dropout_f32(ff, pd, seed + 3, out=ff)
+        y2 = ops.add_rows(ff, x1)
+        x2 = ops.layernorm(y2, _c(n2w), _c(n2b), eps, out_f32=True)
+        x3 = ops.layernorm(x2, _c(nfw), _c(nfb), 1e-5, out_f32=True)
+        out = ops.sgemm(x3, _c(pw), transb=True, bias=_c(pb)) if pw is not None else x3.clone()
+        ctx.meta = dict(meta, B=B, Tp=Tp, D=D, NQ=NQ, R=R, hd=hd, scale=scale)
+        ctx.hidden = hidden
+        ctx.has = (mixw is not None, pw is not None)
+        ctx.save_for_backward(rows, lens_i, c, Win, qt, U, p, zbar, att, y, x1, z1, hm, y2, x2, x3,
+                              _c(out_w), _c(n1w), _c(l1w), _c(l2w), _c(n2w), _c(nfw), _c(pw) if pw is not None else c,
+                              _c(mixw) if mixw is not None else c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rows, lens_i, c, Win, qt, U, p, zbar, att, y, x1, z1, hm, y2, x2, x3, Wo, g1, W1, W2, g2, gf, Wp, mixw) = ctx.saved_tensors
+        m = ctx.meta
+        B, Tp, D, NQ, R, hd, H, scale, eps, pd, seed = m["B"], m["Tp"], m["D"], m["NQ"], m["R"], m["hd"], m["heads"], m["scale"], m["eps"], float(m["drop_p"]), int(m["seed"])
+        has_mix, has_proj = ctx.has
+        dev = rows.device
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)   # noqa: E731
+        dout = dout.float().contiguous()
+        # projection, final norm, norm2
+        if has_proj:
+            dpw = ops.sgemm(dout, x3, transa=True)
+            dpb = ops.colsum(dout)
+            dx3 = ops.sgemm(dout, Wp)
+        else:
+            dpw = dpb = None
+            dx3 = dout
+        dnfw, dnfb, dn2w, dn2b, dn1w, dn1b = z(D), z(D), z(D), z(D), z(D), z(D)
+        dx2 = ops.layernorm_bwd(x2, dx3, gf, dnfw, dnfb, 1e-5)
+        dy2 = ops.layernorm_bwd(y2, dx2, g2, dn2w, dn2b, eps)
+        # FFN
+        dff = ops.dropout_f32(dy2, pd, seed + 3) if pd > 0 else dy2
+        dl2w = ops.sgemm(dff, hm, transa=True)
+        dl2b = ops.colsum(dff)
+        dhm = ops.sgemm(dff, W2)
+        if pd > 0:
+            ops.dropout_f32(dhm, pd, seed + 2, out=dhm)
+        ops.gelu_bwd_(z1, dhm)                                                              # dhm is now dz1
+        dl1w = ops.sgemm(dhm, x1, transa=True)
+        dl1b = ops.colsum(dhm)
+        dx1 = ops.sgemm(dhm, W1, beta=1.0, out=dy2.clone())                                   # residual + through linear1
+        dy = ops.layernorm_bwd(y, dx1, g1, dn1w, dn1b, eps)
+        # attention block: y = c + dropout1(att Wo^T + bo)
+        dcls = ops.colsum(dy).view(NQ, D)
+        dsa = ops.dropout_f32(dy, pd, seed + 1) if pd > 0 else dy
+        dWo = ops.sgemm(dsa, att, transa=True)
+        dbo = ops.colsum(dsa)
+        datt = ops.sgemm(dsa, Wo)
+        dWin, dbin = z(3 * D, D), z(3 * D)
+        dzbar = torch.empty(B, R, D, device=dev, dtype=torch.float32)
+        Wk, Wv = Win[D:2 * D], Win[2 * D:]
+        ops.sgemm_batched(hd, D, B, datt, D, hd, zbar, R * D, D, dWin[2 * D:], D, hd * D, H, transa=True)        # dWv_h = datt_h^T zbar_h
+        ops.colsum(datt, out=dbin[2 * D:])
+        ops.sgemm_batched(B, D, hd, datt, D, hd, Wv, D, hd * D, dzbar, R * D, D, H)                               # dzbar_h = datt_h Wv_h
+        hid = ctx.hidden
+        hid2 = hid.reshape(hid.shape[0], B * Tp, D) if (has_mix and hid is not None) else None
+        du, dck, dalpha = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)), drop_p=pd, seed=seed)
+        dU = ops.colsum(du.view(-1, R * D)).view(R, D)                                        # rows: B x key-splits
+        ops.colsum(dck.view(-1, NQ * D), out=dcls.view(NQ * D), accumulate=True)               # CLS token as a key / value
+        # parameter-only chain: u_r = scale Wk_h^T q_h (beta carries no gradient: softmax is shift invariant)
+        dqt = torch.empty(NQ, D, device=dev, dtype=torch.float32)
+        ops.sgemm_batched(hd, D, NQ, qt, D, hd, dU, H * D, D, dWin[D:2 * D], D, hd * D, H, transa=True, alpha=scale)   # dWk_h = scale q_h (x) dU_h
+        ops.sgemm_batched(NQ, hd, D, dU, H * D, D, Wk, D, hd * D, dqt, D, hd, H, transb=True, alpha=scale)             # dq_h = scale Wk_h dU_h
+        ops.sgemm(dqt, c, transa=True, out=dWin[:D])
+        ops.colsum(dqt, out=dbin[:D])
+        ops.sgemm(dqt, Win[:D], beta=1.0, out=dcls)
+        dmix = None
+        if has_mix and dalpha is not None:
+            dmix = z(mixw.shape[0])
+            ops.mix_softmax_bwd(mixw, dalpha, dmix)
+        return (None, None, None, None, dmix, dcls.view(1, NQ, D), dWin, dbin, dWo, dbo, dn1w, dn1b, dl1w, dl1b, dl2w, dl2b, dn2w, dn2b, dnfw, dnfb,
+                dpw, dpb)
+
+
 # ================================================================= cascaded tail (kwClip.py:697-916)
 def _pool_params(c, Win, bin_, NQ, D, H, hd, scale, dev):
     """Parameter-only operands of the algebraic CLS pooling: queries qt [NQ,D], U [R,D] (u_r = scale Wk_h^T q_h), beta [R]."""
