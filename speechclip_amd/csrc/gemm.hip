@@ -312,8 +312,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 }
                 if (load_next) {
                     __builtin_amdgcn_sched_barrier(0);
-                    af[i] = *(const bf16x8_t*)(src + a_base + off + i * 16 * 128);
-                    if (i < 4) bn[i] = *(const bf16x8_t*)(src + b_base + off + i * 16 * 128);
+                    // ABL 5 / 6 (timing probes, garbage results): drop half / three quarters of the fragment reads = the LDS read volume of a
+                    // 4-wave 128x128-per-wave layout and below
+                    if (!((ABL == 5 || ABL == 6) && (i & 1))) af[i] = *(const bf16x8_t*)(src + a_base + off + i * 16 * 128);
+                    if (i < 4 && !(ABL == 6 && (i & 1))) bn[i] = *(const bf16x8_t*)(src + b_base + off + i * 16 * 128);
+                    if (ABL == 6 && i < 4 && (i & 1)) bn[i] = bn[i - 1];
                     if (dma_k0 >= 0 && ABL != 1) {   // one LDS-DMA instruction per MFMA group instead of a burst behind the barrier
                         int la = lane_a, lw = lane_w;
                         asm volatile("" : "+v"(la), "+v"(lw));   // keep the 64-bit source addresses out of the loop-invariant set (VGPR pressure)
@@ -586,6 +589,8 @@ int launch256(const GemmParams& p, hipStream_t s) {
     if (abl && abl[0] == '1') return launch256_var<1, false>(p, grid, s);
     if (abl && abl[0] == '2') return launch256_var<2, false>(p, grid, s);
     if (abl && abl[0] == '4') return launch256_var<4, false>(p, grid, s);
+    if (abl && abl[0] == '5') return launch256_var<5, false>(p, grid, s);
+    if (abl && abl[0] == '6') return launch256_var<6, false>(p, grid, s);
     return launch256_var<0, false>(p, grid, s);
 }
 
