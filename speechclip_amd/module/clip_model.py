@@ -215,17 +215,19 @@ class CLIP(nn.Module):
         cls = ops.layernorm(x, *P["ln_post"], rows=B, D=W, ld_in=ntok * W)
         return ops.gemm(cls, P["proj_t"], out_f32=True)
 
-    def encode_text_embeddings(self, emb: torch.Tensor, take_pos: torch.Tensor) -> torch.Tensor:
-        """emb: f32 [B, L, tw] token embeddings (before positional add), L <= context_length.  Runs the causal text
+    def encode_text_embeddings(self, emb: torch.Tensor, take_pos) -> torch.Tensor:
+        """emb: f32 [B, L, tw] token embeddings (before positional add), L <= context_length; take_pos: int64 [B] or one int for all rows.  Runs the causal text
         transformer on the first L positions (positions > max(take_pos) cannot influence it) and returns
         ln_final(x)[b, take_pos[b]] @ text_projection as f32 [B, embed_dim].  When `emb` carries a gradient (training the cascaded
         branch through the frozen tower) the differentiable path runs; all rows must then share one take position."""
         assert emb.is_cuda
         if torch.is_grad_enabled() and emb.requires_grad:
             from ..train_tail import TextTowerTrainFn
-            pos = int(take_pos[0].item())
-            assert bool((take_pos == pos).all()), "training path: one EOT position for the whole batch (K keywords => K + 1)"
-            return TextTowerTrainFn.apply(self, emb, pos)
+            if not isinstance(take_pos, int):
+                pos = int(take_pos[0].item())
+                assert bool((take_pos == pos).all()), "training path: one EOT position for the whole batch (K keywords => K + 1)"
+                take_pos = pos
+            return TextTowerTrainFn.apply(self, emb, take_pos)
         with torch.no_grad():
             return self._encode_text_embeddings_eval(emb, take_pos)
 
@@ -234,6 +236,9 @@ class CLIP(nn.Module):
         B, L, tw = emb.shape
         x = (emb.float() + P["txt_pos"][:L]).reshape(B * L, tw).contiguous()
         run_tower(P["txt"], x, B, L, self.transformer.heads, causal=True)
-        rows = x.view(B, L, tw)[torch.arange(B, device=emb.device), take_pos].contiguous()
+        if isinstance(take_pos, int):
+            rows = x.view(B, L, tw)[:, take_pos].contiguous()
+        else:
+            rows = x.view(B, L, tw)[torch.arange(B, device=emb.device), take_pos].contiguous()
         n = ops.layernorm(rows, *P["ln_final"])
         return ops.gemm(n, P["txt_proj_t"], out_f32=True)

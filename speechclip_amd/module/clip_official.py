@@ -99,4 +99,4 @@ class ClipModel(nn.Module):
         emb[:, 0] = tok[sot]
         emb[:, 1:1 + keyword_num] = keywords
         emb[:, 1 + keyword_num] = tok[eot]
-        return self.model.encode_text_embeddings(emb, torch.full((B,), keyword_num + 1, device=dev, dtype=torch.long))
+        return self.model.encode_text_embeddings(emb, keyword_num + 1)       # one EOT position for the batch: a host int, no gather / sync

@@ -36,12 +36,18 @@ class SimpleVectorQuantizer(nn.Module):
         elif isinstance(temp, str) and temp.startswith("fixed="):
             self.temp_type = "fixed"
             self.register_buffer("curr_temp", torch.FloatTensor([ast.literal_eval(temp.replace("fixed=", ""))]))
+            self._fixed_temp = float(ast.literal_eval(temp.replace("fixed=", "")))   # host copy: reading the buffer would sync the stream every step
         else:
             raise NotImplementedError("scheduled VQ temperature is a training-time feature (SURVEY.md section 8f)")
         self.groundTruthPerplexity = None
+        if self.temp_type == "fixed":   # a checkpoint may carry another value in the buffer: refresh the host copy once, at load time
+            self.register_load_state_dict_post_hook(lambda mod, keys: setattr(mod, "_fixed_temp", float(mod.curr_temp.detach().cpu().item())))
 
     def set_num_updates(self, num_updates):
         pass
+
+    def temperature_value(self) -> float:
+        return self._fixed_temp if self.temp_type == "fixed" else float(self.curr_temp.item())
 
     def forward(self, x, prob_msk=[0, 2, 3], produce_targets=True):
         # train mode: same statistics and hard targets; the straight-through gradient (softmax(x / temp), :133-141) is applied where the
@@ -55,7 +61,7 @@ class SimpleVectorQuantizer(nn.Module):
         res["code_perplexity"] = stats[0]
         res["prob_perplexity"] = stats[1]
         res["ent_per_t"] = ent
-        res["temp"] = float(self.curr_temp.item())
+        res["temp"] = self.temperature_value()
         res["diversity_loss"] = (V - stats[1]) / V
         res["targets"] = targets.view(B, K, 1)
         return res
