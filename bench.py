@@ -208,12 +208,29 @@ def main():
             tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
             if os.path.exists(tf) and not args.train and not large and not casc and B == 256 and L == 160000:
                 tj = json.load(open(tf))
-                traffic, tsrc = tj["bytes_per_launch"], tj["source"] + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2)"
-            roof = {"bound": "mfma", "kernel": "sc_gemm_bf16 entry (all launches of the step): gemm256_kernel for fused epilogues / overlapping rows, hipBLASLt for the plain QKV / out-proj / fc2 GEMMs", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
-                    "launches_per_step": launches // args.steps,
-                    "avg_launch_ms": round(ms / launches, 4), "gemm_ms_per_step": round(ms / args.steps, 3),
-                    "executed_over_algorithmic": round(sum(e[2] for e in prof) / alg, 4)}
+                traffic, tsrc = tj["hand_written"]["bytes_per_launch"], tj["source"] + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2; gemm256_kernel + gemm_bf16_kernel launches)"
+            # the entry serves two kernels (vendor_gemm.hip): the hand-written gemm256_kernel family (everything fused / overlapping rows /
+            # small) and hipBLASLt (plain GEMMs).  The DOMINANT kernel of the step is the hand-written one: `achieved` is ITS flops / ITS time;
+            # the whole entry and the library part are reported beside it.
+            exe = sum(e[2] for e in prof)
+            part = {}
+            for path, name in ((0, "hand_written"), (1, "vendor")):
+                sel = [e for e in prof if e[3][6] == path]
+                pms = sum(e[0].elapsed_time(e[1]) for e in sel)
+                pfl = sum(e[2] for e in sel) * (alg / exe)     # algorithmic share (executed flops include <0.2 % tile padding)
+                part[name] = {"launches_per_step": len(sel) // args.steps, "ms_per_step": round(pms / args.steps, 3),
+                              "avg_launch_ms": round(pms / max(1, len(sel)), 4), "achieved": round(pfl / max(pms, 1e-9) / 1e9, 1) if sel else None}
+            hw = part["hand_written"]
+            roof = {"bound": "mfma", "kernel": "gemm256_kernel family (hand-written HIP: fused-GELU / QuickGELU epilogues, conv-as-GEMM with overlapping rows, small shapes)",
+                    "achieved": hw["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(hw["achieved"] / PEAK_BF16_TFLOPS, 4),
+                    "traffic": traffic, "traffic_source": tsrc, "launches_per_step": hw["launches_per_step"], "avg_launch_ms": hw["avg_launch_ms"],
+                    "ms_per_step": hw["ms_per_step"],
+                    "vendor_plain_gemms": dict(part["vendor"], kernel="hipBLASLt (plain QKV / out-proj / fc2 / ViT projections behind the same sc_gemm_bf16 entry)",
+                                               frac=round(part["vendor"]["achieved"] / PEAK_BF16_TFLOPS, 4) if part["vendor"]["achieved"] else None),
+                    "gemm_entry_total": {"achieved": round(ach, 1), "frac": round(ach / PEAK_BF16_TFLOPS, 4), "launches_per_step": launches // args.steps,
+                                         "avg_launch_ms": round(ms / launches, 4), "ms_per_step": round(ms / args.steps, 3)},
+                    "gemm_ms_per_step": round(ms / args.steps, 3),
+                    "executed_over_algorithmic": round(exe / alg, 4)}
         out = {"metric": "speech-image pairs/sec/node (%s)" % ("Cascaded SpeechCLIP base" if casc else "Parallel SpeechCLIP %s" % args.model), "value": round(pairs_per_s, 2), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

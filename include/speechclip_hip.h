@@ -56,6 +56,7 @@ int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
  * hipBLASLt -- the vendor library for plain library GEMMs, hand-written kernels for everything fused -- once the caller has registered a
  * device scratch buffer here (caller-owned; 64 MiB is plenty; NULL disables the library path).  SC_GEMM_NO_VENDOR=1 also disables it. */
 int sc_set_gemm_workspace(void* workspace, int64_t bytes);
+int sc_gemm_last_path(void);   /* instrumentation: 1 if the last sc_gemm_bf16 call ran on the vendor library, 0 on the hand-written kernels */
 
 int sc_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw,
                          int64_t strideW, int w_mod, void* C, int64_t ldc, int64_t strideC,

@@ -638,6 +638,8 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
 int sc_vendor_gemm_try(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* residual,
                        int64_t ldr, int64_t M, int N, int K, int out_f32, hipStream_t s);   // vendor_gemm.hip
 
+static int g_last_path = 0;   // 0: hand-written kernels of this file, 1: vendor library (instrumentation: which kernel a bench launch hit)
+extern "C" int sc_gemm_last_path(void) { return g_last_path; }
 static unsigned long long* g_gemm_trace = nullptr;
 extern "C" void sc_debug_set_gemm_trace(void* dev_buf) { g_gemm_trace = (unsigned long long*)dev_buf; }
 
@@ -647,8 +649,9 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     if ((flags & SC_GEMM_ACT_MASK) == 0 && lda >= K && !g_gemm_trace && A && W && C && M > 0 && N > 0 && K > 0 && K % 64 == 0) {
         // plain GEMM (+ bias, + residual; bf16 or fp32 out): the vendor library's kernel when a workspace is registered (vendor_gemm.hip)
         const int rc = sc_vendor_gemm_try(A, lda, W, ldw, C, ldc, bias, residual, ldr, M, N, K, (flags & SC_GEMM_OUT_F32) ? 1 : 0, (hipStream_t)stream);
-        if (rc <= 0) return rc;
+        if (rc <= 0) { g_last_path = 1; return rc; }
     }
+    g_last_path = 0;
     GemmParams p{};
     p.A = (const bf16_t*)A; p.lda = lda; p.strideA = 0;
     p.W = (const bf16_t*)W; p.ldw = ldw; p.strideW = 0; p.w_mod = 1;

@@ -60,7 +60,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
                              residual.stride(-2) if residual is not None else 0, M, N, K, flags, stream()), "sc_gemm_bf16")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, act, residual is not None, out_f32)))
+        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, act, residual is not None, out_f32, int(lib().sc_gemm_last_path()))))
     return out
 
 
@@ -73,7 +73,7 @@ def gemm_batched(a, lda, stride_a, w, stride_w, w_mod, out, ldc, stride_c, bias,
                                      M, N, K, batch, act, stream()), "sc_gemm_bf16_batched")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, act, False, False, batch)))
+        PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, act, False, False, 0, batch)))   # tag[6] = path (0 hand-written), tag[7] = batch
     return out
 
 
