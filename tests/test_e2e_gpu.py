@@ -337,3 +337,22 @@ def test_validation_hooks_recall_vs_oracle_pipeline():
         assert abs(r_ab[k] - o_ab[k]) <= 100.0 * flips_ab / n_a + 1e-4, (k, r_ab[k], o_ab[k], flips_ab)
         assert abs(r_ba[k] - o_ba[k]) <= 100.0 * flips_ba / n_i + 1e-4, (k, r_ba[k], o_ba[k], flips_ba)
     assert r_ab["recall@10"] == 100.0 and r_ba["recall@10"] == 100.0       # 6 images: everything is in the top 10
+
+
+def test_samples_beyond_wav_len_are_ignored():
+    """speech_encoder_plus.py:520-534 slices every utterance to wav[:wav_len] and re-pads with zeros, so whatever the caller left beyond
+    wav_len (collate garbage, a previous batch) cannot reach the features -- same here, bitwise, for base (GroupNorm extractor) and for the
+    large layout (per-utterance wave LayerNorm over the valid samples only)."""
+    for tag, large in (("tiny_base_p", False), ("tiny_large_p", True)):
+        g, model, batch = _load_model(tag, large)
+        lens = batch["wav_len"].clone()
+        wav = batch["wav"].clone()
+        dirty = wav.clone()
+        for i in range(wav.shape[0]):
+            dirty[i, int(lens[i]):] = 3.0 * torch.randn(wav.shape[1] - int(lens[i]), device=wav.device) + 1.0
+        if bool((lens == wav.shape[1]).all()):
+            pytest.skip("fixture has no padded utterance")
+        with torch.no_grad():
+            a, _, _ = model(batch)
+            b, _, _ = model(dict(batch, wav=dirty))
+        assert torch.equal(a["parallel_audio_feat"], b["parallel_audio_feat"]), tag
