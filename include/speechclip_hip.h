@@ -145,6 +145,9 @@ int sc_posconv_finish(const void* x, const int32_t* valid, const void* conv, con
 int sc_crop_pad(const float* wav, int64_t ld, const int32_t* starts, const int32_t* lens, float* out, int B, int Lout, void* stream);
 
 /* ---- CLIP ViT stem -- openai VisionTransformer.forward up to ln_pre (clip_official.py:209) ----- */
+/* sc_image_normalize_u8: torchvision ToTensor + Normalize of CLIP's `_transform` (openai clip.py `_transform`, called through
+ *   avssl/data/*_dataset.py image_transform): uint8 [B,H,W,3] (host pointers: mean3 / std3) -> f32 [B,3,H,W]. */
+int sc_image_normalize_u8(const void* u8_hwc, float* out_chw, int B, int H, int W, const float* mean3, const float* std3, void* stream);
 int sc_vit_patchify(const float* img, void* cols, int B, int R, int p, int Kpad, void* stream);
 int sc_vit_embed(const void* patch, const float* cls, const float* pos, const float* gamma, const float* beta, float* out, int B,
                  int ntok, int D, float eps, void* stream);

@@ -58,6 +58,7 @@ def _declare(L):
         "sc_posconv_pack": ([P, P, P, I, I, I, I, I, P], c_int),
         "sc_posconv_finish": ([P, P, P, P, P, P, P, I, I, I, I, I, F, P], c_int),
         "sc_crop_pad": ([P, L64, P, P, P, I, I, P], c_int),
+        "sc_image_normalize_u8": ([P, P, I, I, I, P, P, P], c_int),
         "sc_vit_patchify": ([P, P, I, I, I, I, P], c_int),
         "sc_vit_embed": ([P, P, P, P, P, P, I, I, I, F, P], c_int),
         "sc_infonce_workspace_bytes": ([I], c_int64),

@@ -551,3 +551,21 @@ def kw_bn_bwd(x, dy, gamma, mean, rstd, want_param_grads=True):
     db = torch.empty(K * E, device=x.device, dtype=torch.float32) if want_param_grads else None
     check(lib().sc_kw_bn_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db), B, K, E, stream()), "sc_kw_bn_bwd")
     return dx, dg, db
+
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def image_normalize_u8(u8, mean=CLIP_MEAN, std=CLIP_STD):
+    """uint8 [B,H,W,3] (already resized / centre-cropped on the host) -> f32 [B,3,H,W] = (x/255 - mean) / std  (ToTensor + Normalize)."""
+    import ctypes
+    _need_cuda(u8)
+    assert u8.dtype == torch.uint8 and u8.dim() == 4 and u8.shape[-1] == 3 and u8.is_contiguous()
+    B, H, W, _ = u8.shape
+    out = torch.empty(B, 3, H, W, device=u8.device, dtype=torch.float32)
+    m = (ctypes.c_float * 3)(*[float(x) for x in mean])
+    sd = (ctypes.c_float * 3)(*[float(x) for x in std])
+    check(lib().sc_image_normalize_u8(ptr(u8), ptr(out), B, H, W, ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), stream()),
+          "sc_image_normalize_u8")
+    return out

@@ -237,6 +237,21 @@ def gen_small_ops(ws_mod, du_mod):
             sch.step()
         out[f"sched_{name}_lr"] = np.array(lrs, dtype=np.float64)
     out["sched_steps"] = np.array(steps)
+    # collate_general (avssl/data/collate_function.py:7-36) on ragged rows -- loaded from its file: the package __init__ pulls in the datasets
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_collate_function", f"{REF}/avssl/data/collate_function.py")
+    cf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cf)
+    gc = torch.Generator().manual_seed(9)
+    lens_c = [5, 17, 9, 17, 1]
+    rows = [{"wav": torch.randn(n, generator=gc), "image": torch.randn(3, 4, 4, generator=gc), "id": 7 * i + 1} for i, n in enumerate(lens_c)]
+    col = cf.collate_general(rows)
+    assert list(col.keys()) == ["wav", "image", "id", "wav_len"]
+    out["collate_lens"] = np.array(lens_c)
+    out["collate_wav_flat"] = torch.cat([r["wav"] for r in rows]).numpy()
+    out["collate_image_rows"] = torch.stack([r["image"] for r in rows]).numpy()
+    for k, v in col.items():
+        out["collate_out_" + k] = v.numpy()
     save("small_ops.npz", **out)
 
 

@@ -303,3 +303,24 @@ def test_pretrained_checkpoint_loaders_from_local_files(tmp_path, monkeypatch):
     cgot = clip.model.state_dict()
     for k, v in csrc.state_dict().items():
         assert k in cgot and torch.equal(cgot[k].float(), v.float()), k
+
+
+def test_collate_general_matches_reference_golden():
+    """speechclip_amd.data.collate_general vs the reference's collate_general on the same ragged rows (tests/golden/small_ops.npz)."""
+    from speechclip_amd.data import collate_general
+    g = np.load(os.path.join(GOLD, "small_ops.npz"))
+    lens = [int(x) for x in g["collate_lens"]]
+    flat = torch.from_numpy(g["collate_wav_flat"])
+    imgs = torch.from_numpy(g["collate_image_rows"])
+    rows, off = [], 0
+    for i, n in enumerate(lens):
+        rows.append({"wav": flat[off:off + n].clone(), "image": imgs[i], "id": 7 * i + 1})
+        off += n
+    out = collate_general(rows)
+    assert list(out.keys()) == ["wav", "image", "id", "wav_len"]
+    for k, v in out.items():
+        ref = torch.from_numpy(g["collate_out_" + k])
+        assert v.dtype == ref.dtype and torch.equal(v, ref), k
+    # rows without waves: no wav_len key, numbers -> LongTensor
+    out2 = collate_general([{"id": 3, "image": imgs[0]}, {"id": 5, "image": imgs[1]}])
+    assert list(out2.keys()) == ["id", "image"] and out2["id"].dtype == torch.int64 and out2["image"].shape[0] == 2

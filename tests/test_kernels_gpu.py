@@ -297,3 +297,19 @@ def test_retrieval_ranks_golden_and_random():
     # rows without any positive candidate rank last
     r = ops.retrieval_ranks(sd[:8].contiguous(), torch.full((8,), 10 ** 9), img_ids)
     assert bool((r == n_img).all())
+
+
+def test_image_normalize_u8_and_collate_to_device():
+    """ToTensor + Normalize of CLIP's `_transform` on the device (uint8 HWC crop -> f32 CHW) and the batch hand-over that uses it."""
+    from speechclip_amd import ops
+    from speechclip_amd.data import collate_general, collate_to_device
+    g = _g(5)
+    u8 = torch.randint(0, 256, (3, 224, 224, 3), generator=g, dtype=torch.uint8)
+    ref = (u8.permute(0, 3, 1, 2).float() / 255.0 - torch.tensor(ops.CLIP_MEAN).view(1, 3, 1, 1)) / torch.tensor(ops.CLIP_STD).view(1, 3, 1, 1)
+    y = ops.image_normalize_u8(u8.cuda())
+    torch.testing.assert_close(y.cpu(), ref, atol=1e-6, rtol=1e-6)
+    rows = [{"wav": torch.randn(n, generator=g), "image": u8[i], "id": i} for i, n in enumerate([1600, 400, 1000])]
+    batch = collate_to_device(collate_general(rows), torch.device("cuda", 0))
+    assert batch["wav"].is_cuda and batch["wav"].shape == (3, 1600) and not batch["wav_len"].is_cuda
+    assert float(batch["wav"][1, 400:].abs().max()) == 0.0
+    torch.testing.assert_close(batch["image"].cpu(), ref, atol=1e-6, rtol=1e-6)
