@@ -9,7 +9,6 @@ The image tower keeps an fp32 residual stream (pre-LN blocks; M = B*50 rows is t
 dense contraction through the bf16 MFMA GEMM; LayerNorms compute in fp32 like CLIP's LayerNorm.
 """
 from dataclasses import dataclass
-from typing import Optional
 
 import torch
 import torch.nn as nn

@@ -16,7 +16,7 @@ Layout notes (DESIGN.md has the full picture):
 """
 import math
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import torch
 import torch.nn as nn

@@ -1,6 +1,6 @@
 """WeightedSumLayer -- same constructor / call contract as avssl/module/weighted_sum.py:10-45, computed by
 sc_weighted_sum_fwd (softmax over the n scalars, optional per-feature layer_norm, one streaming pass)."""
-from typing import List, Sequence, Union
+from typing import Sequence, Union
 
 import torch
 import torch.nn as nn
