@@ -242,7 +242,7 @@ class HubertModel(nn.Module):
         assert T >= 1, "waveform too short for the conv stack"
         C = cfg.conv_layers[0][0]
         bf = torch.bfloat16
-        lens_i32 = torch.tensor([int(l) for l in lens], dtype=torch.int32, device=dev)
+        lens_i32 = ops.dev_ints(lens, torch.int32, dev)
         if cfg.normalize:
             wav = ops.wave_layernorm(wav.contiguous(), lens_i32)
         ln_mode = cfg.extractor_mode == "layer_norm"
@@ -271,7 +271,7 @@ class HubertModel(nn.Module):
         xp = ops.gemm(feats, P["proj_w"], P["proj_b"], out=self._buf("proj", (M, d), bf, dev))
         # ---- frame mask, positional conv (+ LN for post-LN models)
         valid = self.valid_frames(lens, lmax, T)
-        valid_i32 = torch.tensor(valid, dtype=torch.int32, device=dev)
+        valid_i32 = ops.dev_ints(valid, torch.int32, dev)
         nl = cfg.encoder_layers
         pre_ln = cfg.layer_norm_first
         hid_dtype = torch.float32 if pre_ln else bf

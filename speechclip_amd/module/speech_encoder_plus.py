@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import ops
 from .hubert import HubertConfig, HubertModel
 from .weighted_sum import WeightedSumLayer
 
@@ -117,7 +118,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             padded = wav[:, :lmax].to(dev, torch.float32)
             # the reference rebuilds the batch from wav[b, :len] with zero right-padding: enforce the zeros
             if any(l < lmax for l in lens):
-                keep = torch.arange(lmax, device=dev)[None, :] < torch.tensor(lens, device=dev)[:, None]
+                keep = torch.arange(lmax, device=dev)[None, :] < ops.dev_ints(lens, torch.int64, dev)[:, None]
                 padded = padded * keep
             padded = padded.contiguous()
         elif isinstance(wav, torch.Tensor) and wav.dim() == 2 and len(wav_len) > 0 and self.training and wav.is_cuda:
@@ -130,7 +131,6 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                     starts.append(0); lens.append(n)
                 else:
                     starts.append(int(np.random.randint(n - self.max_audio_len))); lens.append(self.max_audio_len)
-            from .. import ops
             padded = ops.crop_pad(wav.to(dev, torch.float32), starts, lens, max(lens))
         else:
             wavs = self._to_list(wav, wav_len)
@@ -144,7 +144,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if self.normalize_hiddenstates and self.normalize_type.startswith("method"):
             raise NotImplementedError("normalize_type method1/method2 are not used by any shipped config")
         # speech_encoder_plus.py:604-611: Python round() (banker's) of len / 320, clamped to T
-        feat_len = torch.clamp_max(torch.tensor([round(l / self.downsample_rate) for l in lens], dtype=torch.long), T).to(dev)
+        feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()   # escapes to the caller
         if feat_select_idx is None:
             feat_select_idx = self.feat_select_idx
         layers = lambda: tuple(hidden[i, :, :T] for i in range(hidden.shape[0]))  # noqa: E731

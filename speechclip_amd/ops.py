@@ -199,13 +199,30 @@ def posconv(x, valid_i32, wg, bias, gamma, beta, B, Tp, D, G, Kw, out=None, out_
     return out
 
 
+_DEV_INTS = {}
+
+
+def dev_ints(values, dtype, device):
+    """Small host integer lists (utterance lengths, valid-frame counts) as a device tensor, cached by value: fixed-length batches upload
+    them once instead of every step, and a step that only replays cached uploads can be captured in a HIP graph (a pageable
+    host-to-device copy is not capturable).  The returned tensor is shared: callers must not write to it."""
+    key = (tuple(int(v) for v in values), dtype, str(device))
+    t = _DEV_INTS.get(key)
+    if t is None:
+        if len(_DEV_INTS) > 256:
+            _DEV_INTS.clear()
+        t = torch.tensor(list(key[0]), dtype=dtype).to(device)
+        _DEV_INTS[key] = t
+    return t
+
+
 def crop_pad(wav, starts, lens, Lout):
     """wav f32 [B, L] (device); starts/lens host int lists -> f32 [B, Lout]: out[b, j] = wav[b, starts[b] + j] for j < lens[b], else 0."""
     _need_cuda(wav)
     assert wav.dtype == torch.float32 and wav.dim() == 2 and wav.stride(1) == 1
     B = wav.shape[0]
     assert all(0 <= s and s + l <= wav.shape[1] and l <= Lout for s, l in zip(starts, lens))
-    meta = torch.tensor([list(starts), list(lens)], dtype=torch.int32).to(wav.device)
+    meta = torch.tensor([list(starts), list(lens)], dtype=torch.int32).to(wav.device)      # random crop offsets: new every step
     out = torch.empty(B, Lout, device=wav.device, dtype=torch.float32)
     check(lib().sc_crop_pad(ptr(wav), wav.stride(0), ptr(meta[0]), ptr(meta[1]), ptr(out), B, Lout, stream()), "sc_crop_pad")
     return out

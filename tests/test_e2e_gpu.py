@@ -356,3 +356,31 @@ def test_samples_beyond_wav_len_are_ignored():
             a, _, _ = model(batch)
             b, _, _ = model(dict(batch, wav=dirty))
         assert torch.equal(a["parallel_audio_feat"], b["parallel_audio_feat"]), tag
+
+
+def test_step_is_hip_graph_capturable():
+    """The whole forward + loss step (every kernel behind the C ABI, hipBLASLt included) can be captured in a HIP graph and replayed with
+    new inputs in the static buffers, bitwise equal to eager execution (length uploads come from ops.dev_ints' cache after warm-up)."""
+    g, model, batch = _load_model("tiny_base_p", False)
+    batch = dict(batch, wav_len=batch["wav_len"].cpu())          # host lengths: the encoder's length arithmetic is host logic
+
+    def step():
+        with torch.no_grad():
+            lf, _, _ = model(batch)
+            return model.compute_loss(lf)["loss"], lf["parallel_audio_feat"]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_loss, g_feat = step()
+    graph.replay()
+    e_loss, e_feat = step()
+    assert torch.equal(g_feat, e_feat) and float(g_loss) == float(e_loss)
+    batch["wav"].mul_(0.5)                                       # new samples through the same buffers
+    graph.replay()
+    e_loss2, e_feat2 = step()
+    assert torch.equal(g_feat, e_feat2) and float(g_loss) == float(e_loss2) and not torch.equal(e_feat, e_feat2)
