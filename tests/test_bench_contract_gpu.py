@@ -1,0 +1,43 @@
+"""bench.py prints ONE JSON line with the contract's fields (task statement: metric/value/unit/n_gpus/steps/warmup/ms_per_step/
+higher_is_better/scaling/vs_baseline/dtype/data/config + roofline + cpu_baseline).  Small batch so the check takes seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8", *extra],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract_forward():
+    d = _run("--cpu-pairs", "2")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3          # value = pairs / time of the timed region
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches_per_step"] > 0 and r["avg_launch_ms"] > 0 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+
+
+def test_bench_json_contract_train_and_cascaded():
+    t = _run("--cpu-pairs", "0", "--train")
+    assert t["config"]["mode"].startswith("train") and t["cpu_baseline"] is None and t["value"] > 0
+    c = _run("--cpu-pairs", "0", "--model", "cascaded")
+    assert "Cascaded" in c["metric"] and c["value"] > 0
