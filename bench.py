@@ -21,7 +21,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md
 
@@ -63,7 +62,7 @@ LARGE = dict(d=1024, ffn=4096, layers=24, vit_w=1024, vit_layers=24, patch=14, E
 
 
 def build_model(seed=7122, large=False, cascaded=False):
-    from helpers import make_config
+    from speechclip_amd.util.shipped_configs import make_config
     from speechclip_amd.model import KWClip_GeneralTransformer
     torch.manual_seed(seed)
     if cascaded:      # C-base (BASELINE configs[2]): 8 keyword queries -> BatchNorm -> VQ over the 49408 sub-words -> CLIP text tower

@@ -2,7 +2,7 @@
 """Probe: capture the whole forward + loss step in a HIP graph (torch.cuda.CUDAGraph on ROCm = hipGraph) and compare eager vs replay."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import torch
 import bench
 from speechclip_amd import parallel

@@ -4,7 +4,6 @@ milliseconds go when producers/consumers run around it (tools/gemm_bench.py time
 import os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench
 from speechclip_amd import ops, parallel
