@@ -45,7 +45,7 @@ bool build_plan(Plan& p, int64_t M, int N, int K, int64_t lda, int64_t ldc, int6
     if (hipblasLtMatrixLayoutCreate(&p.ld, ct, N, M, ldc) != HIPBLAS_STATUS_SUCCESS) return false;
     hipblasLtMatmulPreference_t pref;
     if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return false;
-    const uint64_t maxws = g_ws_bytes;
+    const uint64_t maxws = g_ws_bytes / 2;
     hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &maxws, sizeof(maxws));
     hipblasLtMatmulHeuristicResult_t res[4];
     int n = 0;
@@ -53,7 +53,7 @@ bool build_plan(Plan& p, int64_t M, int N, int K, int64_t lda, int64_t ldc, int6
     hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || n <= 0) return false;
     for (int i = 0; i < n; ++i)
-        if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= g_ws_bytes) { p.algo = res[i].algo; p.ws = res[i].workspaceSize; return true; }
+        if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= g_ws_bytes / 2) { p.algo = res[i].algo; p.ws = res[i].workspaceSize; return true; }
     return false;
 }
 
@@ -86,7 +86,10 @@ int sc_vendor_gemm_try(const void* A, int64_t lda, const void* W, int64_t ldw, v
     if (!p.ok) return 1;
     if (hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return 1;
     const float alpha = 1.0f, beta = residual ? 1.0f : 0.0f;
-    const hipblasStatus_t st = hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.la, A, p.lb, &beta, residual ? residual : C, p.lc, C, p.ld, &p.algo, g_ws,
+    // two streams may run library GEMMs concurrently (the image tower beside the speech tower): each gets its own half of the workspace
+    static hipStream_t first_stream = s;
+    void* ws = (s == first_stream) ? g_ws : (void*)((char*)g_ws + g_ws_bytes / 2);
+    const hipblasStatus_t st = hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.la, A, p.lb, &beta, residual ? residual : C, p.lc, C, p.ld, &p.algo, ws,
                                                p.ws, s);
     if (st != HIPBLAS_STATUS_SUCCESS) { sc_set_error("sc_gemm_bf16: hipblasLtMatmul failed (%d)", (int)st); return -3; }
     return 0;

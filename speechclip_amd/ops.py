@@ -15,6 +15,7 @@ bf16 = torch.bfloat16
 # Optional HIP-event instrumentation of the dominant kernel (bench.py roofline leg): when PROFILE is a list, every
 # sc_gemm_bf16 launch appends (start_event, end_event, flops, shape_tag) recorded on the launch stream.
 PROFILE = None
+PROFILE_SIDE = []     # (start, end) HIP events of every side-stream window (the image tower running beside the speech tower) while PROFILE is on
 
 _GEMM_WS = {}
 
@@ -60,7 +61,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
                              residual.stride(-2) if residual is not None else 0, M, N, K, flags, stream()), "sc_gemm_bf16")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, act, residual is not None, out_f32, int(lib().sc_gemm_last_path()))))
+        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, act, residual is not None, out_f32, int(lib().sc_gemm_last_path())),
+                        torch.cuda.current_stream().cuda_stream))
     return out
 
 
@@ -73,7 +75,8 @@ def gemm_batched(a, lda, stride_a, w, stride_w, w_mod, out, ldc, stride_c, bias,
                                      M, N, K, batch, act, stream()), "sc_gemm_bf16_batched")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, act, False, False, 0, batch)))   # tag[6] = path (0 hand-written), tag[7] = batch
+        PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, act, False, False, 0, batch),   # tag[6] = path (0 hand-written), tag[7] = batch
+                        torch.cuda.current_stream().cuda_stream))
     return out
 
 
