@@ -208,7 +208,7 @@ def main():
             tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
             if os.path.exists(tf) and not args.train and not large and not casc and B == 256 and L == 160000:
                 tj = json.load(open(tf))
-                traffic, tsrc = tj["hand_written"]["bytes_per_launch"], tj["source"] + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2; gemm256_kernel + gemm_bf16_kernel launches)"
+                traffic, tsrc = tj["hand_written_main_stream"]["bytes_per_launch"], tj["source"] + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2; gemm256_kernel + gemm_bf16_kernel launches)"
             # the entry serves two kernels (vendor_gemm.hip): the hand-written gemm256_kernel family (everything fused / overlapping rows /
             # small) and hipBLASLt (plain GEMMs).  The DOMINANT kernel of the step is the hand-written one: `achieved` is ITS flops / ITS time;
             # the whole entry and the library part are reported beside it.
