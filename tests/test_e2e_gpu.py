@@ -384,3 +384,24 @@ def test_step_is_hip_graph_capturable():
     graph.replay()
     e_loss2, e_feat2 = step()
     assert torch.equal(g_feat, e_feat2) and float(g_loss) == float(e_loss2) and not torch.equal(e_feat, e_feat2)
+
+
+def test_image_tower_on_side_stream_is_bitwise_equal_to_serial():
+    """KWClip_GeneralTransformer.forward runs the frozen image tower on a side HIP stream beside the speech tower (default); serialising the
+    towers (SC_OVERLAP_VIT=0 / the module switch) must give bitwise identical features and loss."""
+    import speechclip_amd.model.kwClip as K
+    g, model, batch = _load_model("tiny_base_p", False)
+    assert K._OVERLAP_IMAGE_TOWER or os.environ.get("SC_OVERLAP_VIT") == "0"
+    outs = []
+    for flag in (True, False, True):
+        K._OVERLAP_IMAGE_TOWER = flag
+        try:
+            with torch.no_grad():
+                lf, _, _ = model(batch)
+                loss = model.compute_loss(lf)["loss"]
+            torch.cuda.synchronize()
+            outs.append((lf["image_feat"].clone(), lf["parallel_audio_feat"].clone(), float(loss)))
+        finally:
+            K._OVERLAP_IMAGE_TOWER = True
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and o[2] == outs[0][2]
