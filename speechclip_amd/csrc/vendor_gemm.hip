@@ -86,9 +86,19 @@ int sc_vendor_gemm_try(const void* A, int64_t lda, const void* W, int64_t ldw, v
     if (!p.ok) return 1;
     if (hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return 1;
     const float alpha = 1.0f, beta = residual ? 1.0f : 0.0f;
-    // two streams may run library GEMMs concurrently (the image tower beside the speech tower): each gets its own half of the workspace
-    static hipStream_t first_stream = s;
-    void* ws = (s == first_stream) ? g_ws : (void*)((char*)g_ws + g_ws_bytes / 2);
+    // two streams may run library GEMMs concurrently (the image tower beside the speech tower): each owns one half of the workspace;
+    // a third stream does not get the library path (its GEMMs run on the hand-written kernels, which need no workspace)
+    static hipStream_t slot_stream[2];
+    static int n_slots = 0;
+    int slot = -1;
+    for (int i = 0; i < n_slots; ++i)
+        if (slot_stream[i] == s) slot = i;
+    if (slot < 0) {
+        if (n_slots == 2) return 1;
+        slot = n_slots;
+        slot_stream[n_slots++] = s;
+    }
+    void* ws = (void*)((char*)g_ws + (size_t)slot * (g_ws_bytes / 2));
     const hipblasStatus_t st = hipblasLtMatmul(g_handle, p.desc, &alpha, W, p.la, A, p.lb, &beta, residual ? residual : C, p.lc, C, p.ld, &p.algo, ws,
                                                p.ws, s);
     if (st != HIPBLAS_STATUS_SUCCESS) { sc_set_error("sc_gemm_bf16: hipblasLtMatmul failed (%d)", (int)st); return -3; }

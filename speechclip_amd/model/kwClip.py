@@ -20,6 +20,7 @@ from torch import nn
 from .. import ops, parallel
 
 _OVERLAP_IMAGE_TOWER = os.environ.get("SC_OVERLAP_VIT", "1") != "0"
+_SIDE_STREAMS = {}
 from ..base import OrderedNamespace
 from ..module import ClipModel, FairseqSpeechEncoder_Hubert, MLPLayers, S3prlSpeechEncoderPlus, losses, mutualRetrieval
 from ..module.kw_modules import TransformerModels
@@ -395,10 +396,11 @@ class KWClip_GeneralTransformer(KWClipBase):
             # The frozen image tower does not depend on the speech tower: it runs on a side HIP stream and fills the CUs the speech tower's
             # kernels leave idle (GEMM tails, HBM-bound conv0 / LayerNorm phases): 45.9 -> 44.7 ms per B = 256 step.  SC_OVERLAP_VIT=0: serial.
             cur = torch.cuda.current_stream()
-            if getattr(self, "_side_stream", None) is None:
-                self._side_stream = torch.cuda.Stream()
-            self._side_stream.wait_stream(cur)
-            with torch.cuda.stream(self._side_stream):
+            side = _SIDE_STREAMS.get(image.device.index)          # one side stream per device for the whole process (the library path keeps
+            if side is None:                                      # one workspace half per stream: vendor_gemm.hip)
+                side = _SIDE_STREAMS[image.device.index] = torch.cuda.Stream(device=image.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
                 if ops.PROFILE is not None:        # bench instrumentation: the window in which two kernels may share the CUs
                     w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     w0.record()
@@ -407,7 +409,7 @@ class KWClip_GeneralTransformer(KWClipBase):
                     w1.record()
                     ops.PROFILE_SIDE.append((w0, w1))
             audio_feat, audio_len = self.forward_audio(wav, wav_len)
-            cur.wait_stream(self._side_stream)
+            cur.wait_stream(side)
             image_feat.record_stream(cur)
         else:
             audio_feat, audio_len = self.forward_audio(wav, wav_len)
