@@ -168,6 +168,9 @@ int sc_infonce_fwd(const float* feat_a, const float* feat_b, const int64_t* ids,
 int sc_kw_affine(const float* x, const float* scale, const float* shift, float* out, int64_t rows, int K, int D, void* stream);
 int64_t sc_cosine_workspace_bytes(int R, int V);
 int sc_cosine_scores(const float* a, const float* emb, void* workspace, float* out, int R, int V, int E, float eps, void* stream);
+/* sc_cosine_refine: for score matrices produced on the MFMA path (three-term bf16 split GEMM, ~1e-5 accurate): every entry within `delta` of its
+ *   row maximum is recomputed in fp32 as (a . e) / (max(|a|,eps) max(|e|,eps)), so the arg-max is decided by fp32 arithmetic (kwClip.py:889-909). */
+int sc_cosine_refine(float* scores, const float* a, const float* emb, int R, int V, int E, float delta, float eps, void* stream);
 int64_t sc_vq_workspace_bytes(int R, int V);
 int sc_vq_fwd(const float* scores, int64_t* targets, float* stats2, float* ent_per_t, void* workspace, int R, int K, int V,
               const int32_t* host_mask_ids, int n_mask, void* stream);
@@ -228,7 +231,7 @@ int sc_mix_softmax_bwd(const float* w, const float* dalpha_b, int B, int n, floa
  *   `momentum` (unbiased variance), NULL: not tracked.  mean_out / rstd_out f32 [K*E] (data order) feed the backward. */
 /* sc_split_hilo_bf16: out bf16 [M, 2K] = (bf16(a) | bf16(a - bf16(a))): a @ W^T = out @ [W | W]^T keeps ~16 mantissa bits of an fp32 gradient on the
  *   bf16 MFMA GEMM (the dX products against the frozen text tower / sub-word table). */
-int sc_split_hilo_bf16(const float* a, int64_t lda, void* out, int64_t M, int K, void* stream);
+int sc_split_hilo_bf16(const float* a, int64_t lda, void* out, int64_t M, int K, int nblk, void* stream);   /* nblk 2: (hi|lo); 3: (hi|lo|hi) */
 int sc_attn_small_bwd(const void* qkv, const float* dout, float* dqkv, int B, int L, int heads, int head_dim, int causal, void* stream);
 int sc_quickgelu_f32(const float* z, void* y_or_dh, int64_t n, int backward, int out_bf16, void* stream);
 int sc_vq_st_bwd(const float* cos_scores, float* dprob_inout, float* rowdot, int R, int V, float temp, const int* mask_ids, int n_mask, void* stream);

@@ -69,6 +69,49 @@ __global__ __launch_bounds__(256) void cosine_tile_kernel(const float* __restric
     }
 }
 
+
+// Exact re-evaluation of the near-maximal entries of a score row.  The MFMA path (sc_gemm_bf16 on three-term bf16 splits of the normalised
+// operands) is accurate to ~1e-5; every entry within `delta` of the row maximum is recomputed here as (a . e) inv|a| inv|e| in fp32, so the
+// arg-max -- the sub-word the quantiser picks -- is decided by fp32 arithmetic as in the reference.  One block per row.
+constexpr int MAXCAND = 128;
+__global__ __launch_bounds__(256) void cosine_refine_kernel(float* __restrict__ cosv, const float* __restrict__ a, const float* __restrict__ e, int V, int E,
+                                                            float delta, float eps) {
+    __shared__ float s_red[8];
+    __shared__ int s_cand[MAXCAND];
+    __shared__ int s_n;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* row = cosv + (int64_t)r * V;
+    const float* ar = a + (int64_t)r * E;
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 256) mx = fmaxf(mx, row[v]);
+    mx = wave_max(mx);
+    if (lane == 0) s_red[wv] = mx;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    for (int v = tid; v < V; v += 256)
+        if (row[v] >= mx - delta) { const int i = atomicAdd(&s_n, 1); if (i < MAXCAND) s_cand[i] = v; }
+    float qa = 0.f;
+    for (int k = tid; k < E; k += 256) qa += ar[k] * ar[k];
+    qa = wave_sum(qa);
+    __syncthreads();
+    if (lane == 0) s_red[4 + wv] = qa;
+    __syncthreads();
+    const float inv_a = 1.0f / fmaxf(sqrtf(s_red[4] + s_red[5] + s_red[6] + s_red[7]), eps);
+    const int n = s_n < MAXCAND ? s_n : MAXCAND;
+    for (int c = 0; c < n; ++c) {
+        const int v = s_cand[c];
+        const float* ev = e + (int64_t)v * E;
+        float d = 0.f, q = 0.f;
+        for (int k = tid; k < E; k += 256) { const float x = ev[k]; d = fmaf(ar[k], x, d); q = fmaf(x, x, q); }
+        d = wave_sum(d); q = wave_sum(q);
+        __syncthreads();
+        if (lane == 0) { s_red[wv] = d; s_red[4 + wv] = q; }
+        __syncthreads();
+        if (tid == 0) row[v] = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) * inv_a * (1.0f / fmaxf(sqrtf(s_red[4] + s_red[5] + s_red[6] + s_red[7]), eps));
+    }
+}
+
 __device__ __forceinline__ bool is_masked(int v, const int* msk, int nmsk) {
     for (int i = 0; i < nmsk; ++i)
         if (msk[i] == v) return true;
@@ -215,6 +258,15 @@ extern "C" int sc_cosine_scores(const float* a, const float* emb, void* workspac
 }
 
 static int vq_nsplit(int R) { return R >= 1024 ? 32 : (R >= 64 ? 8 : 1); }
+
+extern "C" int sc_cosine_refine(float* scores, const float* a, const float* emb, int R, int V, int E, float delta, float eps, void* stream) {
+    SC_CHECK_ARG(R >= 0 && V > 0 && E > 0 && delta >= 0.f, "sc_cosine_refine: bad arguments");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(cosine_refine_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, scores, a, emb, V, E, delta, eps);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int64_t sc_vq_workspace_bytes(int R, int V) { return ((int64_t)3 * R + (V + 255) / 256 + (int64_t)V * (1 + vq_nsplit(R))) * 4; }
 
 extern "C" int sc_vq_fwd(const float* scores, int64_t* targets, float* stats2, float* ent_per_t, void* workspace, int R, int K, int V,

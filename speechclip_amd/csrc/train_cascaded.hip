@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void quickgelu_kernel(const float* __restrict_
 
 // out bf16 [M, 2K] = (hi | lo) with hi = bf16(a), lo = bf16(a - hi): the two-term operand of the backward products (a @ W^T = [hi|lo] @ [W|W]^T,
 // ~16 mantissa bits of the gradient survive the bf16 MFMA GEMM).  K % 4 == 0.
-__global__ __launch_bounds__(256) void split_hilo_kernel(const float* __restrict__ a, int64_t lda, bf16_t* __restrict__ out, int64_t M, int K) {
+__global__ __launch_bounds__(256) void split_hilo_kernel(const float* __restrict__ a, int64_t lda, bf16_t* __restrict__ out, int64_t M, int K, int nblk) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int kq = K / 4;
     if (i >= M * kq) return;
@@ -90,8 +90,9 @@ __global__ __launch_bounds__(256) void split_hilo_kernel(const float* __restrict
     h.x = pack2bf(v[0], v[1]); h.y = pack2bf(v[2], v[3]);
     l.x = pack2bf(v[0] - lo2f(h.x), v[1] - hi2f(h.x));
     l.y = pack2bf(v[2] - lo2f(h.y), v[3] - hi2f(h.y));
-    *(uint2*)(out + r * 2 * K + c) = h;
-    *(uint2*)(out + r * 2 * K + K + c) = l;
+    *(uint2*)(out + r * nblk * K + c) = h;
+    *(uint2*)(out + r * nblk * K + K + c) = l;
+    if (nblk == 3) *(uint2*)(out + r * nblk * K + 2 * K + c) = h;     // (hi | lo | hi): pairs with a table laid out (hi | hi | lo)
 }
 
 struct MaskIds { int n; int id[8]; };
@@ -260,11 +261,12 @@ extern "C" int sc_kw_bn_bwd(const float* x, const float* dy, const float* gamma,
     return 0;
 }
 
-extern "C" int sc_split_hilo_bf16(const float* a, int64_t lda, void* out, int64_t M, int K, void* stream) {
+extern "C" int sc_split_hilo_bf16(const float* a, int64_t lda, void* out, int64_t M, int K, int nblk, void* stream) {
     SC_CHECK_ARG(K > 0 && K % 4 == 0 && lda % 4 == 0, "sc_split_hilo_bf16: K=%d and lda must be multiples of 4", K);
+    SC_CHECK_ARG(nblk == 2 || nblk == 3, "sc_split_hilo_bf16: nblk=%d must be 2 (hi|lo) or 3 (hi|lo|hi)", nblk);
     if (M <= 0) return 0;
     const int64_t n = M * (K / 4);
-    hipLaunchKernelGGL(split_hilo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, lda, (bf16_t*)out, M, K);
+    hipLaunchKernelGGL(split_hilo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, lda, (bf16_t*)out, M, K, nblk);
     SC_CHECK_LAUNCH();
     return 0;
 }

@@ -273,15 +273,49 @@ def kw_affine(x, scale, shift):
     return out
 
 
-def cosine_scores(a, emb, eps=1e-8):
-    """a f32 [R,E], emb f32 [V,E] -> f32 [R,V] cosine similarities."""
+_COS_TABLES = {}
+
+
+def _cos_table(emb):
+    """(e/|e|) of the frozen sub-word table as a three-block bf16 operand [V, 3E] = (hi | hi | lo): with the keyword side split as (hi | lo | hi),
+    ONE bf16 MFMA GEMM of depth 3E returns a_hi.e_hi + a_lo.e_hi + a_hi.e_lo (~16 mantissa bits of the fp32 product).  Cached per table version."""
+    import weakref
+    key = emb.data_ptr()
+    hit = _COS_TABLES.get(key)
+    if hit is not None and hit[0] == (emb._version, tuple(emb.shape)) and hit[2]() is emb:
+        return hit[1]
+    en = l2norm(emb.detach().float().contiguous())
+    hi = en.to(bf16)
+    lo = (en - hi.float()).to(bf16)
+    tab = torch.cat([hi, hi, lo], dim=1).contiguous()
+    _COS_TABLES.clear()
+    _COS_TABLES[key] = ((emb._version, tuple(emb.shape)), tab, weakref.ref(emb))
+    return tab
+
+
+def cosine_scores(a, emb, eps=1e-8, exact=None):
+    """a f32 [R,E], emb f32 [V,E] -> f32 [R,V] cosine similarities.
+    Large problems (the 49408-entry sub-word table) run on the MFMA GEMM with three-term bf16 splits of the normalised operands (~1e-5
+    accurate) followed by sc_cosine_refine, which recomputes every entry within 1e-3 of its row maximum in fp32 -- the arg-max is decided
+    by fp32 arithmetic either way.  Small problems / `exact=True`: the fp32 SIMT kernel for the whole matrix."""
     _need_cuda(a, emb)
-    a, emb = a.float().contiguous(), emb.detach().float().contiguous()
+    a = a.float().contiguous()
     R, E = a.shape
     V = emb.shape[0]
-    ws = torch.empty(lib().sc_cosine_workspace_bytes(R, V), device=a.device, dtype=torch.uint8)
+    if exact is None:
+        exact = not (E % 64 == 0 and V % 4 == 0 and R * V >= (1 << 22))
     out = torch.empty(R, V, device=a.device, dtype=torch.float32)
-    check(lib().sc_cosine_scores(ptr(a), ptr(emb), ptr(ws), ptr(out), R, V, E, eps, stream()), "sc_cosine_scores")
+    if exact:
+        embf = emb.detach().float().contiguous()
+        ws = torch.empty(lib().sc_cosine_workspace_bytes(R, V), device=a.device, dtype=torch.uint8)
+        check(lib().sc_cosine_scores(ptr(a), ptr(embf), ptr(ws), ptr(out), R, V, E, eps, stream()), "sc_cosine_scores")
+        return out
+    tab = _cos_table(emb)
+    a3 = split_hilo(l2norm(a), nblk=3)
+    gemm(a3, tab, out=out, out_f32=True)
+    embf = emb.detach()
+    embf = embf if (embf.dtype == torch.float32 and embf.is_contiguous()) else embf.float().contiguous()
+    check(lib().sc_cosine_refine(ptr(out), ptr(a), ptr(embf), R, V, E, 1e-3, eps, stream()), "sc_cosine_refine")
     return out
 
 
@@ -506,13 +540,13 @@ def attn_small_bwd(qkv16, dout, B, L, H, causal=True):
     return dqkv
 
 
-def split_hilo(a):
-    """a f32 [M,K] (row stride allowed) -> bf16 [M, 2K] = (hi | lo), hi + lo = a to ~16 bits."""
+def split_hilo(a, nblk=2):
+    """a f32 [M,K] (row stride allowed) -> bf16 [M, nblk*K] = (hi | lo) or (hi | lo | hi), hi + lo = a to ~16 bits."""
     _need_cuda(a)
     assert a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1
     M, K = a.shape
-    out = torch.empty(M, 2 * K, device=a.device, dtype=bf16)
-    check(lib().sc_split_hilo_bf16(ptr(a), a.stride(0), ptr(out), M, K, stream()), "sc_split_hilo_bf16")
+    out = torch.empty(M, nblk * K, device=a.device, dtype=bf16)
+    check(lib().sc_split_hilo_bf16(ptr(a), a.stride(0), ptr(out), M, K, nblk, stream()), "sc_split_hilo_bf16")
     return out
 
 

@@ -313,3 +313,23 @@ def test_image_normalize_u8_and_collate_to_device():
     assert batch["wav"].is_cuda and batch["wav"].shape == (3, 1600) and not batch["wav_len"].is_cuda
     assert float(batch["wav"][1, 400:].abs().max()) == 0.0
     torch.testing.assert_close(batch["image"].cpu(), ref, atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("R,V,E", [(2048, 49408, 512), (4096, 1024, 64)])
+def test_cosine_scores_mfma_path_keeps_the_fp32_argmax(R, V, E):
+    """Large keyword-vs-sub-word score matrices run on the MFMA GEMM (three-term bf16 splits) + sc_cosine_refine: values within 3e-5 of the
+    fp32 SIMT kernel, and the row arg-max (what the quantiser picks) identical to the fp32 kernel's -- including planted near-ties."""
+    from speechclip_amd import ops
+    g = _g(R + V)
+    emb = torch.nn.Parameter((0.02 * torch.randn(V, E, generator=g)).cuda(), requires_grad=False)
+    a = torch.randn(R, E, generator=g).cuda()
+    with torch.no_grad():                      # near-ties: rows 0..63 get two sub-words at almost the same angle
+        for r in range(64):
+            a[r] = emb[5 + r] * (1 + 1e-3) + emb[700 + r] * (1 - 1e-3) * (emb[5 + r].norm() / emb[700 + r].norm())
+    exact = ops.cosine_scores(a, emb, exact=True)
+    fast = ops.cosine_scores(a, emb)           # auto: R*V >= 4M -> MFMA path
+    assert (fast - exact).abs().max().item() < 3e-5
+    assert torch.equal(fast.argmax(-1), exact.argmax(-1))
+    t_fast, _, _ = ops.vq_fwd(fast, 8)
+    t_exact, _, _ = ops.vq_fwd(exact, 8)
+    assert torch.equal(t_fast, t_exact)
