@@ -1,16 +1,18 @@
 #!/bin/bash
-# Build an A/B pair of the product library: A = gemm.hip of a git revision (default HEAD), B = the working tree.  Output: tools/ab/lib{A,B}.so
+# A/B builds of the product library: recompile ONE source with extra flags (or from another git revision) and link it with the current
+# objects into tools/ab/lib<name>.so; run the two libraries in the same gpurun call with SPEECHCLIP_HIP_LIB=tools/ab/lib<name>.so.
+#   tools/build_ab.sh attention.hip "-DSC_ATTN_ABL=1" noexp        # working-tree source + flags
+#   tools/build_ab.sh gemm.hip "" old HEAD~3                       # the file as of a revision
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-REV=${1:-HEAD}
+SRC=$1; EXTRA=$2; NAME=${3:-B}; REV=$4
 CS=$ROOT/speechclip_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form=1 -I$CS"
 mkdir -p $ROOT/tools/ab
 make -C $CS -j8 >/dev/null
-git -C $ROOT show $REV:speechclip_amd/csrc/gemm.hip > $ROOT/tools/ab/gemm_A.hip
-git -C $ROOT show $REV:speechclip_amd/csrc/common.h > $ROOT/tools/ab/common.h
-(cd $ROOT/tools/ab && hipcc $FLAGS -I$ROOT/tools/ab -c gemm_A.hip -o gemm_A.o 2>&1 | grep -E "error" || true)
-OBJS=$(ls $CS/*.o | grep -v gemm.o)
-hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $ROOT/tools/ab/gemm_A.o -o $ROOT/tools/ab/libA.so
-cp $ROOT/speechclip_amd/libspeechclip_hip.so $ROOT/tools/ab/libB.so
-ls -la $ROOT/tools/ab/*.so
+IN=$CS/$SRC
+if [ -n "$REV" ]; then IN=$ROOT/tools/ab/${NAME}_$SRC; git -C $ROOT show $REV:speechclip_amd/csrc/$SRC > $IN; fi
+hipcc $FLAGS $EXTRA -c $IN -o $ROOT/tools/ab/${NAME}_${SRC%.hip}.o
+OBJS=$(ls $CS/*.o | grep -v "/${SRC%.hip}.o$")
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $ROOT/tools/ab/${NAME}_${SRC%.hip}.o -L/opt/rocm/lib -lhipblaslt -Wl,-rpath,/opt/rocm/lib -o $ROOT/tools/ab/lib$NAME.so
+ls -la $ROOT/tools/ab/lib$NAME.so
