@@ -357,6 +357,24 @@ def gen_end_to_end(kwclip_mod, OrderedNamespace, tag, hubert_cfg, clip_cfg, casc
         for k, prm in sc.parallel_branch.named_parameters():
             assert torch.allclose(prm.grad, torch.from_numpy(arrays["grad/parallel_branch." + k]), atol=2e-5, rtol=1e-3), k
         assert torch.allclose(sc.ws_weights.grad, torch.from_numpy(arrays["grad/audio_encoder.weightedsum_layer.weights"]), atol=2e-5, rtol=1e-3)
+    if parallel and not cascaded:
+        # a short optimisation trajectory with the reference's own modules and optimizer recipe (Adam, weight decay 1e-6, clip_grad_norm_ 4:
+        # spchclp_p.yaml:96-118,:125), dropout off (eval mode), on a deep copy so the saved weights stay the initial ones
+        import copy
+        m2 = copy.deepcopy(model)
+        prm2 = [p for k, p in m2.named_parameters() if k.startswith("parallel_branch.") or k == "audio_encoder.weightedsum_layer.weights"]
+        opt2 = torch.optim.Adam(prm2, lr=1e-3, weight_decay=1e-6)
+        seq = []
+        for _ in range(4):
+            opt2.zero_grad()
+            lg, _, _ = m2.forward(batch)
+            l2 = m2.compute_loss(lg)["loss"]
+            seq.append(l2.item())
+            l2.backward()
+            torch.nn.utils.clip_grad_norm_(prm2, 4.0)
+            opt2.step()
+        arrays["train/loss_seq"] = np.array(seq, dtype=np.float64)
+        del m2
     if cascaded and not parallel:
         # TRAIN-mode gradients of the cascaded tail from the reference's own modules: batch-statistics Kw_BatchNorm, straight-through VQ
         # (my_vector_quantizer.py:133-141), gradients through the frozen CLIP text tower.  Attention dropout is set to 0 (its RNG stream is
