@@ -288,9 +288,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         if (j + 2 < nkv) tile_body(j + 2, std::integral_constant<int, 2>{});
     }
 
-    if (TRACE && trace && tid == 0) {
-        unsigned long long* tr = trace + (size_t)id * 8;
+    if (TRACE && trace && lane == 0) {     // one row per wave: [id][wave][8]
+        unsigned long long* tr = trace + ((size_t)id * NW + wave) * 8;
         tr[0] = tr_qk; tr[1] = tr_sm; tr[2] = tr_pv; tr[3] = tr_bar; tr[4] = nkv; tr[5] = tr_start; tr[6] = __builtin_amdgcn_s_memrealtime();
+        tr[7] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | ((32 - 1) << 11));
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
