@@ -40,9 +40,36 @@ except Exception:  # noqa: BLE001
             ckpt = torch.load(path, map_location=map_location, weights_only=False)
             config = ckpt["hyper_parameters"]["config"]
             model = cls(config)
-            sd = {k: v for k, v in ckpt["state_dict"].items() if not k.startswith("cascaded_branch.clip.")}  # duplicate of clip.*
-            model.load_state_dict(sd, strict=strict)
+            load_checkpoint_state(model, ckpt["state_dict"], strict=strict)
             return model
+
+
+def load_checkpoint_state(model: nn.Module, state_dict: dict, strict: bool = True):
+    """Load a reference checkpoint's `state_dict` into `model`.
+
+    Reference checkpoints carry the shared CLIP tower twice -- `clip.*` and `cascaded_branch.clip.*`, because KW_CascadedBranch registers
+    the shared ClipModel as a sub-module (kwClip.py:720) -- and so does this model's own state_dict.  Both spellings are accepted: whichever
+    of the two is absent from the checkpoint is aliased from the other, nothing is dropped.  Keys that are derived state rather than weights
+    (the loss's identity-matrix buffers, losses.py:126) may be missing or extra; anything else missing / unexpected raises under `strict`."""
+    sd = dict(state_dict)
+    dup, own = "cascaded_branch.clip.", "clip."
+    want = model.state_dict().keys()
+    for k in want:
+        if k in sd:
+            continue
+        if k.startswith(dup) and own + k[len(dup):] in sd:
+            sd[k] = sd[own + k[len(dup):]]
+        elif k.startswith(own) and dup + k[len(own):] in sd:
+            sd[k] = sd[dup + k[len(own):]]
+    if not any(k.startswith(dup) for k in want):          # parallel-only model fed a checkpoint that has the duplicate tower
+        sd = {k: v for k, v in sd.items() if not k.startswith(dup)}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    derived = ("criterion.eye_mat", "criterion.neg_eye_mat")
+    bad_missing = [k for k in missing if not k.startswith(derived)]
+    bad_unexpected = [k for k in unexpected if not k.startswith(derived)]
+    if strict and (bad_missing or bad_unexpected):
+        raise RuntimeError(f"load_checkpoint_state: missing keys {bad_missing}, unexpected keys {bad_unexpected}")
+    return bad_missing, bad_unexpected
 
 
 class BaseLightningModel(_Base):

@@ -120,7 +120,7 @@ class KWClipBase(BaseLightningModel):
         losses_ = self.compute_loss(parallel.gather_loss_feats(outputs["loss_feats"]))
         self.log_dict(self._reduce_metrics("val", losses_, outputs["log_metrics"]), on_step=True, on_epoch=True, prog_bar=True,
                       logger=True, sync_dist=True)
-        others = outputs["others"]
+        others = parallel.gather_rows_dict(outputs["others"])     # all ranks' rows: recall is ranked against the full candidate pool
         for k in others:
             if isinstance(others[k], torch.Tensor):
                 others[k] = others[k].detach().cpu()

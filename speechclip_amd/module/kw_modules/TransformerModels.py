@@ -37,10 +37,11 @@ _CAST_CACHE = {}
 
 
 def cached_cast(t: torch.Tensor, dtype) -> torch.Tensor:
-    """Detached, contiguous copy of parameter `t` in `dtype`, rebuilt only when the parameter changes (the in-place version counter moves
-    on optimizer steps / load_state_dict): the eval forward does not re-cast the frozen branch weights on every call."""
+    """Detached, contiguous copy of parameter `t` in `dtype`, rebuilt only when the parameter changes (torch's in-place version counter
+    moves on torch optimizer steps / load_state_dict; ops.param_epoch() moves on FusedAdam steps, which write through raw pointers): the
+    eval forward does not re-cast the frozen branch weights on every call."""
     key = (t.data_ptr(), dtype)
-    ver = (t._version, t.device, tuple(t.shape))
+    ver = (t._version, ops.param_epoch(t), t.device, tuple(t.shape))
     hit = _CAST_CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is t:      # same tensor OBJECT: a freed tensor's address can be reused
         return hit[1]
@@ -55,7 +56,7 @@ def _pool_operands(cls, in_w, in_b, heads):
     """Parameter-only preprocessing of the algebraic CLS pooling (cached per parameter version, like weight-norm folding):
     u_r = scale * Wk_h^T Q_{q,h},  beta_r = scale * Q_{q,h} . bk_h  for r = (q, h);  Q = Wq cls + bq."""
     key = (cls.data_ptr(), in_w.data_ptr(), in_b.data_ptr(), heads)
-    ver = (cls._version, in_w._version, in_b._version, cls.device)
+    ver = (cls._version, in_w._version, in_b._version, ops.param_epoch(cls, in_w, in_b), cls.device)
     hit = _POOL_CACHE.get(key)
     if hit is not None and hit[0] == ver and all(r() is o for r, o in zip(hit[2], (cls, in_w, in_b))):   # object identity, not just addresses
         return hit[1]

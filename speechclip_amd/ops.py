@@ -19,6 +19,23 @@ PROFILE_SIDE = []     # (start, end) HIP events of every side-stream window (the
 
 _GEMM_WS = {}
 
+# Parameter epoch: bumped by every optimizer step that writes parameters through raw pointers (train_tail.FusedAdam -> sc_adam_step does not
+# move torch's per-tensor version counter).  Every parameter-derived cache (bf16 weight casts, pooling operands, cosine / VQ tables) carries
+# it in its key, so an eval forward after training steps never sees pre-step weights.
+_PARAM_EPOCH = [0]
+
+
+def param_epoch(*tensors) -> int:
+    """Current epoch; with tensors given, -1 if none of them is trainable (a frozen tensor cannot be written by an optimizer step, so its
+    derived tables -- the 49408-row sub-word tables -- are not rebuilt after every step)."""
+    if tensors and not any(t.requires_grad for t in tensors):
+        return -1
+    return _PARAM_EPOCH[0]
+
+
+def bump_param_epoch() -> None:
+    _PARAM_EPOCH[0] += 1
+
 
 def _ensure_gemm_workspace(dev):
     """One 64 MiB scratch buffer per process (one process per GPU) for the plain-GEMM library path (sc_set_gemm_workspace)."""
@@ -282,14 +299,14 @@ def _cos_table(emb):
     import weakref
     key = emb.data_ptr()
     hit = _COS_TABLES.get(key)
-    if hit is not None and hit[0] == (emb._version, tuple(emb.shape)) and hit[2]() is emb:
+    if hit is not None and hit[0] == (emb._version, param_epoch(emb), tuple(emb.shape)) and hit[2]() is emb:
         return hit[1]
     en = l2norm(emb.detach().float().contiguous())
     hi = en.to(bf16)
     lo = (en - hi.float()).to(bf16)
     tab = torch.cat([hi, hi, lo], dim=1).contiguous()
     _COS_TABLES.clear()
-    _COS_TABLES[key] = ((emb._version, tuple(emb.shape)), tab, weakref.ref(emb))
+    _COS_TABLES[key] = ((emb._version, param_epoch(emb), tuple(emb.shape)), tab, weakref.ref(emb))
     return tab
 
 

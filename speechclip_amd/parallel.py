@@ -19,12 +19,8 @@ def world():
     return 0, 1
 
 
-def gather_loss_feats(feats: Dict[str, torch.Tensor], force: bool = False) -> Dict[str, torch.Tensor]:
-    """{id [B] i64, image_feat [B,E], parallel_audio_feat / cascaded_audio_feat [B,E]} -> same keys, global batch.
-    `force`: run the packed collective even at world size 1 (single-GPU check of the RCCL path)."""
-    rank, ws = world()
-    if ws == 1 and not (force and dist.is_available() and dist.is_initialized()):
-        return feats
+def pack_feats(feats: Dict[str, torch.Tensor]):
+    """-> (packed f32 [B, sum(E_k) + 2], keys, widths): every float feature side by side, the int64 ids bit-cast into the last two fp32 lanes."""
     keys = [k for k in sorted(feats) if k != "id" and torch.is_tensor(feats[k])]
     ids = feats["id"].to(torch.int64).contiguous()
     B = ids.shape[0]
@@ -33,14 +29,60 @@ def gather_loss_feats(feats: Dict[str, torch.Tensor], force: bool = False) -> Di
     packed = torch.empty(B, sum(widths) + 2, device=dev, dtype=torch.float32)
     off = 0
     for k, w in zip(keys, widths):
-        packed[:, off:off + w] = feats[k].float()
+        packed[:, off:off + w] = feats[k].detach().float()
         off += w
     packed[:, off:off + 2] = ids.to(dev).view(torch.int32).view(B, 2).view(torch.float32)   # bit-cast, no value conversion
-    out = torch.empty(ws * B, packed.shape[1], device=dev, dtype=torch.float32)
-    dist.all_gather_into_tensor(out, packed)
+    return packed, keys, widths
+
+
+def unpack_feats(out: torch.Tensor, keys, widths) -> Dict[str, torch.Tensor]:
     res, off = {}, 0
     for k, w in zip(keys, widths):
         res[k] = out[:, off:off + w].contiguous()
         off += w
     res["id"] = out[:, off:off + 2].contiguous().view(torch.int32).view(-1, 2).view(torch.int64).view(-1)
+    return res
+
+
+def all_gather_packed(packed: torch.Tensor) -> torch.Tensor:
+    """THE exchange step: one all_gather_into_tensor (RCCL over xGMI) of the packed per-rank rows, rank-major."""
+    rank, ws = world()
+    out = torch.empty(ws * packed.shape[0], packed.shape[1], device=packed.device, dtype=packed.dtype)
+    dist.all_gather_into_tensor(out, packed.contiguous())
+    return out
+
+
+def gather_loss_feats(feats: Dict[str, torch.Tensor], force: bool = False) -> Dict[str, torch.Tensor]:
+    """{id [B] i64, image_feat [B,E], parallel_audio_feat / cascaded_audio_feat [B,E]} -> same keys, global batch.
+    `force`: run the packed collective even at world size 1 (single-GPU check of the RCCL path)."""
+    rank, ws = world()
+    if ws == 1 and not (force and dist.is_available() and dist.is_initialized()):
+        return feats
+    packed, keys, widths = pack_feats(feats)
+    return unpack_feats(all_gather_packed(packed), keys, widths)
+
+
+def gather_rows_dict(d: dict) -> dict:
+    """Validation outputs (`others`: id, audio_feat, image_feat, text_feat, keywords ...): every tensor whose dim 0 is the local batch is
+    all-gathered rank-major (float tensors of any trailing shape in ONE packed collective with the ids; other integer tensors one collective
+    each), non-tensors are passed through.  The reference's DataParallel hands validation_epoch_end the outputs of ALL replicas
+    (kwClip.py:193-275): recall is ranked against the full candidate pool, not a per-rank shard."""
+    rank, ws = world()
+    if ws == 1:
+        return d
+    B = d["id"].shape[0]
+    flt = {k: v for k, v in d.items() if torch.is_tensor(v) and v.is_floating_point() and v.dim() >= 2 and v.shape[0] == B}
+    shapes = {k: v.shape[1:] for k, v in flt.items()}
+    feats = {k: v.reshape(B, -1) for k, v in flt.items()}
+    feats["id"] = d["id"]
+    out = gather_loss_feats(feats)
+    res = dict(d)
+    for k in flt:
+        res[k] = out[k].view(ws * B, *shapes[k]).to(flt[k].dtype)
+    res["id"] = out["id"]
+    for k, v in d.items():
+        if k != "id" and torch.is_tensor(v) and not v.is_floating_point() and v.dim() >= 1 and v.shape[0] == B:
+            g = torch.empty(ws * B, *v.shape[1:], device=v.device, dtype=v.dtype)
+            dist.all_gather_into_tensor(g, v.contiguous())
+            res[k] = g
     return res

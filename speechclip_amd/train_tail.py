@@ -15,7 +15,7 @@ parameters the reference optimises and any torch optimizer -- or `FusedAdam` bel
   TextTowerTrainFn      : frozen CLIP text tower with the gradient w.r.t. its input embeddings     (clip_official.py:220-264)
   L2NormFn              : x / |x|                                                      (kwClip.py:1436)
   MaskedContrastiveFn   : masked InfoNCE on the gathered global batch                  (losses.py:185-245)
-  GatherFeatsFn         : RCCL all-gather whose backward keeps the local rows           (replaces DP's gather, kwClip.py:147-191)
+  PackedGatherFn        : ONE RCCL all-gather of all features + ids whose backward keeps the local rows (replaces DP's gather, kwClip.py:147-191)
 
 Dropout (0.1 at four sites of nn.TransformerEncoderLayer) uses a counter-based hash RNG inside the kernels, seeded per call from
 torch's generator: masks are reproducible from (seed, site) and are regenerated -- not stored -- in the backward.
@@ -294,12 +294,12 @@ def _vq_tables(emb):
     import weakref
     key = emb.data_ptr()
     hit = _VQ_TABLES.get(key)
-    if hit is not None and hit[0] == (emb._version, tuple(emb.shape)) and hit[2]() is emb:
+    if hit is not None and hit[0] == (emb._version, ops.param_epoch(emb), tuple(emb.shape)) and hit[2]() is emb:
         return hit[1]
     e = emb.detach().float().contiguous()
     out = (_dup_k(e.to(BF)), _dup_k(ops.l2norm(e).t().contiguous().to(BF)))
     _VQ_TABLES.clear()
-    _VQ_TABLES[key] = ((emb._version, tuple(emb.shape)), out, weakref.ref(emb))
+    _VQ_TABLES[key] = ((emb._version, ops.param_epoch(emb), tuple(emb.shape)), out, weakref.ref(emb))
     return out
 
 
@@ -411,49 +411,46 @@ class MaskedContrastiveFn(torch.autograd.Function):
     def backward(ctx, dloss):
         da, dinv = ctx.saved_tensors
         g = dloss.float()
-        dtemp = (dinv * ctx.inv_t * g).reshape(()) if ctx.has_temp else None       # inv_t = exp(param)
+        # inv_t = exp(param).  Every rank evaluates the FULL global loss, so every rank holds the full d loss / d log-temperature, while
+        # FusedAdam SUMS the flat gradient over ranks (right for the branch weights, whose per-rank gradients are partial sums through the
+        # local rows): the temperature's share is therefore 1/ws per rank.
+        ws = parallel.world()[1]
+        dtemp = (dinv * (ctx.inv_t / ws) * g).reshape(()) if ctx.has_temp else None
         return da * g, None, None, dtemp, None, None, None, None, None
 
 
-class GatherFeatsFn(torch.autograd.Function):
-    """all_gather of [B_local, E] rows in rank-major order.  Every rank evaluates the SAME global loss, so the gradient of its local
-    rows is simply its slice of d loss / d gathered (no reduce-scatter); parameter gradients are summed over ranks afterwards."""
+class PackedGatherFn(torch.autograd.Function):
+    """The training-time exchange step as ONE collective: all float features of the rank are packed side by side with the bit-cast ids
+    (parallel.pack_feats), all-gathered rank-major, and unpacked.  Every rank evaluates the SAME global loss, so the gradient of its local
+    rows is simply its slice of d loss / d gathered (no reduce-scatter); parameter gradients are summed over ranks afterwards (FusedAdam)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, ids, keys, *tensors):
         rank, ws = parallel.world()
-        ctx.rank, ctx.B = rank, x.shape[0]
-        if ws == 1:
-            return x
-        out = torch.empty(ws * x.shape[0], *x.shape[1:], device=x.device, dtype=x.dtype)
-        dist.all_gather_into_tensor(out, x.contiguous())
-        return out
+        feats = dict(zip(keys, tensors), id=ids)
+        packed, pkeys, widths = parallel.pack_feats(feats)
+        out = parallel.unpack_feats(parallel.all_gather_packed(packed), pkeys, widths)
+        ctx.rank, ctx.B = rank, ids.shape[0]
+        ctx.mark_non_differentiable(out["id"])
+        return (out["id"],) + tuple(out[k] for k in keys)
 
     @staticmethod
-    def backward(ctx, dy):
-        return dy[ctx.rank * ctx.B:(ctx.rank + 1) * ctx.B]
+    def backward(ctx, _did, *dys):
+        lo, hi = ctx.rank * ctx.B, (ctx.rank + 1) * ctx.B
+        return (None, None) + tuple(None if dy is None else dy[lo:hi] for dy in dys)
 
 
 def gather_loss_feats_train(feats: dict) -> dict:
-    """Training-time variant of parallel.gather_loss_feats: differentiable w.r.t. the audio features."""
+    """Training-time variant of parallel.gather_loss_feats: differentiable w.r.t. the audio features, still a single collective."""
     rank, ws = parallel.world()
     if ws == 1:
         return feats
-    out = {}
-    for k, v in feats.items():
-        if k == "id":
-            g = torch.empty(ws * v.shape[0], device=v.device, dtype=v.dtype)
-            dist.all_gather_into_tensor(g, v.contiguous())
-            out[k] = g
-        elif torch.is_tensor(v) and v.requires_grad:
-            out[k] = GatherFeatsFn.apply(v)
-        elif torch.is_tensor(v):
-            g = torch.empty(ws * v.shape[0], *v.shape[1:], device=v.device, dtype=v.dtype)
-            dist.all_gather_into_tensor(g, v.contiguous())
-            out[k] = g
-        else:
-            out[k] = v
-    return out
+    keys = tuple(k for k in sorted(feats) if k != "id" and torch.is_tensor(feats[k]))
+    outs = PackedGatherFn.apply(feats["id"], keys, *[feats[k] for k in keys])
+    res = {k: v for k, v in feats.items() if k not in keys and k != "id"}
+    res["id"] = outs[0]
+    res.update(dict(zip(keys, outs[1:])))
+    return res
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -501,3 +498,40 @@ class FusedAdam(torch.optim.Optimizer):
         self.last_grad_norm = nc
         self.steps += 1
         ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.steps, g["lr"], g["betas"], g["eps"], g["weight_decay"], clip_coef=nc)
+        # sc_adam_step wrote the parameters through raw pointers: torch's per-tensor version counters did not move, so every
+        # parameter-derived cache of the eval path (bf16 casts, pooling operands) is invalidated through the global epoch instead
+        ops.bump_param_epoch()
+
+    # ---- checkpoint / resume (Lightning saves optimizer.state_dict() and restores it under --resume, base_task.py:60-61,:212)
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["fused"] = {"m": self.m.detach().clone(), "v": self.v.detach().clone(), "steps": int(self.steps),
+                       "numel": [int(p.numel()) for p in self._params]}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        fused = state_dict.pop("fused", None)
+        super().load_state_dict(state_dict)
+        if fused is not None:
+            if list(fused["numel"]) != [int(p.numel()) for p in self._params]:
+                raise ValueError("FusedAdam.load_state_dict: parameter layout differs from the checkpoint's")
+            self.m.copy_(fused["m"].to(self.m.device))
+            self.v.copy_(fused["v"].to(self.v.device))
+            self.steps = int(fused["steps"])
+        self._reattach()
+
+    def _reattach(self):
+        """p.data / p.grad back onto the flat buffers (a module.load_state_dict copies in place and keeps the views; anything that REPLACED
+        p.data -- module.to(), a manual assignment -- is folded back here)."""
+        off = 0
+        for p in self._params:
+            k = p.numel()
+            view = self.flat_p[off:off + k].view_as(p)
+            if p.data.data_ptr() != view.data_ptr():
+                view.copy_(p.data.detach().float())
+                p.data = view
+            if p.grad is None or p.grad.data_ptr() != self.flat_g[off:off + k].data_ptr():
+                p.grad = self.flat_g[off:off + k].view_as(p)
+            off += k
+        ops.bump_param_epoch()

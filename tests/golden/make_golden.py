@@ -271,8 +271,54 @@ def tiny_config(OrderedNamespace, yaml_path, d_model, n_kw=8, cascaded=False, pa
     return OrderedNamespace(cfg)
 
 
+def plant_decisive_keywords(model, batch, gen):
+    """Second cascaded fixture: make every arg-max of the sub-word retrieval decisive, so that a bf16 implementation must
+    reproduce the reference's VQ targets EXACTLY and the embedding / loss / gradient checks need no `if targets agree` escape.
+      1. Kw_BatchNorm's running statistics are set to the statistics of this batch (what a trained model's running statistics look like for
+         in-distribution data; also makes the train-mode and eval-mode keyword vectors coincide);
+      2. for every (utterance, keyword) row, one (non-special) row of the reduced sub-word table is replaced by a noisy copy of the
+         reference's own keyword vector for that row, scaled to the table's typical norm.
+    Everything is computed by the reference's own modules (hooks on model.cascaded_branch.bn_layer).  Returns the smallest top1 - top2 margin."""
+    import torch.nn.functional as F
+    cb = model.cascaded_branch
+    cap = {}
+    h = cb.bn_layer.register_forward_pre_hook(lambda m, inp: cap.__setitem__("x", inp[0].detach().clone()))
+    with torch.no_grad():
+        model.forward(batch)
+    h.remove()
+    x = cap["x"]                                                      # [B, K, D] = linear_proj output
+    B, K, D = x.shape
+    flat = x.permute(0, 2, 1).reshape(B, -1)                          # kw_bn.py:122-126 feature order
+    bn = cb.bn_layer.bn_layer
+    with torch.no_grad():
+        bn.running_mean.copy_(flat.mean(0))
+        bn.running_var.copy_(flat.var(0, unbiased=False))
+    h = cb.bn_layer.register_forward_hook(lambda m, inp, out: cap.__setitem__("kw", out.detach().clone()))
+    with torch.no_grad():
+        model.forward(batch)
+    h.remove()
+    kw = cap["kw"].reshape(B * K, D)
+    emb = model.clip.model.token_embedding.weight
+    typical = emb.norm(dim=-1).mean().item()
+    # In a random-init model the K keyword rows of one utterance nearly coincide after the BatchNorm (1-head attention over random frames is
+    # close to uniform pooling: the utterance-dependent part is shared by all K queries, the query-dependent part is utterance-independent
+    # and removed by the BatchNorm), while different utterances are decorrelated: one planted sub-word per utterance.
+    kn = F.normalize(kw, dim=-1).view(B, K, D)
+    assign = [b for b in range(B) for _ in range(K)]
+    with torch.no_grad():
+        for b in range(B):
+            noise = F.normalize(torch.randn(D, generator=gen), dim=0)
+            emb[4 + b] = typical * F.normalize(F.normalize(kn[b].mean(0), dim=0) + 0.1 * noise, dim=0)
+    cos = F.cosine_similarity(kw[:, None, :], emb[None, :, :], dim=-1)
+    cos[:, [0, 2, 3]] = float("-inf")
+    top2 = cos.topk(2, dim=-1).values
+    print(f"planted {B} sub-words for {B * K} keyword rows; own cos min {top2[:, 0].min():.3f}, runner-up max {top2[:, 1].max():.3f}")
+    assert torch.equal(cos.argmax(-1), torch.tensor(assign) + 4)
+    return (top2[:, 0] - top2[:, 1]).min().item()
+
+
 def gen_end_to_end(kwclip_mod, OrderedNamespace, tag, hubert_cfg, clip_cfg, cascaded, parallel, lens, normalize_hiddenstates,
-                   reduce_vocab_ids=None):
+                   reduce_vocab_ids=None, plant_margins=False):
     STATE["hubert_cfg"], STATE["clip_cfg"] = hubert_cfg, clip_cfg
     vocab_path = None
     if reduce_vocab_ids is not None:
@@ -298,6 +344,11 @@ def gen_end_to_end(kwclip_mod, OrderedNamespace, tag, hubert_cfg, clip_cfg, casc
     res = clip_cfg.image_resolution
     batch = {"wav": wav, "wav_len": torch.tensor(lens), "image": torch.randn(B, 3, res, res, generator=g),
              "id": torch.tensor([7, 7, 3, 9, 11, 3][:B])}
+    min_margin = None
+    if plant_margins:
+        min_margin = plant_decisive_keywords(model, batch, g)
+        print(f"{tag}: smallest arg-max margin after planting = {min_margin:.3f}")
+        assert min_margin > 0.2
     with torch.no_grad():
         losses, log_metrics, others = model.forward(batch)
         loss = model.compute_loss(losses)
@@ -335,6 +386,9 @@ def gen_end_to_end(kwclip_mod, OrderedNamespace, tag, hubert_cfg, clip_cfg, casc
         arrays["vq_targets"] = others["vq_results"]["targets"].numpy()
         arrays["vq_ent_per_t"] = others["vq_results"]["ent_per_t"].numpy()
         arrays["keywords"] = others["keywords"].numpy()
+        if plant_margins:
+            arrays["min_margin"] = np.float64(min_margin)
+            assert int(others["vq_results"]["targets"].min()) >= 4 and int(others["vq_results"]["targets"].max()) < 4 + len(lens) * 8
     my_loss = sc.compute_loss(o, w_par=1.0 if parallel else 0.0, w_casc=1.0 if cascaded else 0.0)["loss"].item()
     assert abs(my_loss - loss["loss"].item()) < 1e-5
     if parallel and not cascaded:
@@ -391,6 +445,8 @@ def gen_end_to_end(kwclip_mod, OrderedNamespace, tag, hubert_cfg, clip_cfg, casc
         arrays["train/cascaded_audio_feat"] = losses_g["cascaded_audio_feat"].detach().numpy().copy()
         arrays["train/loss"] = np.float64(loss_g.item())
         arrays["train/vq_targets"] = others_g["vq_results"]["targets"].numpy().copy()
+        if plant_margins:       # train-mode BatchNorm uses the same batch statistics the running buffers were set to: same decisive targets
+            assert torch.equal(others_g["vq_results"]["targets"], others["vq_results"]["targets"])
         n_grad = 0
         for k, prm in model.named_parameters():
             if prm.grad is not None and ((k.startswith("cascaded_branch.") and not k.startswith("cascaded_branch.clip.")) or
@@ -469,6 +525,8 @@ def main():
     vocab = np.array([0, 320, 510, 511] + list(range(5, 300, 3)))
     gen_end_to_end(kwclip_mod, OrderedNamespace, "tiny_base_c", tiny_b, tiny_clip, cascaded=True, parallel=False,
                    lens=[8000, 5000, 6777, 1200], normalize_hiddenstates=False, reduce_vocab_ids=vocab)
+    gen_end_to_end(kwclip_mod, OrderedNamespace, "tiny_base_c2", tiny_b, tiny_clip, cascaded=True, parallel=False,
+                   lens=[8000, 7600, 7777, 7100], normalize_hiddenstates=False, reduce_vocab_ids=vocab, plant_margins=True)
 
 
 if __name__ == "__main__":

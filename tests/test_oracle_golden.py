@@ -95,9 +95,10 @@ def test_e2e_parallel_golden(tag, large):
     assert abs(m.compute_loss(o)["loss"].item() - float(g["loss"])) < 1e-5
 
 
-def test_e2e_cascaded_golden():
+@pytest.mark.parametrize("tag", ["tiny_base_c", "tiny_base_c2"])
+def test_e2e_cascaded_golden(tag):
     vocab = torch.tensor([0, 320, 510, 511] + list(range(5, 300, 3)))
-    g, m, batch = _build("tiny_base_c", HubertRefConfig.tiny(), cascaded=True, parallel=False, norm_hidden=False, vocab=vocab)
+    g, m, batch = _build(tag, HubertRefConfig.tiny(), cascaded=True, parallel=False, norm_hidden=False, vocab=vocab)
     o = m(batch)
     assert np.array_equal(o["vq_results"]["targets"].numpy(), g["vq_targets"])
     np.testing.assert_allclose(o["cascaded_audio_feat"].numpy(), g["cascaded_audio_feat"], atol=1e-5)
