@@ -5,7 +5,11 @@ Workload (BASELINE.json configs[1] / SURVEY.md section 8d "C2"): HuBERT-base + C
 compute, per-GPU batch 256, every wave exactly 160000 samples (10 s @ 16 kHz => T = 499), 224^2 images, unique ids,
 random-init weights (no network), synthetic inputs resident in HBM before the timed region.  One "step" = the full
 forward of both towers + head + L2 norms + (N > 1: RCCL all-gather of the embeddings) + masked InfoNCE on the global batch.
-N > 1: one process per GPU (torchrun), weak scaling (256 pairs per GPU), value = all pairs / max-over-ranks time.
+N > 1: one process per GPU, weak scaling (256 pairs per GPU), value = all pairs / max-over-ranks time.  `python bench.py --gpus N` works
+both under an external `python -m torch.distributed.run ...` (RANK / WORLD_SIZE in the environment) and on its own: with --gpus N > 1 and
+no WORLD_SIZE it re-executes itself under torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous) and rank 0 prints the line.
+Every GEMM of the step runs on the hand-written gemm256_kernel; hipBLASLt on the plain shapes is measured BESIDE the headline as
+`vendor_comparator` (never part of `value`).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
   "roofline":     dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of all its launches / their HIP-event time
@@ -61,12 +65,21 @@ def algorithmic_gflop_per_pair(L=160000, d=768, ffn=3072, layers=12, vit_w=768, 
 LARGE = dict(d=1024, ffn=4096, layers=24, vit_w=1024, vit_layers=24, patch=14, E=768)   # HuBERT-large + ViT-L/14 (BASELINE configs[4])
 
 
-def build_model(seed=7122, large=False, cascaded=False):
+def build_model(seed=7122, large=False, cascaded=False, vocab=8112):
     from speechclip_amd.util.shipped_configs import make_config
     from speechclip_amd.model import KWClip_GeneralTransformer
     torch.manual_seed(seed)
-    if cascaded:      # C-base (BASELINE configs[2]): 8 keyword queries -> BatchNorm -> VQ over the 49408 sub-words -> CLIP text tower
-        cfg = make_config(parallel=False, cascaded=True)
+    if cascaded:      # C-base (BASELINE configs[2]): 8 keyword queries -> BatchNorm -> VQ over the sub-word table -> CLIP text tower
+        # spchclp_c.yaml:94 ships a REDUCED vocabulary of 8112 sub-words (`reduce_subword_embbedding`); --vocab 49408 = the full table (stress)
+        vp = None
+        if vocab and vocab < 49408:
+            import tempfile
+            import numpy as np
+            g = torch.Generator().manual_seed(seed)
+            ids = torch.cat([torch.tensor([0, 320, 49406, 49407]), torch.randperm(49000, generator=g)[:vocab - 4] + 321]).numpy()
+            vp = os.path.join(tempfile.gettempdir(), f"bench_vocab_{vocab}_{os.getpid()}.npy")
+            np.save(vp, np.stack([ids, np.arange(len(ids))[::-1] + 1], axis=1))
+        cfg = make_config(parallel=False, cascaded=True, reduce_vocab=vp)
     elif large:
         cfg = make_config(d_model=1024, branch_heads=8, hubert_name="hubert_large_ll60k", clip_name="ViT-L/14", normalize_hiddenstates=True,
                           temperature_trainable=True)
@@ -75,8 +88,21 @@ def build_model(seed=7122, large=False, cascaded=False):
     return KWClip_GeneralTransformer(cfg).eval()
 
 
-def cpu_baseline(model_sd, n_pairs, L):
-    """fp32 CPU oracle (port of the reference's CPU path) on n_pairs of the same workload, all host cores."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(model_sd, n_pairs, L, iters=3):
+    """fp32 CPU oracle (port of the reference's CPU path) on the host cores, SURVEY.md section 8(d) protocol: 1 warm-up + `iters` timed
+    iterations of (a) `n_pairs` fixed-length pairs of the headline workload and (b) the C1 batch (BASELINE configs[0]: 16 pairs, variable
+    lengths); os.cpu_count() and the CPU model stated; per-segment split (CNN / transformer / layer mix + branch / ViT / loss) from module
+    hooks.  The thread count is what torch uses after a probe (its CPU kernels do not scale to all hardware threads on this workload)."""
     from oracle.clip_ref import ClipRefConfig
     from oracle.hubert_ref import HubertRefConfig
     from oracle.speechclip_ref import SpeechClipRef
@@ -87,14 +113,26 @@ def cpu_baseline(model_sd, n_pairs, L):
     ref.parallel_branch.load_state_dict({k[len("parallel_branch."):]: v for k, v in model_sd.items() if k.startswith("parallel_branch.")})
     g = torch.Generator().manual_seed(7122)
 
-    def mk(b):
-        return {"wav": 0.1 * torch.randn(b, L, generator=g), "wav_len": torch.full((b,), L), "image": torch.randn(b, 3, 224, 224, generator=g),
-                "id": torch.arange(b)}
-    # torch's CPU kernels do not scale to hundreds of threads on this workload (measured on the 2 x 64-core box: 16 threads beat
-    # 128 by 3.5x): pick the best of a few thread counts on a 2-pair probe, report the count actually used as `cores`.
+    def mk(b, lens=None):
+        lens = [L] * b if lens is None else lens
+        wav = torch.zeros(b, max(lens))
+        for i, n in enumerate(lens):
+            wav[i, :n] = 0.1 * torch.randn(n, generator=g)
+        return {"wav": wav, "wav_len": torch.tensor(lens), "image": torch.randn(b, 3, 224, 224, generator=g), "id": torch.arange(b)}
+    # segment timers: forward hooks on the oracle's own modules
+    seg = {"cnn": 0.0, "transformer": 0.0, "vit": 0.0, "branch": 0.0}
+    t_in = {}
+
+    def hook(name, mod):
+        mod.register_forward_pre_hook(lambda m, a: t_in.__setitem__(name, time.perf_counter()))
+        mod.register_forward_hook(lambda m, a, o: seg.__setitem__(name, seg[name] + time.perf_counter() - t_in[name]))
+    hook("cnn", ref.encoder.feature_extractor)
+    hook("transformer", ref.encoder.encoder)
+    hook("vit", ref.clip.visual)
+    hook("branch", ref.parallel_branch)
     best, cores = 0.0, 1
     with torch.no_grad():
-        for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
             torch.set_num_threads(n)
             ref(mk(1))
             t0 = time.perf_counter()
@@ -103,15 +141,99 @@ def cpu_baseline(model_sd, n_pairs, L):
             if r > best:
                 best, cores = r, n
     torch.set_num_threads(cores)
-    with torch.no_grad():
-        ref.compute_loss(ref(mk(1)))                         # warm-up
-        t0 = time.perf_counter()
-        o = ref(mk(n_pairs))
-        loss = ref.compute_loss(o)["loss"].item()
-        dt = time.perf_counter() - t0
-    return {"value": round(n_pairs / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{n_pairs} pairs (10 s audio + 224^2 image) through oracle/speechclip_ref.py fp32 with {cores} threads "
-                      f"(best of 8/16/32/64 on a probe; box has {ncpu} hw threads), {dt:.1f} s, loss {loss:.4f}"}
+
+    def run(batch_fn, n):
+        with torch.no_grad():
+            ref.compute_loss(ref(batch_fn()))                 # warm-up
+            for k in seg:
+                seg[k] = 0.0
+            times, t_loss = [], 0.0
+            for _ in range(iters):
+                b = batch_fn()
+                t0 = time.perf_counter()
+                o = ref(b)
+                t1 = time.perf_counter()
+                loss = ref.compute_loss(o)["loss"].item()
+                t2 = time.perf_counter()
+                times.append(t2 - t0)
+                t_loss += t2 - t1
+        tot = sum(times)
+        split = {k: round(v / tot, 4) for k, v in seg.items()}
+        split["loss"] = round(t_loss / tot, 4)
+        split["mix_and_glue"] = round(max(0.0, 1.0 - sum(split.values())), 4)
+        return {"pairs_per_s": round(n * iters / tot, 3), "iter_s": [round(t, 2) for t in times], "segments_frac": split, "loss": round(loss, 4)}
+    fixed = run(lambda: mk(n_pairs), n_pairs)
+    c1_lens = [int(x) for x in torch.randint(L // 4, L + 1, (16,), generator=g)]
+    c1 = run(lambda: mk(16, c1_lens), 16)
+    return {"value": fixed["pairs_per_s"], "unit": "pairs/s", "cores": cores, "kind": "port", "host_hw_threads": ncpu, "cpu_model": _cpu_model(),
+            "timed_iterations": iters, "fixed_length": fixed, "c1_varlen_b16": dict(c1, lens_min_max=[min(c1_lens), max(c1_lens)]),
+            "sample": f"{iters} timed iterations (after 1 warm-up) of {n_pairs} pairs (10 s audio + 224^2 image) through oracle/speechclip_ref.py fp32 "
+                      f"with {cores} torch threads (best of 8/16/32/64/all on a 2-pair probe; host: {ncpu} hardware threads, {_cpu_model()}), "
+                      f"{sum(fixed['iter_s']):.1f} s; plus the C1 batch (16 pairs, variable lengths) {c1['pairs_per_s']} pairs/s"}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU, loopback rendezvous."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """Launcher / exchange-protocol check without a GPU (tests, CPU container): `gloo` process group, random unit embeddings instead of
+    the towers, the SAME packed all-gather (speechclip_amd.parallel), barrier + max-over-ranks timing and JSON contract.  No kernel runs
+    and nothing here is a throughput claim (`data` says so)."""
+    import torch.distributed as dist
+    from speechclip_amd import parallel
+    if world > 1:
+        dist.init_process_group("gloo")
+    B, E = args.batch or 8, 512
+    g = torch.Generator().manual_seed(7122 + rank)
+
+    def step():
+        a = torch.nn.functional.normalize(torch.randn(B, E, generator=g), dim=-1)
+        i = torch.nn.functional.normalize(torch.randn(B, E, generator=g), dim=-1)
+        f = parallel.gather_loss_feats({"id": torch.arange(B) + rank * B, "image_feat": i, "parallel_audio_feat": a})
+        lg = f["parallel_audio_feat"] @ f["image_feat"].t() / 0.07
+        return 0.5 * ((torch.logsumexp(lg, 1) - lg.diagonal()).mean() + (torch.logsumexp(lg, 0) - lg.diagonal()).mean()), f["id"].shape[0]
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, bg = step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    seen = torch.ones(1)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"metric": "speech-image pairs/sec/node (dry run)", "value": round(world * B * args.steps / dt, 2), "unit": "pairs/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dry-run: launcher + exchange protocol on CPU/gloo, no kernels, not a measurement",
+                          "config": {"workload": "dry run", "pairs_per_gpu": B, "global_batch": int(bg), "parallelism": f"dp{world}"},
+                          "ranks_seen": int(seen.item()), "loss": round(float(loss), 5), "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -127,24 +249,42 @@ def main():
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--train", action="store_true", help="time the TRAINING step of the trainable tail instead (forward in train mode + loss.backward() "
                     "+ grad all-reduce + clip + Adam + LR schedule); not the headline metric, reported with config.mode = 'train'")
+    ap.add_argument("--vocab", type=int, default=8112, help="--model cascaded: sub-word table size (8112 = the shipped reduced vocabulary, "
+                    "spchclp_c.yaml:94; 49408 = the full table)")
+    ap.add_argument("--no-vendor-comparator", action="store_true", help="skip the hipBLASLt comparator run beside the headline")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of the launcher + exchange protocol (no GPU, no kernels)")
+    ap.add_argument("--share-gpu", action="store_true", help="TEST HOOK for 1-GPU boxes: all N ranks run on cuda:0 and exchange over gloo, so the N > 1 code "
+                    "path (packed gather, global-batch loss, max-over-ranks timing) executes with the real kernels; the line says so in `data`")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher around us: become one
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    if args.share_gpu:
+        local_rank = 0
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} needs cuda:{local_rank}, but {torch.cuda.device_count()} device(s) are visible (use --dry-run for a CPU protocol check)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" = RCCL on ROCm: xGMI between the GPUs of the node
 
     from speechclip_amd import ops, parallel
     large = args.model == "large"
     if args.batch is None:
         args.batch = 64 if large else 256
     casc = args.model == "cascaded"
-    model = build_model(large=large, cascaded=casc)
+    model = build_model(large=large, cascaded=casc, vocab=args.vocab)
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_pairs > 0 and world == 1 and not args.train and not large and not casc) else None
     model = model.to(dev)
     B, L = args.batch, args.audio_len
@@ -197,6 +337,47 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     pairs_per_s = world * B * args.steps / dt
+    # ---- beside the timed region (all ranks take part; none of it enters `value`)
+    seen = torch.ones(1, device=dev)
+    exchange_ms = None
+    if world > 1:
+        torch.distributed.all_reduce(seen)                    # every rank of the job answered over RCCL
+        with torch.no_grad():
+            E = 768 if large else 512                          # the step's payload: ids + image + audio embeddings of this rank's pairs
+            lf_x = {"id": batch["id"], "image_feat": torch.randn(B, E, device=dev), ("cascaded_audio_feat" if casc else "parallel_audio_feat"): torch.randn(B, E, device=dev)}
+            for _ in range(3):
+                parallel.gather_loss_feats(lf_x)
+            fence()
+            x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            x0.record()
+            for _ in range(20):
+                parallel.gather_loss_feats(lf_x)               # pack + ONE all_gather_into_tensor + unpack: the step's exchange
+            x1.record()
+            fence()
+            t = torch.tensor([x0.elapsed_time(x1) / 20], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            exchange_ms = round(t.item(), 4)
+    vendor = None
+    if not args.no_vendor_comparator and not args.train:
+        # the same step with hipBLASLt taking the plain GEMMs (QKV / out-proj / fc2 / ViT projections): a COMPARATOR for the hand-written
+        # kernel on those shapes, measured with the same fences, reported beside the headline and never part of it
+        ops.set_vendor_gemm(True)
+        for _ in range(2):
+            step()
+        fence()
+        v0 = time.perf_counter()
+        nv = max(3, min(args.steps, 8))
+        for _ in range(nv):
+            step()
+        fence()
+        vdt = time.perf_counter() - v0
+        ops.set_vendor_gemm(False)
+        if world > 1:
+            t = torch.tensor([vdt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            vdt = t.item()
+        vendor = {"kernel": "hipBLASLt on the plain GEMMs (SC_GEMM_VENDOR=1), everything else unchanged", "steps": nv,
+                  "ms_per_step": round(vdt / nv * 1e3, 3), "value": round(world * B * nv / vdt, 2), "unit": "pairs/s"}
     # train mode crops every utterance to audio_encoder.max_audio_len (102400 samples, T = 319) exactly as the reference trains
     mal = int(getattr(model.audio_encoder, "max_audio_len", -1))
     L_eff = min(L, mal) if (args.train and mal > 0) else L
@@ -211,7 +392,9 @@ def main():
             # HBM traffic of the kernel cannot be measured from inside this process (PMC counters need rocprofv3 and their own passes):
             # report the committed per-launch figure of the same command, with its source, or null if it is not there / not this workload
             traffic, tsrc = None, None
-            tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
+            tf = os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")
+            if not os.path.exists(tf):
+                tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
             if os.path.exists(tf) and not args.train and not large and not casc and B == 256 and L == 160000:
                 tj = json.load(open(tf))
                 traffic, tsrc = tj["hand_written_main_stream"]["bytes_per_launch"], tj["source"] + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2; gemm256_kernel + gemm_bf16_kernel launches)"
@@ -260,7 +443,8 @@ def main():
                     "executed_over_algorithmic": round(exe / alg, 4)}
         out = {"metric": "speech-image pairs/sec/node (%s)" % ("Cascaded SpeechCLIP base" if casc else "Parallel SpeechCLIP %s" % args.model), "value": round(pairs_per_s, 2), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "data": "synthetic" if not args.share_gpu else "synthetic; TEST HOOK --share-gpu: all ranks on one GPU over gloo, not a scaling measurement",
                "config": {"workload": ("Cascaded SpeechCLIP base (HuBERT-base + ViT-B/32 + CLIP text tower; flop model = the encoders' GEMMs, the keyword head adds < 1 %)" if casc else
                                        "Parallel SpeechCLIP large (HuBERT-large + ViT-L/14)" if large else "Parallel SpeechCLIP base (HuBERT-base + ViT-B/32)")
                           + " forward + InfoNCE, 10 s/16 kHz audio + 224^2 images",
@@ -269,6 +453,10 @@ def main():
                           "algorithmic_gflop_per_pair": round(total_gf, 2), "mode": "train (tail: branch + layer-mix weights)" if args.train else "forward + loss"},
                "e2e_tflops_per_gpu": round(total_gf * 1e9 * pairs_per_s / world / 1e12, 1),
                "e2e_frac_of_bf16_peak": round(total_gf * 1e9 * pairs_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+               "rccl_ranks_seen": int(seen.item()), "exchange_ms_per_step": exchange_ms,
+               "exchange": ("one packed all_gather_into_tensor over RCCL per step (speechclip_amd/parallel.py); exchange_ms_per_step = pack + collective + unpack, "
+                            "timed beside the step, max over ranks") if world > 1 else None,
+               "vendor_comparator": vendor,
                "loss": round(float(loss), 5), "roofline": roof, "cpu_baseline": None}
         if sd_cpu is not None:
             del model

@@ -107,6 +107,15 @@ int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, con
 int sc_cls_attention_fwd(const void* cls_qkv, const void* kv_x, int64_t ld_kv, const int32_t* lens, void* out, int B, int T,
                          int NQ, int H, int head_dim, float scale, void* stream);
 
+/* Full-row multi-head attention, any head_dim <= 1024 (multiple of 8), arbitrary boolean key-padding mask (uint8 [B, L], 1 = padding;
+ * NULL = none): torch.nn.MultiheadAttention(batch_first) as the reference's pooling heads call it on WHOLE sequences --
+ * TransformerEncoder.forward / extract_hidden_states (avssl/module/kw_modules/TransformerModels.py:77-96) and
+ * MultiheadAttentionAndNorm.forward / extract_hidden_states (:119-129), reached through KW_*Branch.extract_hidden_states
+ * (avssl/model/kwClip.py:828-856, :1049-1076) and feature_extractor_s3prl (:1213-1247).  Not on the hot path (which keeps the CLS rows
+ * only: sc_cls_pool_fwd).  q/k/v: bf16, row (b*L + t) at stride ld_qkv, head h at column h*head_dim; out: bf16 rows of stride ld_out. */
+int sc_attention_rows_fwd(const void* q, const void* k, const void* v, void* out, const uint8_t* key_padding_mask, int B, int H, int L,
+                          int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, void* stream);
+
 /* Algebraic form of the same pooling attention (no K/V of the frames is formed): score_r(x) = x . u_r + beta_r with
  * u_r = scale * Wk_h^T Q_{q,h}, r = (q,h), R = NQ*H <= 8.  `scores` f32 [B*T, R] are the frame scores (one skinny sc_gemm_bf16 with
  * W = u, bias = beta), `cls_scores` f32 [NQ, R] those of the CLS tokens; the kernel soft-maxes over [CLS tokens ; frames t < lens[b]]
@@ -146,7 +155,7 @@ int sc_crop_pad(const float* wav, int64_t ld, const int32_t* starts, const int32
 
 /* ---- CLIP ViT stem -- openai VisionTransformer.forward up to ln_pre (clip_official.py:209) ----- */
 /* sc_image_normalize_u8: torchvision ToTensor + Normalize of CLIP's `_transform` (openai clip.py `_transform`, called through
- *   avssl/data/*_dataset.py image_transform): uint8 [B,H,W,3] (host pointers: mean3 / std3) -> f32 [B,3,H,W]. */
+ *   avssl/data/{flickr,coco}_dataset.py image_transform): uint8 [B,H,W,3] (host pointers: mean3 / std3) -> f32 [B,3,H,W]. */
 int sc_image_normalize_u8(const void* u8_hwc, float* out_chw, int B, int H, int W, const float* mean3, const float* std3, void* stream);
 int sc_vit_patchify(const float* img, void* cols, int B, int R, int p, int Kpad, void* stream);
 int sc_vit_embed(const void* patch, const float* cls, const float* pos, const float* gamma, const float* beta, float* out, int B,

@@ -320,8 +320,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     if (dma_k0 >= 0 && ABL != 1) {   // one LDS-DMA instruction per MFMA group instead of a burst behind the barrier
                         int la = lane_a, lw = lane_w;
                         asm volatile("" : "+v"(la), "+v"(lw));   // keep the 64-bit source addresses out of the loop-invariant set (VGPR pressure)
-                        if (i < 4) glds16(sa.ta + (i * lda64 + dma_k0) + la, dma_slot + (i * 512 + wave * 64) * 16);
-                        else glds16(sa.tw + ((i - 4) * ldw64 + dma_k0) + lw, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
+                        const int dk = (ABL == 7) ? 0 : dma_k0;   // ABL 7 (timing probe, garbage results): the in-loop DMA always re-reads k-chunk 0 = cache hits
+                        if (i < 4) glds16(sa.ta + (i * lda64 + dk) + la, dma_slot + (i * 512 + wave * 64) * 16);
+                        else glds16(sa.tw + ((i - 4) * ldw64 + dk) + lw, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -591,6 +592,7 @@ int launch256(const GemmParams& p, hipStream_t s) {
     if (abl && abl[0] == '4') return launch256_var<4, false>(p, grid, s);
     if (abl && abl[0] == '5') return launch256_var<5, false>(p, grid, s);
     if (abl && abl[0] == '6') return launch256_var<6, false>(p, grid, s);
+    if (abl && abl[0] == '7') return launch256_var<7, false>(p, grid, s);
     return launch256_var<0, false>(p, grid, s);
 }
 

@@ -204,8 +204,9 @@ class KW_ParallelBranch(nn.Module):
         if self.need_projection:
             self.linear_proj = nn.Linear(self.audio_dim, self.out_dim)
 
-    def extract_hidden_states(self, audio_feat, audio_len):
-        raise NotImplementedError("analysis-only path (feature_extractor_s3prl); SURVEY.md section 8f")
+    def extract_hidden_states(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> tuple:
+        """kwClip.py:1049-1076: hidden representation of every layer of the branch over [CLS; frames], CLS position dropped."""
+        return _branch_hidden_states(self, audio_feat, audio_len, 1)
 
     def forward(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> torch.Tensor:
         if torch.is_grad_enabled() and self.cls.requires_grad:
@@ -215,6 +216,16 @@ class KW_ParallelBranch(nn.Module):
             out = ops.gemm(out, TransformerModels.cached_cast(self.linear_proj.weight, torch.bfloat16),
                            TransformerModels.cached_cast(self.linear_proj.bias, torch.float32), out_f32=True)
         return out
+
+
+def _branch_hidden_states(branch, audio_feat: torch.Tensor, audio_len: torch.Tensor, n_cls: int) -> tuple:
+    """Shared body of KW_ParallelBranch / KW_CascadedBranch.extract_hidden_states (kwClip.py:828-856, :1049-1076): full-row pass of
+    [CLS tokens; frames] with the `len + n_cls` key-padding mask, then the CLS positions are cut off."""
+    B, T, D = audio_feat.shape
+    src = torch.cat([branch.cls.detach().to(audio_feat.device, torch.float32).expand(B, -1, -1), audio_feat.detach().float()], dim=1)
+    mask = get_keypadding_mask(max_length=T + n_cls, data_lens=audio_len.to(audio_feat.device) + n_cls).to(audio_feat.device)
+    hidden = branch.self_att.extract_hidden_states(src=src, key_padding_mask=mask)
+    return tuple(x[:, n_cls:, ...] for x in hidden)
 
 
 def _kw_parallel_forward_train(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> torch.Tensor:
@@ -263,6 +274,10 @@ class KW_CascadedBranch(nn.Module):
                                          init_bias=torch.mean(emb, dim=0), init_scale=torch.std(emb, dim=0), std_scale=bn.std_scale,
                                          learnable=bn.learnable if hasattr(bn, "learnable") else True,
                                          parallel=bn.parallel if hasattr(bn, "parallel") else False)
+
+    def extract_hidden_states(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> tuple:
+        """kwClip.py:828-856."""
+        return _branch_hidden_states(self, audio_feat, audio_len, self.keyword_num)
 
     def forward(self, audio_feat: torch.Tensor, audio_len: torch.Tensor):
         if self.training and torch.is_grad_enabled() and self.cls.requires_grad:
@@ -384,9 +399,19 @@ class KWClip_GeneralTransformer(KWClipBase):
         return {"cascaded_audio_feat": c_feat, "parallel_audio_feat": p_feat, "vq_results": vq, "keywords": kw}
 
     def feature_extractor_s3prl(self, wav):
+        """kwClip.py:1213-1247: encoder hidden states followed by the branches' (cascaded first, then parallel; the branch input itself,
+        element [0] of each, is dropped)."""
         wav, wav_len = self.processWavs(wav)
         audio_feat, audio_len, hidden_states = self.forward_audio(wav, wav_len, return_hidden_states=True)
         assert isinstance(hidden_states, tuple)
+        if self.cascaded_branch is not None:
+            c_hidden = self.cascaded_branch.extract_hidden_states(audio_feat, audio_len)
+            assert isinstance(c_hidden, tuple)
+            hidden_states = hidden_states + tuple(c_hidden[1:])
+        if self.parallel_branch is not None:
+            p_hidden = self.parallel_branch.extract_hidden_states(audio_feat, audio_len)
+            assert isinstance(p_hidden, tuple)
+            hidden_states = hidden_states + tuple(p_hidden[1:])
         return hidden_states[-1], hidden_states
 
     def forward(self, batch) -> tuple:

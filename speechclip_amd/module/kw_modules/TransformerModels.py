@@ -130,11 +130,44 @@ class TransformerEncoder(nn.Module):
         x2 = ops.layernorm(y2, f32(L.norm2.weight), f32(L.norm2.bias), self.eps, out_f32=True)
         return ops.layernorm(x2, f32(self.model.norm.weight), f32(self.model.norm.bias), 1e-5)
 
-    def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
-        raise NotImplementedError("full-row forward is off the hot path; use forward_cls (KW_ParallelBranch does)")
+    # ---- full-row path (TransformerModels.py:77-96): every position of [CLS; frames], any boolean key-padding mask.  Off the hot path
+    #      (forward_cls is what KW_ParallelBranch.forward runs); eval-mode arithmetic (no dropout), no autograd.
+    @torch.no_grad()
+    def _layer_rows(self, x32: torch.Tensor, key_padding_mask, B: int, Lq: int) -> torch.Tensor:
+        """One post-LN nn.TransformerEncoderLayer on fp32 rows [B*L, D] -> fp32 rows."""
+        L = self.model.layers[0]
+        sa = L.self_attn
+        D = x32.shape[-1]
+        f32 = lambda t: cached_cast(t, torch.float32)  # noqa: E731
+        w16 = lambda t: cached_cast(t, BF)             # noqa: E731
+        qkv = ops.gemm(x32.to(BF), w16(sa.in_proj_weight), f32(sa.in_proj_bias))
+        att = ops.attention_rows(qkv, B, Lq, self.nhead, D // self.nhead, key_padding_mask)
+        y = ops.gemm(att, w16(sa.out_proj.weight), f32(sa.out_proj.bias), residual=x32, out_f32=True)
+        x1 = ops.layernorm(y, f32(L.norm1.weight), f32(L.norm1.bias), self.eps, out_f32=True)
+        h = ops.gemm(x1.to(BF), w16(L.linear1.weight), f32(L.linear1.bias), ACT_GELU)
+        y2 = ops.gemm(h, w16(L.linear2.weight), f32(L.linear2.bias), residual=x1, out_f32=True)
+        return ops.layernorm(y2, f32(L.norm2.weight), f32(L.norm2.bias), self.eps, out_f32=True)
 
-    def extract_hidden_states(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
-        raise NotImplementedError("extract_hidden_states is analysis-only (SURVEY.md section 8f)")
+    @torch.no_grad()
+    def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor = None):
+        """src [B, L, D] -> fp32 [B, L, D] = norm(layer(src)) for every position (rows at padded positions are computed like any other
+        query row, as torch's non-fused path does)."""
+        return self.extract_hidden_states_and_output(src, key_padding_mask)[0]
+
+    @torch.no_grad()
+    def extract_hidden_states_and_output(self, src, key_padding_mask=None):
+        B, Lq, D = src.shape
+        x = src.detach().float().contiguous().view(B * Lq, D)
+        hidden = [x.view(B, Lq, D)]
+        x = self._layer_rows(x, key_padding_mask, B, Lq)
+        hidden.append(x.view(B, Lq, D))
+        out = ops.layernorm(x, cached_cast(self.model.norm.weight, torch.float32), cached_cast(self.model.norm.bias, torch.float32), 1e-5, out_f32=True)
+        return out.view(B, Lq, D), tuple(hidden)
+
+    def extract_hidden_states(self, src: torch.Tensor, key_padding_mask: torch.Tensor = None):
+        """(input of every layer ..., output of the last layer BEFORE the final norm) -- nnTransformerEncoder.extract_hidden_states
+        (TransformerModels.py:16-44), element [1] as TransformerModels.py:83-96 returns it."""
+        return self.extract_hidden_states_and_output(src, key_padding_mask)[1]
 
 
 class MultiheadAttentionAndNorm(nn.Module):
@@ -156,5 +189,19 @@ class MultiheadAttentionAndNorm(nn.Module):
         n = self.attentionBlock_Norm
         return ops.layernorm(y, cached_cast(n.weight, torch.float32), cached_cast(n.bias, torch.float32), self.eps).view(B, NQ, D)
 
-    def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor):
-        raise NotImplementedError("full-row forward is off the hot path; use forward_cls (KW_CascadedBranch does)")
+    @torch.no_grad()
+    def forward(self, src: torch.Tensor, key_padding_mask: torch.Tensor = None):
+        """Full-row LN(MHA(src) + src) (TransformerModels.py:119-125): src [B, L, D] -> fp32 [B, L, D].  Off the hot path (forward_cls is what
+        KW_CascadedBranch.forward runs); eval-mode arithmetic, no autograd."""
+        m = self.multihead_attn_layer
+        B, Lq, D = src.shape
+        x = src.detach().float().contiguous().view(B * Lq, D)
+        qkv = ops.gemm(x.to(BF), cached_cast(m.in_proj_weight, BF), cached_cast(m.in_proj_bias, torch.float32))
+        att = ops.attention_rows(qkv, B, Lq, self.nhead, D // self.nhead, key_padding_mask)
+        y = ops.gemm(att, cached_cast(m.out_proj.weight, BF), cached_cast(m.out_proj.bias, torch.float32), residual=x, out_f32=True)
+        n = self.attentionBlock_Norm
+        return ops.layernorm(y, cached_cast(n.weight, torch.float32), cached_cast(n.bias, torch.float32), self.eps, out_f32=True).view(B, Lq, D)
+
+    def extract_hidden_states(self, src: torch.Tensor, key_padding_mask: torch.Tensor = None):
+        """TransformerModels.py:127-128."""
+        return tuple([src, self.forward(src, key_padding_mask)])

@@ -18,6 +18,34 @@ PROFILE = None
 PROFILE_SIDE = []     # (start, end) HIP events of every side-stream window (the image tower running beside the speech tower) while PROFILE is on
 
 _GEMM_WS = {}
+# The plain GEMMs (QKV / out-proj / fc2 / ViT projections) run on the hand-written gemm256_kernel like everything else.  hipBLASLt behind
+# the same entry (csrc/vendor_gemm.hip) is a COMPARATOR only: SC_GEMM_VENDOR=1 in the environment, or set_vendor_gemm(True) at run time
+# (bench.py measures it beside the headline number); it is never on by default.
+import os as _os
+_VENDOR_GEMM = [_os.environ.get("SC_GEMM_VENDOR", "0") == "1"]
+
+
+def set_vendor_gemm(enabled: bool) -> None:
+    """Switch the vendor-library comparator path for plain GEMMs on / off (registers / drops the library workspace)."""
+    _VENDOR_GEMM[0] = bool(enabled)
+    if not enabled and _GEMM_WS:
+        torch.cuda.synchronize()
+        check(lib().sc_set_gemm_workspace(None, 0), "sc_set_gemm_workspace")
+        _GEMM_WS.clear()
+
+
+def vendor_gemm_enabled() -> bool:
+    return _VENDOR_GEMM[0]
+
+
+def _ensure_gemm_workspace(dev):
+    """Comparator path only: one 64 MiB scratch buffer per process (one process per GPU) for the library (sc_set_gemm_workspace)."""
+    if _VENDOR_GEMM[0] and dev not in _GEMM_WS:
+        ws = torch.empty(64 << 20, device=dev, dtype=torch.uint8)
+        check(lib().sc_set_gemm_workspace(ptr(ws), ws.numel()), "sc_set_gemm_workspace")
+        _GEMM_WS.clear()          # the library keeps ONE registration: a process that hops devices re-registers
+        _GEMM_WS[dev] = ws
+
 
 # Parameter epoch: bumped by every optimizer step that writes parameters through raw pointers (train_tail.FusedAdam -> sc_adam_step does not
 # move torch's per-tensor version counter).  Every parameter-derived cache (bf16 weight casts, pooling operands, cosine / VQ tables) carries
@@ -35,15 +63,6 @@ def param_epoch(*tensors) -> int:
 
 def bump_param_epoch() -> None:
     _PARAM_EPOCH[0] += 1
-
-
-def _ensure_gemm_workspace(dev):
-    """One 64 MiB scratch buffer per process (one process per GPU) for the plain-GEMM library path (sc_set_gemm_workspace)."""
-    if dev not in _GEMM_WS:
-        ws = torch.empty(64 << 20, device=dev, dtype=torch.uint8)
-        check(lib().sc_set_gemm_workspace(ptr(ws), ws.numel()), "sc_set_gemm_workspace")
-        _GEMM_WS.clear()          # the library keeps ONE registration: a process that hops devices re-registers
-        _GEMM_WS[dev] = ws
 
 
 def _need_cuda(*ts):
@@ -156,6 +175,22 @@ def attention(qkv, B, T, H, klens_i32=None, out=None, scale=None, causal=False):
     esz = 2
     check(lib().sc_attention_fwd(qkv.data_ptr(), qkv.data_ptr() + D * esz, qkv.data_ptr() + 2 * D * esz, ptr(out), ptr(klens_i32),
                                  B, H, T, 64, 3 * D, D, 0.125 if scale is None else scale, int(causal), stream()), "sc_attention_fwd")
+    return out
+
+
+def attention_rows(qkv, B, L, H, hd, key_padding_mask=None, scale=None):
+    """Full-row MHA for any head dim: qkv bf16 [B*L, 3*H*hd] packed (q|k|v); key_padding_mask bool/uint8 [B, L] (True = padding) or None.
+    Returns bf16 [B*L, H*hd] (heads concatenated, before out_proj)."""
+    _need_cuda(qkv, key_padding_mask)
+    D = H * hd
+    assert qkv.dtype == bf16 and qkv.shape == (B * L, 3 * D) and qkv.is_contiguous()
+    m = None
+    if key_padding_mask is not None:
+        assert key_padding_mask.shape == (B, L)
+        m = key_padding_mask.to(torch.uint8).contiguous()
+    out = torch.empty(B * L, D, device=qkv.device, dtype=bf16)
+    check(lib().sc_attention_rows_fwd(qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2, ptr(out), ptr(m), B, H, L, hd, 3 * D, D,
+                                      hd ** -0.5 if scale is None else scale, stream()), "sc_attention_rows_fwd")
     return out
 
 
