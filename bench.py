@@ -132,7 +132,7 @@ def cpu_baseline(model_sd, n_pairs, L, iters=3):
     hook("branch", ref.parallel_branch)
     best, cores = 0.0, 1
     with torch.no_grad():
-        for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+        for n in (sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}) if n_pairs >= 8 else [min(16, ncpu)]):   # (tiny samples: the contract test)
             torch.set_num_threads(n)
             ref(mk(1))
             t0 = time.perf_counter()
@@ -163,13 +163,14 @@ def cpu_baseline(model_sd, n_pairs, L, iters=3):
         split["mix_and_glue"] = round(max(0.0, 1.0 - sum(split.values())), 4)
         return {"pairs_per_s": round(n * iters / tot, 3), "iter_s": [round(t, 2) for t in times], "segments_frac": split, "loss": round(loss, 4)}
     fixed = run(lambda: mk(n_pairs), n_pairs)
-    c1_lens = [int(x) for x in torch.randint(L // 4, L + 1, (16,), generator=g)]
-    c1 = run(lambda: mk(16, c1_lens), 16)
+    n_c1 = 16 if n_pairs >= 16 else max(2, n_pairs)           # C1 = 16 pairs (BASELINE configs[0]); smaller only for the quick contract test
+    c1_lens = [int(x) for x in torch.randint(L // 4, L + 1, (n_c1,), generator=g)]
+    c1 = run(lambda: mk(n_c1, c1_lens), n_c1)
     return {"value": fixed["pairs_per_s"], "unit": "pairs/s", "cores": cores, "kind": "port", "host_hw_threads": ncpu, "cpu_model": _cpu_model(),
-            "timed_iterations": iters, "fixed_length": fixed, "c1_varlen_b16": dict(c1, lens_min_max=[min(c1_lens), max(c1_lens)]),
+            "timed_iterations": iters, "fixed_length": fixed, "c1_varlen_b16": dict(c1, pairs=n_c1, lens_min_max=[min(c1_lens), max(c1_lens)]),
             "sample": f"{iters} timed iterations (after 1 warm-up) of {n_pairs} pairs (10 s audio + 224^2 image) through oracle/speechclip_ref.py fp32 "
                       f"with {cores} torch threads (best of 8/16/32/64/all on a 2-pair probe; host: {ncpu} hardware threads, {_cpu_model()}), "
-                      f"{sum(fixed['iter_s']):.1f} s; plus the C1 batch (16 pairs, variable lengths) {c1['pairs_per_s']} pairs/s"}
+                      f"{sum(fixed['iter_s']):.1f} s; plus the C1 batch ({n_c1} pairs, variable lengths) {c1['pairs_per_s']} pairs/s"}
 
 
 def _free_port():

@@ -83,8 +83,11 @@ int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, const float* 
 int sc_weighted_sum_fwd(const void* hidden, int64_t layer_stride, const float* weights, void* out, int n_layers,
                         int64_t rows, int D, int flags, float eps, void* stream);
 
-/* ---- L2 normalise -- avssl/model/kwClip.py:1436,:1444-1454 (x / ||x||, no eps), f32 out ------- */
-int sc_l2norm_fwd(const void* x, int64_t ld_in, float* out, int64_t rows, int D, int in_f32, void* stream);
+/* ---- L2 normalise -- avssl/model/kwClip.py:1436,:1444-1454 (x / ||x||, no eps), f32 out.  SC_L2NORM_CLAMP: x / max(||x||, 1e-8), the
+ * operand normalisation of F.cosine_similarity (kwClip.py:889-897) -- a zero row gives zeros, not NaN ------- */
+#define SC_L2NORM_IN_F32 0x1
+#define SC_L2NORM_CLAMP 0x2
+int sc_l2norm_fwd(const void* x, int64_t ld_in, float* out, int64_t rows, int D, int flags, void* stream);
 
 /* ---- Per-utterance wave layer-norm -- speech_encoder_plus.py:507-508 (task.cfg.normalize) -----
  * out[b,:len_b] = layer_norm(wav[b,:len_b]); out[b,len_b:] = 0.  wav/out are [B, ld] f32. */

@@ -197,7 +197,11 @@ __device__ __forceinline__ void stage256(const StageAddr& sa, int lane_a, int la
     for (int i = 0; i < 4; ++i) glds16(sa.tw + (i * ldw64 + k0) + lane_w, slot + 256 * 128 + (i * 512 + wave * 64) * 16);
 }
 
-template <int ABL, bool TRACE, int ACT, bool RES>
+// RING3: the A operand (streamed from HBM once per M-panel; W mostly hits in L2) gets a THREE-slot ring, W keeps two: 3 x 32 KiB + 2 x 32 KiB
+// = all 160 KiB of LDS.  Stage kt+3 of A is requested while stage kt computes (2.5 k-steps of lead instead of 0.5-1: HBM / MALL latency
+// is ~1 k-step), W as before one step ahead; per half-step a wave issues its 4 W pieces first and its 4 A pieces last, so the mid-step
+// wait is `vmcnt(4)` (in-order retirement: everything but the newest A pieces), not a drain.
+template <int ABL, bool TRACE, int ACT, bool RES, bool RING3>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -217,8 +221,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int frow = lane & 15, fk = lane >> 4;
     const int off_h0 = frow * 128 + ((fk ^ (frow & 7)) << 4);
     const int off_h1 = frow * 128 + (((4 + fk) ^ (frow & 7)) << 4);
+    constexpr int HALF_SLOT = 256 * 128;                       // one operand of one stage: 256 rows x 128 B
     const int a_base = wm * 128 * 128;
-    const int b_base = 256 * 128 + wn * 64 * 128;
+    const int b_base = (RING3 ? 0 : 256 * 128) + wn * 64 * 128;   // RING3: relative to the W slot; else relative to the combined slot
+    // slot addresses: 2-ring = [A|W] x 2 (64 KiB each); 3-ring = A0 A1 A2 W0 W1 (32 KiB each)
+    auto a_slot = [&](int st) -> char* { return RING3 ? smem + (st % 3) * HALF_SLOT : smem + (st & 1) * SLOT_BYTES; };
+    auto w_slot = [&](int st) -> char* { return RING3 ? smem + (3 + (st & 1)) * HALF_SLOT : smem + (st & 1) * SLOT_BYTES; };
+    auto w_dst = [&](int st) -> char* { return RING3 ? w_slot(st) : w_slot(st) + HALF_SLOT; };   // where the W pieces of stage st land
+    const bool k_counted_wait = p.epi_mode >= 0 && !(p.epi_mode & 0x100);   // SC_GEMM_EPI |= 0x100: always drain at tile start (A/B)
     const bool vec_ok = !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!RES || p.ldr % 8 == 0);
     const bool f32_ok = p.out_f32 && (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!RES || p.ldr % 4 == 0);
 
@@ -263,11 +273,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     int tm, tn;
     bool have = tile_of(0, tm, tn);
     StageAddr sa{nullptr, nullptr};
+    int tail_ops = 0;   // vector-memory operations the previous epilogue issued after the next tile's stage-0 pieces (0 = unknown: drain)
+    // q-th prologue DMA instruction of a tile, in issue order: A(0) x4, W(0) x4, A(1) x4, W(1) x4, [RING3: A(2) x4]
+    constexpr int NPRO = RING3 ? 20 : 16;
+    auto issue_q = [&](int q) {
+        const int st = q >> 3, g = q & 7;
+        if (st >= nk) return;
+        if (g < 4) glds16(sa.ta + (g * lda64 + kofs(st)) + lane_a, a_slot(st) + (g * 512 + wave * 64) * 16);
+        else if (st < 2) glds16(sa.tw + ((g - 4) * ldw64 + kofs(st)) + lane_w, w_dst(st) + ((g - 4) * 512 + wave * 64) * 16);
+    };
     if (have) {
         rot = p.rot ? tm % nk : 0;
         sa = StageAddr{A + tile_m0(tm) * p.lda, W + (int64_t)tile_n0(tn) * p.ldw};
-        stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(0), smem, wave);
-        if (nk > 1) stage256(sa, lane_a, lane_w, lda64, ldw64, kofs(1), smem + SLOT_BYTES, wave);
+#pragma unroll
+        for (int q = 0; q < NPRO; ++q) issue_q(q);
     }
     for (int it = 0; have; ++it) {
         const int64_t m0 = tile_m0(tm), m_lo = (int64_t)tm * 256;   // rows < m_lo belong to the previous tile
@@ -281,19 +300,33 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         bf16x8_t bfr[4], af[8];
         // stage 0 of this tile (issued before the previous tile's epilogue) must have landed; stage 1 may still fly on
         // the first tile only (afterwards the previous epilogue's stores sit behind it in the queue, so drain).
-        if (it == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Later tiles: stage 0 (DMA pieces 0..7 of the prologue) was interleaved with the first four row blocks of the previous epilogue and
+        // vmcnt retires in order, so everything issued AFTER piece 7 may still fly: the stores (and residual loads) of row blocks 4..7 and the
+        // 8 pieces of stage 1 -- `tail_ops`, counted by the epilogue below for full tiles (edge tiles predicate their stores: drain).
+        {
+            // pieces of the prologue issued after W(0): stage 1 (8) and, RING3, A(2) (4) -- they may all still fly
+            const int after0 = (nk > 1 ? 8 : 0) + (RING3 && nk > 2 ? 4 : 0);
+            const int allow = it == 0 ? after0 : tail_ops;
+            if (allow >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (allow >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else if (allow >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (allow >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (allow >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (TRACE) { unsigned long long t = __builtin_readcyclecounter(); t_wait += t - t_begin; t_begin = t; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8_t*)(smem + b_base + off_h0 + j * 16 * 128);
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8_t*)(w_slot(0) + b_base + off_h0 + j * 16 * 128);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8_t*)(smem + a_base + off_h0 + i * 16 * 128);
+        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8_t*)(a_slot(0) + a_base + off_h0 + i * 16 * 128);
 
         // One half-step: 32 MFMAs on (bfr, af) while the next half's fragments are read ({4 MFMA, 1 ds_read} x 8).  The B
         // fragments of the next half go into bn right after the first MFMA group, so no LDS wait gates the group head.
-        auto half_step = [&](const char* src, int off, bool load_next, int dma_k0, char* dma_slot) {
+        // srcA / srcW: slots the next half's fragments are read from; dma_k0 >= 0: refill stage (2-ring: A and W of one stage into dma_slot;
+        // RING3: W of that stage into dma_slot and, dma_ka0 >= 0, A of the stage after it into dma_aslot)
+        auto half_step = [&](const char* srcA, const char* srcW, int off, bool load_next, int dma_k0, char* dma_slot, int dma_ka0, char* dma_aslot) {
             bf16x8_t bn[4];
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -314,15 +347,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                     // ABL 5 / 6 (timing probes, garbage results): drop half / three quarters of the fragment reads = the LDS read volume of a
                     // 4-wave 128x128-per-wave layout and below
-                    if (!((ABL == 5 || ABL == 6) && (i & 1))) af[i] = *(const bf16x8_t*)(src + a_base + off + i * 16 * 128);
-                    if (i < 4 && !(ABL == 6 && (i & 1))) bn[i] = *(const bf16x8_t*)(src + b_base + off + i * 16 * 128);
+                    if (!((ABL == 5 || ABL == 6) && (i & 1))) af[i] = *(const bf16x8_t*)(srcA + a_base + off + i * 16 * 128);
+                    if (i < 4 && !(ABL == 6 && (i & 1))) bn[i] = *(const bf16x8_t*)(srcW + b_base + off + i * 16 * 128);
                     if (ABL == 6 && i < 4 && (i & 1)) bn[i] = bn[i - 1];
-                    if (dma_k0 >= 0 && ABL != 1) {   // one LDS-DMA instruction per MFMA group instead of a burst behind the barrier
+                    if (ABL != 1) {   // one LDS-DMA instruction per MFMA group instead of a burst behind the barrier
                         int la = lane_a, lw = lane_w;
                         asm volatile("" : "+v"(la), "+v"(lw));   // keep the 64-bit source addresses out of the loop-invariant set (VGPR pressure)
-                        const int dk = (ABL == 7) ? 0 : dma_k0;   // ABL 7 (timing probe, garbage results): the in-loop DMA always re-reads k-chunk 0 = cache hits
-                        if (i < 4) glds16(sa.ta + (i * lda64 + dk) + la, dma_slot + (i * 512 + wave * 64) * 16);
-                        else glds16(sa.tw + ((i - 4) * ldw64 + dk) + lw, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
+                        if (!RING3) {
+                            const int dk = (ABL == 7) ? 0 : dma_k0;   // ABL 7 (timing probe, garbage results): the in-loop DMA always re-reads k-chunk 0 = cache hits
+                            if (dma_k0 >= 0) {
+                                if (i < 4) glds16(sa.ta + (i * lda64 + dk) + la, dma_slot + (i * 512 + wave * 64) * 16);
+                                else glds16(sa.tw + ((i - 4) * ldw64 + dk) + lw, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
+                            }
+                        } else {   // W pieces first, A pieces last: the mid-step wait lets the 4 newest (A) fly
+                            if (i < 4) { if (dma_k0 >= 0) glds16(sa.tw + (i * ldw64 + dma_k0) + lw, dma_slot + (i * 512 + wave * 64) * 16); }
+                            else if (dma_ka0 >= 0) glds16(sa.ta + ((i - 4) * lda64 + dma_ka0) + la, dma_aslot + ((i - 4) * 512 + wave * 64) * 16);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -334,24 +374,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             }
         };
         auto mid_sync = [&](int kt) {
-            // slot kt is entirely in registers; stage kt+1 must have landed before anyone reads it
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // slot kt is entirely in registers; stage kt+1 must have landed before anyone reads it.  RING3: the newest 4 operations of this
+            // wave are the A pieces of stage kt+2 (issued last in the previous refill / prologue) whenever that stage exists: let them fly.
+            if (RING3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };
         for (int kt = 0; kt + 1 < nk; ++kt) {
-            const char* slot = smem + (kt & 1) * SLOT_BYTES;
-            const char* nslot = smem + ((kt + 1) & 1) * SLOT_BYTES;
-            half_step(slot, off_h1, true, -1, nullptr);      // MFMAs of (kt, h0); read (kt, h1)
+            half_step(a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, -1, nullptr);      // MFMAs of (kt, h0); read (kt, h1)
             mid_sync(kt);
-            // MFMAs of (kt, h1); read (kt+1, h0); refill slot kt with stage kt+2
-            half_step(nslot, off_h0, true, kt + 2 < nk ? kofs(kt + 2) : -1, smem + (kt & 1) * SLOT_BYTES);
+            // MFMAs of (kt, h1); read (kt+1, h0); refill: 2-ring = stage kt+2 into slot kt; RING3 = W(kt+2) into W slot kt, A(kt+3) into A slot kt
+            if (!RING3) half_step(a_slot(kt + 1), w_slot(kt + 1), off_h0, true, kt + 2 < nk ? kofs(kt + 2) : -1, a_slot(kt), -1, nullptr);
+            else half_step(a_slot(kt + 1), w_slot(kt + 1), off_h0, true, kt + 2 < nk ? kofs(kt + 2) : -1, w_slot(kt), kt + 3 < nk ? kofs(kt + 3) : -1, a_slot(kt));
         }
         {   // last k-step (peeled: nothing left to prefetch after its first half)
             const int kt = nk - 1;
-            half_step(smem + (kt & 1) * SLOT_BYTES, off_h1, true, -1, nullptr);
+            half_step(a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, -1, nullptr);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            half_step(nullptr, 0, false, -1, nullptr);
+            half_step(nullptr, nullptr, 0, false, -1, nullptr, -1, nullptr);
         }
         // bias for this lane's 4 x 4 output columns: loaded BEFORE the next tile's LDS-DMA is issued (an ordinary load
         // issued behind the DMA would have to drain it first: vmcnt is in-order)
@@ -373,18 +414,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const int nrot = (nhave && p.rot) ? ntm % nk : 0;
         if (nhave) sa = StageAddr{A + tile_m0(ntm) * p.lda, W + (int64_t)tile_n0(ntn) * p.ldw};
         rot = nrot;   // the k-loop of THIS tile is over; from here on kofs() addresses the next tile
-        // q-th of the 16 prologue DMA instructions of the next tile (stage q >> 3; A row groups then W row groups)
-        auto issue_q = [&](int q) {
-            const int st = q >> 3, g = q & 7;
-            if (st == 1 && nk < 2) return;
-            char* slot = smem + st * SLOT_BYTES;
-            if (g < 4) glds16(sa.ta + (g * lda64 + kofs(st)) + lane_a, slot + (g * 512 + wave * 64) * 16);
-            else glds16(sa.tw + ((g - 4) * ldw64 + kofs(st)) + lane_w, slot + 256 * 128 + ((g - 4) * 512 + wave * 64) * 16);
-        };
-        const int emode = RES ? p.epi_mode_res : p.epi_mode;
+        const int emode = (RES ? p.epi_mode_res : p.epi_mode) & 0xff;
         if (nhave && emode == 0) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) issue_q(q);
+            for (int q = 0; q < NPRO; ++q) issue_q(q);
         }
 
         if (TRACE) { unsigned long long t = __builtin_readcyclecounter(); t_pre += t - t_begin; t_begin = t; }
@@ -452,6 +485,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     }
                 }
                 if (nhave && emode == 2) { issue_q(2 * i); issue_q(2 * i + 1); }
+            }
+            if (RING3 && nhave && emode == 2) {
+#pragma unroll
+                for (int q = 16; q < NPRO; ++q) issue_q(q);
             }
         } else if (f32_ok) {
             // fp32 outputs (the ViT / pre-LN residual streams): same quad rule as above.  Lane (frow, fk) holds 4 consecutive fp32 =
@@ -535,7 +572,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         }
         if (nhave && (emode == 3 || (emode == 2 && !vec_ok))) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) issue_q(q);
+            for (int q = 0; q < NPRO; ++q) issue_q(q);
+        }
+        {
+            // vector-memory operations issued AFTER the next tile's W(0) pieces, all of which may still fly at the next tile-start wait: the
+            // rest of its prologue (8 [+4] pieces) and, when the prologue was interleaved with this epilogue's row blocks (W(0) completes with
+            // row block 3), the stores [+ residual loads] of row blocks 4..7 -- counted only for full tiles (edge tiles predicate their stores)
+            const bool full_tile_now = (m0 == m_lo) && (n0 == n_lo);
+            tail_ops = 0;
+            if (k_counted_wait && nhave) {
+                tail_ops = (nk > 1 ? 8 : 0) + (RING3 && nk > 2 ? 4 : 0);
+                if (emode == 2 && vec_ok && full_tile_now && nk > 1) tail_ops += RES ? 12 : 8;
+            }
         }
         have = nhave;
         tm = ntm;
@@ -550,26 +598,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     }
 }
 
-template <int ABL, bool TRACE, int ACT, bool RES>
+template <int ABL, bool TRACE, int ACT, bool RES, bool RING3>
 int launch256_one(const GemmParams& p, int grid, hipStream_t s) {
-    constexpr int lds = 2 * SLOT_BYTES;   // 128 KiB operand ring
+    constexpr int lds = RING3 ? 5 * 256 * 128 : 2 * SLOT_BYTES;   // 160 KiB (A x3 + W x2) or 128 KiB ([A|W] x2)
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<ABL, TRACE, ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<ABL, TRACE, ACT, RES, RING3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<ABL, TRACE, ACT, RES>), dim3(grid), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((gemm256_kernel<ABL, TRACE, ACT, RES, RING3>), dim3(grid), dim3(512), lds, s, p);
     SC_CHECK_LAUNCH();
     return 0;
 }
 
-template <int ABL, bool TRACE>
+template <int ABL, bool TRACE, bool RING3 = false>
 int launch256_var(const GemmParams& p, int grid, hipStream_t s) {
     const bool res = p.residual != nullptr;
     switch (p.act) {
-        case SC_ACT_GELU: return res ? launch256_one<ABL, TRACE, SC_ACT_GELU, true>(p, grid, s) : launch256_one<ABL, TRACE, SC_ACT_GELU, false>(p, grid, s);
-        case SC_ACT_QUICKGELU: return res ? launch256_one<ABL, TRACE, SC_ACT_QUICKGELU, true>(p, grid, s) : launch256_one<ABL, TRACE, SC_ACT_QUICKGELU, false>(p, grid, s);
-        default: return res ? launch256_one<ABL, TRACE, SC_ACT_NONE, true>(p, grid, s) : launch256_one<ABL, TRACE, SC_ACT_NONE, false>(p, grid, s);
+        case SC_ACT_GELU: return res ? launch256_one<ABL, TRACE, SC_ACT_GELU, true, RING3>(p, grid, s) : launch256_one<ABL, TRACE, SC_ACT_GELU, false, RING3>(p, grid, s);
+        case SC_ACT_QUICKGELU: return res ? launch256_one<ABL, TRACE, SC_ACT_QUICKGELU, true, RING3>(p, grid, s) : launch256_one<ABL, TRACE, SC_ACT_QUICKGELU, false, RING3>(p, grid, s);
+        default: return res ? launch256_one<ABL, TRACE, SC_ACT_NONE, true, RING3>(p, grid, s) : launch256_one<ABL, TRACE, SC_ACT_NONE, false, RING3>(p, grid, s);
     }
 }
 
@@ -593,6 +641,9 @@ int launch256(const GemmParams& p, hipStream_t s) {
     if (abl && abl[0] == '5') return launch256_var<5, false>(p, grid, s);
     if (abl && abl[0] == '6') return launch256_var<6, false>(p, grid, s);
     if (abl && abl[0] == '7') return launch256_var<7, false>(p, grid, s);
+    // SC_GEMM_RING3=1: three-slot A ring (see gemm256_kernel); A/B switch while the default is being decided by measurement
+    static const bool ring3 = getenv("SC_GEMM_RING3") && atoi(getenv("SC_GEMM_RING3")) != 0;
+    if (ring3) return launch256_var<0, false, true>(p, grid, s);
     return launch256_var<0, false>(p, grid, s);
 }
 

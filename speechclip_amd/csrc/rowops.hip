@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(const void* __restric
 }
 
 template <bool IN_F32>
-__global__ __launch_bounds__(256) void l2norm_kernel(const void* __restrict__ x, int64_t ld_in, float* __restrict__ out, int64_t rows, int D) {
+__global__ __launch_bounds__(256) void l2norm_kernel(const void* __restrict__ x, int64_t ld_in, float* __restrict__ out, int64_t rows, int D, float norm_floor) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const void* __restrict__ x,
     for (int c = 0; c < MAXC; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i) q += v[c][i] * v[c][i];
-    const float inv = 1.0f / sqrtf(wave_sum(q));  // no eps: kwClip.py:1436 divides by the plain norm
+    // norm_floor = 0: kwClip.py:1436 divides by the plain norm (no eps); 1e-8: the clamp of F.cosine_similarity's operands (kwClip.py:889-897)
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(q)), norm_floor);
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         int e = c * 256 + lane * 4;
@@ -339,12 +340,13 @@ extern "C" int sc_weighted_sum_fwd(const void* hidden, int64_t layer_stride, con
     return 0;
 }
 
-extern "C" int sc_l2norm_fwd(const void* x, int64_t ld_in, float* out, int64_t rows, int D, int in_f32, void* stream) {
+extern "C" int sc_l2norm_fwd(const void* x, int64_t ld_in, float* out, int64_t rows, int D, int flags, void* stream) {
     SC_CHECK_ARG(D > 0 && D <= 1024 && D % 4 == 0, "sc_l2norm: D=%d must be a multiple of 4, <= 1024", D);
     if (rows <= 0) return 0;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (in_f32) hipLaunchKernelGGL((l2norm_kernel<true>), grid, block, 0, (hipStream_t)stream, x, ld_in, out, rows, D);
-    else hipLaunchKernelGGL((l2norm_kernel<false>), grid, block, 0, (hipStream_t)stream, x, ld_in, out, rows, D);
+    const float floor_ = (flags & SC_L2NORM_CLAMP) ? 1e-8f : 0.0f;
+    if (flags & SC_L2NORM_IN_F32) hipLaunchKernelGGL((l2norm_kernel<true>), grid, block, 0, (hipStream_t)stream, x, ld_in, out, rows, D, floor_);
+    else hipLaunchKernelGGL((l2norm_kernel<false>), grid, block, 0, (hipStream_t)stream, x, ld_in, out, rows, D, floor_);
     SC_CHECK_LAUNCH();
     return 0;
 }

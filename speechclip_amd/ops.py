@@ -149,11 +149,12 @@ def weighted_sum(hidden, weights, normalize=False, eps=1e-5):
     return out
 
 
-def l2norm(x):
+def l2norm(x, clamp=False):
+    """x / ||x|| (no eps: kwClip.py:1436); clamp=True: x / max(||x||, 1e-8) (the operand normalisation of F.cosine_similarity)."""
     _need_cuda(x)
     assert x.dim() == 2 and x.stride(1) == 1
     out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
-    check(lib().sc_l2norm_fwd(ptr(x), x.stride(0), ptr(out), x.shape[0], x.shape[1], int(x.dtype == torch.float32), stream()), "sc_l2norm_fwd")
+    check(lib().sc_l2norm_fwd(ptr(x), x.stride(0), ptr(out), x.shape[0], x.shape[1], int(x.dtype == torch.float32) | (2 if clamp else 0), stream()), "sc_l2norm_fwd")
     return out
 
 
@@ -336,7 +337,7 @@ def _cos_table(emb):
     hit = _COS_TABLES.get(key)
     if hit is not None and hit[0] == (emb._version, param_epoch(emb), tuple(emb.shape)) and hit[2]() is emb:
         return hit[1]
-    en = l2norm(emb.detach().float().contiguous())
+    en = l2norm(emb.detach().float().contiguous(), clamp=True)
     hi = en.to(bf16)
     lo = (en - hi.float()).to(bf16)
     tab = torch.cat([hi, hi, lo], dim=1).contiguous()
@@ -363,7 +364,7 @@ def cosine_scores(a, emb, eps=1e-8, exact=None):
         check(lib().sc_cosine_scores(ptr(a), ptr(embf), ptr(ws), ptr(out), R, V, E, eps, stream()), "sc_cosine_scores")
         return out
     tab = _cos_table(emb)
-    a3 = split_hilo(l2norm(a), nblk=3)
+    a3 = split_hilo(l2norm(a, clamp=True), nblk=3)
     gemm(a3, tab, out=out, out_f32=True)
     embf = emb.detach()
     embf = embf if (embf.dtype == torch.float32 and embf.is_contiguous()) else embf.float().contiguous()

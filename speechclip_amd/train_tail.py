@@ -297,7 +297,7 @@ def _vq_tables(emb):
     if hit is not None and hit[0] == (emb._version, ops.param_epoch(emb), tuple(emb.shape)) and hit[2]() is emb:
         return hit[1]
     e = emb.detach().float().contiguous()
-    out = (_dup_k(e.to(BF)), _dup_k(ops.l2norm(e).t().contiguous().to(BF)))
+    out = (_dup_k(e.to(BF)), _dup_k(ops.l2norm(e, clamp=True).t().contiguous().to(BF)))
     _VQ_TABLES.clear()
     _VQ_TABLES[key] = ((emb._version, ops.param_epoch(emb), tuple(emb.shape)), out, weakref.ref(emb))
     return out
@@ -431,7 +431,9 @@ class PackedGatherFn(torch.autograd.Function):
         packed, pkeys, widths = parallel.pack_feats(feats)
         out = parallel.unpack_feats(parallel.all_gather_packed(packed), pkeys, widths)
         ctx.rank, ctx.B = rank, ids.shape[0]
-        ctx.mark_non_differentiable(out["id"])
+        # only the features that carry a gradient on this rank (the audio embeddings) stay differentiable: the gathered image features of a
+        # frozen tower must not look trainable to the loss
+        ctx.mark_non_differentiable(out["id"], *[out[k] for k, t in zip(keys, tensors) if not t.requires_grad])
         return (out["id"],) + tuple(out[k] for k in keys)
 
     @staticmethod

@@ -43,7 +43,7 @@ def test_kw_affine_vs_oracle_kw_batchnorm_eval(B, K, D):
 
 
 @pytest.mark.parametrize("R,V,E,exact", [(24, 8112, 512, True), (24, 8112, 512, None), (64, 103, 64, True), (7, 333, 32, None),
-                                          (2048, 8112, 512, None), (2048, 49408, 512, None)])
+                                          (1024, 8112, 512, None), (256, 49408, 512, None)])
 def test_cosine_scores_vs_fp32_cosine_similarity(R, V, E, exact):
     """sc_cosine_scores (fp32 SIMT) and the default dispatch (MFMA three-term split + sc_cosine_refine for large problems) against
     F.cosine_similarity in fp32 on the CPU, the reference's own expression (kwClip.py:889-897): values, and the arg-max on every row whose
@@ -66,7 +66,7 @@ def test_cosine_scores_vs_fp32_cosine_similarity(R, V, E, exact):
     assert (got - want).abs().max().item() < tol, (got - want).abs().max().item()
     top2 = want.topk(2, dim=-1)
     decisive = (top2.values[:, 0] - top2.values[:, 1]) > 4e-7
-    assert decisive.float().mean().item() > 0.9
+    assert decisive.float().mean().item() > 0.8                 # (all rows but the planted near-tie)
     assert torch.equal(got.argmax(-1)[decisive], top2.indices[decisive, 0])
     # near the maximum the values themselves are fp32-accurate on both paths (the refine pass recomputes them)
     near = want >= (top2.values[:, :1] - 5e-4)

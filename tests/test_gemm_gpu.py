@@ -124,3 +124,24 @@ def test_vendor_comparator_path_correct_on_three_streams():
     assert lib().sc_gemm_last_path() == 0
     for o in outs:
         torch.testing.assert_close(o.float(), ref, atol=3e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K,res,f32", [(70000, 768, 128, False, False), (70000, 768, 128, True, False), (66000, 512, 192, False, True),
+                                            (131072, 768, 768, True, False), (40000, 2304, 64, False, False)])
+def test_gemm_256_tile_switch_counted_wait(M, N, K, res, f32):
+    """Many tiles per persistent block with SHORT k-loops (nk = 1..3), where the tile-start wait is counted (`s_waitcnt vmcnt(N)`: the tail
+    of the previous epilogue's stores and the next tile's stage 1 stay in flight): a wrong count would read a stage before it landed.
+    Checked against fp32 and for run-to-run bitwise stability over several launches."""
+    from speechclip_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to("cuda", torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16)
+    bias = torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).to("cuda", torch.float32 if f32 else torch.bfloat16) if res else None
+    outs = [ops.gemm(a, w, bias, 0, r, out_f32=f32) for _ in range(4)]
+    torch.cuda.synchronize()
+    ref = _ref(a, w, bias, 0, r)
+    tol = 2e-3 if f32 else 2e-2
+    torch.testing.assert_close(outs[0].float(), ref, atol=tol, rtol=tol)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])

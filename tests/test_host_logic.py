@@ -330,6 +330,8 @@ def _one_collective_worker(rank, world, port, q):
              "cascaded_audio_feat": torch.randn(B, 8, generator=g).requires_grad_(True)}
     out = gather_loss_feats_train(feats)
     n_train = len(calls)
+    assert not out["image_feat"].requires_grad and not out["id"].requires_grad          # a frozen tower's features stay non-differentiable
+    assert out["parallel_audio_feat"].requires_grad and out["cascaded_audio_feat"].requires_grad
     (out["parallel_audio_feat"].sum() * 2 + out["cascaded_audio_feat"][rank * B:(rank + 1) * B].sum() * 3).backward()
     ok_grad = bool(torch.all(feats["parallel_audio_feat"].grad == 2) and torch.all(feats["cascaded_audio_feat"].grad == 3))
     calls.clear()
