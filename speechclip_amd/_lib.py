@@ -45,6 +45,9 @@ def _declare(L):
         "sc_gemm_bf16_batched": ([P, L64, L64, P, L64, L64, I, P, L64, L64, P, L64, I, I, I, I, P], c_int),
         "sc_layernorm": ([P, L64, P, P, P, L64, L64, I, F, I, P], c_int),
         "sc_weighted_sum_fwd": ([P, L64, P, P, I, L64, I, I, F, P], c_int),
+        "sc_gemm_bf16_ln": ([P, L64, P, L64, P, L64, P, P, L64, L64, I, I, I, I, P, P, P, P, P, P, P], c_int),
+        "sc_ln_stats_finalize": ([P, I, P, L64, I, F, P], c_int),
+        "sc_weighted_sum_ln_fwd": ([P, P, L64, P, P, P, P, I, L64, I, F, P], c_int),
         "sc_l2norm_fwd": ([P, L64, P, L64, I, I, P], c_int),
         "sc_wave_layernorm": ([P, P, P, I, L64, F, P], c_int),
         "sc_attention_fwd": ([P, P, P, P, P, I, I, I, I, L64, L64, F, I, P], c_int),

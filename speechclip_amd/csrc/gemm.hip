@@ -28,6 +28,13 @@ struct GemmParams {
     int rot;                     // rotate the K loop per block (L2 channel de-correlation)
     int band;                    // N-tiles per column band of the persistent tile order (0/>=tiles_n: M-panel-major over all of N)
     int epi_mode, epi_mode_res;                // next tile's first two stages: 0 issued before the epilogue, 2 interleaved with its stores (default), 3 after it
+    // LayerNorm folded into the GEMMs around it (sc_gemm_bf16_ln; post-LN transformer layers, eval path):
+    const float* ln_stats;                     // EPI 1: [M,2] (mean, rstd) of the LayerNorm whose output is the A operand; A holds the PRE-norm rows, W = gamma (.) W
+    const float* ln_c;                         // EPI 1: [N] c_n = sum_k W'[n,k]   =>  out = rstd_m (acc - mean_m c_n) + bias_n   (bias = W beta + b)
+    const float* res_stats;                    // EPI 2: [M,2] stats of the LayerNorm whose output is the RESIDUAL; `residual` holds the pre-norm rows
+    const float* res_gamma; const float* res_beta;   // EPI 2: [N] affine of that LayerNorm
+    float* ln_partial;                         // EPI 2: [M, 4*tiles_n, 2] per-(row, 64-column strip) partial (sum, sum of squares) of the OUTPUT rows
+    int kpair;                                 // > 0: stride-2 kernel-3 conv as GEMM (K = 3C, lda = 2C), kpair = C / 64: walk K as (tap0 c, tap2 c) pairs, then tap1
 };
 
 constexpr int BK = 64;  // 128 bytes of bf16 per tile row = 8 chunks of 16 B
@@ -197,11 +204,17 @@ __device__ __forceinline__ void stage256(const StageAddr& sa, int lane_a, int la
     for (int i = 0; i < 4; ++i) glds16(sa.tw + (i * ldw64 + k0) + lane_w, slot + 256 * 128 + (i * 512 + wave * 64) * 16);
 }
 
-// RING3: the A operand (streamed from HBM once per M-panel; W mostly hits in L2) gets a THREE-slot ring, W keeps two: 3 x 32 KiB + 2 x 32 KiB
-// = all 160 KiB of LDS.  Stage kt+3 of A is requested while stage kt computes (2.5 k-steps of lead instead of 0.5-1: HBM / MALL latency
-// is ~1 k-step), W as before one step ahead; per half-step a wave issues its 4 W pieces first and its 4 A pieces last, so the mid-step
-// wait is `vmcnt(4)` (in-order retirement: everything but the newest A pieces), not a drain.
-template <int ABL, bool TRACE, int ACT, bool RES, bool RING3>
+// RING3: the A operand gets a THREE-slot ring, W keeps two (3 x 32 KiB + 2 x 32 KiB = all 160 KiB of LDS), which lets the refill of a stage
+// be spread over BOTH half-steps of a k-step instead of being packed into the second one: with the two-slot [A|W] ring a slot is free only
+// after the mid-step barrier, so its 8 pieces per wave are issued during half of the time -- 64 KiB per half k-step = the CU's whole L2 -> LDS
+// path for that half, nothing in the other.  Here the A pieces of stage kt+2 go out during the FIRST half of k-step kt (their slot held stage
+// kt-1, free since the previous barrier) and the W pieces during the second half: 4 pieces per wave per half-step, and the mid-step wait is
+// `vmcnt(4)` (in-order retirement: everything but the A pieces just issued).  (Round 2 also measured the other use of the third slot -- A
+// prefetched a full k-step deeper, all 8 pieces still in the second half: neutral to -6 %: the loop is not latency-bound.)
+// EPI: 0 plain; 1 the A operand is a pre-LayerNorm tensor (LN folded: W pre-scaled by gamma, per-row (mean, rstd) applied to the accumulator);
+// 2 the residual operand is a pre-LayerNorm tensor (reconstructed per element from its row statistics) and the per-row partial statistics of
+// the output are emitted for the NEXT LayerNorm.  bf16 vector path only (the dispatcher checks the shape rules).
+template <int ABL, bool TRACE, int ACT, bool RES, bool RING3, int EPI = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -217,7 +230,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     // rot = M-panel index mod nk: the N-tiles of one A panel stay in lock-step (their A lines are fetched once and hit in L2 for
     // the siblings) while different M-panels read different W rows at any instant.
     int rot = 0;
-    auto kofs = [&](int st) -> int { int c = st + rot; c = c >= nk ? c - nk : c; return c * BK2; };
+    // Conv-as-GEMM with overlapping rows (k = 3, stride 2: K = 3C, lda = 2C): columns [2C, 3C) of row r ARE columns [0, C) of row r + 1, so
+    // chunk c of tap 2 touches the cache lines chunk c of tap 0 touched one row further down.  Walking K as (tap0 c, tap2 c) pairs puts the
+    // two touches one k-step apart (an L2 / TCP hit) instead of 16 k-steps apart (evicted: every CU streams 64 KiB per k-step through a 4 MiB
+    // L2 shared by 32 CUs) -- the sum over K is order-free.  kpair = C / 64 chunks per tap.
+    const int kpair = p.kpair;
+    auto kofs = [&](int st) -> int {
+        int c = st + rot;
+        c = c >= nk ? c - nk : c;
+        if (kpair > 0) c = c < 2 * kpair ? (c >> 1) + (c & 1) * 2 * kpair : c - kpair;
+        return c * BK2;
+    };
     const int frow = lane & 15, fk = lane >> 4;
     const int off_h0 = frow * 128 + ((fk ^ (frow & 7)) << 4);
     const int off_h1 = frow * 128 + (((4 + fk) ^ (frow & 7)) << 4);
@@ -274,8 +297,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     bool have = tile_of(0, tm, tn);
     StageAddr sa{nullptr, nullptr};
     int tail_ops = 0;   // vector-memory operations the previous epilogue issued after the next tile's stage-0 pieces (0 = unknown: drain)
-    // q-th prologue DMA instruction of a tile, in issue order: A(0) x4, W(0) x4, A(1) x4, W(1) x4, [RING3: A(2) x4]
-    constexpr int NPRO = RING3 ? 20 : 16;
+    // q-th prologue DMA instruction of a tile, in issue order: A(0) x4, W(0) x4, A(1) x4, W(1) x4
+    constexpr int NPRO = 16;
     auto issue_q = [&](int q) {
         const int st = q >> 3, g = q & 7;
         if (st >= nk) return;
@@ -304,8 +327,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         // vmcnt retires in order, so everything issued AFTER piece 7 may still fly: the stores (and residual loads) of row blocks 4..7 and the
         // 8 pieces of stage 1 -- `tail_ops`, counted by the epilogue below for full tiles (edge tiles predicate their stores: drain).
         {
-            // pieces of the prologue issued after W(0): stage 1 (8) and, RING3, A(2) (4) -- they may all still fly
-            const int after0 = (nk > 1 ? 8 : 0) + (RING3 && nk > 2 ? 4 : 0);
+            // pieces of the prologue issued after W(0): stage 1 (8) -- they may all still fly
+            const int after0 = nk > 1 ? 8 : 0;
             const int allow = it == 0 ? after0 : tail_ops;
             if (allow >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             else if (allow >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
@@ -353,14 +376,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     if (ABL != 1) {   // one LDS-DMA instruction per MFMA group instead of a burst behind the barrier
                         int la = lane_a, lw = lane_w;
                         asm volatile("" : "+v"(la), "+v"(lw));   // keep the 64-bit source addresses out of the loop-invariant set (VGPR pressure)
-                        if (!RING3) {
+                        if (!RING3 && ABL == 8) {   // placement variant (correct results): both pieces of a row group in MFMA groups 4..7, which carry one ds_read instead of two
+                            if (dma_k0 >= 0 && i >= 4) {
+                                glds16(sa.ta + ((i - 4) * lda64 + dma_k0) + la, dma_slot + ((i - 4) * 512 + wave * 64) * 16);
+                                glds16(sa.tw + ((i - 4) * ldw64 + dma_k0) + lw, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
+                            }
+                        } else if (!RING3) {
                             const int dk = (ABL == 7) ? 0 : dma_k0;   // ABL 7 (timing probe, garbage results): the in-loop DMA always re-reads k-chunk 0 = cache hits
                             if (dma_k0 >= 0) {
                                 if (i < 4) glds16(sa.ta + (i * lda64 + dk) + la, dma_slot + (i * 512 + wave * 64) * 16);
                                 else glds16(sa.tw + ((i - 4) * ldw64 + dk) + lw, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
                             }
-                        } else {   // W pieces first, A pieces last: the mid-step wait lets the 4 newest (A) fly
-                            if (i < 4) { if (dma_k0 >= 0) glds16(sa.tw + (i * ldw64 + dma_k0) + lw, dma_slot + (i * 512 + wave * 64) * 16); }
+                        } else if (i >= 4) {   // one piece per MFMA group in groups 4..7 (they carry one fragment read, groups 0..3 two): W or A of a stage
+                            if (dma_k0 >= 0) glds16(sa.tw + ((i - 4) * ldw64 + dma_k0) + lw, dma_slot + ((i - 4) * 512 + wave * 64) * 16);
                             else if (dma_ka0 >= 0) glds16(sa.ta + ((i - 4) * lda64 + dma_ka0) + la, dma_aslot + ((i - 4) * 512 + wave * 64) * 16);
                         }
                     }
@@ -375,18 +403,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         };
         auto mid_sync = [&](int kt) {
             // slot kt is entirely in registers; stage kt+1 must have landed before anyone reads it.  RING3: the newest 4 operations of this
-            // wave are the A pieces of stage kt+2 (issued last in the previous refill / prologue) whenever that stage exists: let them fly.
+            // wave are the A pieces of stage kt+2, issued during the half-step that just ended, whenever that stage exists: let them fly.
             if (RING3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };
         for (int kt = 0; kt + 1 < nk; ++kt) {
-            half_step(a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, -1, nullptr);      // MFMAs of (kt, h0); read (kt, h1)
+            // MFMAs of (kt, h0); read (kt, h1); RING3: A pieces of stage kt+2 into the A slot stage kt-1 left free
+            if (!RING3) half_step(a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, -1, nullptr);
+            else half_step(a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, kt + 2 < nk ? kofs(kt + 2) : -1, a_slot(kt + 2));
             mid_sync(kt);
-            // MFMAs of (kt, h1); read (kt+1, h0); refill: 2-ring = stage kt+2 into slot kt; RING3 = W(kt+2) into W slot kt, A(kt+3) into A slot kt
+            // MFMAs of (kt, h1); read (kt+1, h0); refill: 2-ring = stage kt+2 (A and W) into slot kt; RING3 = W(kt+2) into W slot kt
             if (!RING3) half_step(a_slot(kt + 1), w_slot(kt + 1), off_h0, true, kt + 2 < nk ? kofs(kt + 2) : -1, a_slot(kt), -1, nullptr);
-            else half_step(a_slot(kt + 1), w_slot(kt + 1), off_h0, true, kt + 2 < nk ? kofs(kt + 2) : -1, w_slot(kt), kt + 3 < nk ? kofs(kt + 3) : -1, a_slot(kt));
+            else half_step(a_slot(kt + 1), w_slot(kt + 1), off_h0, true, kt + 2 < nk ? kofs(kt + 2) : -1, w_slot(kt), -1, nullptr);
         }
         {   // last k-step (peeled: nothing left to prefetch after its first half)
             const int kt = nk - 1;
@@ -401,6 +431,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         for (int j = 0; j < 4; ++j) {
             const int nn = n0 + wn * 64 + j * 16 + fk * 4;
             bias4[j] = p.bias ? *(const f32x4_t*)(p.bias + nn) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4_t c4[4];
+        float2 rs_acc[8];
+        if (EPI == 1) {   // folded-LN operands in the accumulator layout: c for this lane's 16 columns, (mean, rstd) for its 8 rows
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c4[j] = *(const f32x4_t*)(p.ln_c + n0 + wn * 64 + j * 16 + fk * 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rs_acc[i] = *(const float2*)(p.ln_stats + 2 * (m0 + wm * 128 + i * 16 + frow));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -445,15 +483,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 }
             };
             uint4 res[3][2];
+            float2 rstat[3];
+            float psum = 0.f, psq = 0.f;
+            f32x4_t rg[2][2], rb[2][2];      // EPI 2: gamma / beta of the residual's LayerNorm for this lane's 2 x 8 columns
+            auto load_rstat = [&](int i) -> float2 {
+                const int64_t m = mrow0 + i * 16;
+                return *(const float2*)(p.res_stats + 2 * m);
+            };
+            if (EPI == 2) {
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const int n = ncol0 + jp * 32;
+                    rg[jp][0] = *(const f32x4_t*)(p.res_gamma + n); rg[jp][1] = *(const f32x4_t*)(p.res_gamma + n + 4);
+                    rb[jp][0] = *(const f32x4_t*)(p.res_beta + n);  rb[jp][1] = *(const f32x4_t*)(p.res_beta + n + 4);
+                }
+                rstat[0] = load_rstat(0); rstat[1] = load_rstat(1);
+            }
             if (RES) { load_res(0, res[0]); load_res(1, res[1]); }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int64_t m = mrow0 + i * 16;
-                if (RES && i + 2 < 8) load_res(i + 2, res[(i + 2) % 3]);
+                if (RES && i + 2 < 8) { load_res(i + 2, res[(i + 2) % 3]); if (EPI == 2) rstat[(i + 2) % 3] = load_rstat(i + 2); }
                 uint2 pk[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4_t v4 = acc[i][j];
+                    if (EPI == 1) {   // rstd (acc - mean c)
+                        const float rstd = rs_acc[i].y, nm = -rs_acc[i].x * rs_acc[i].y;
+                        v4 = v4 * rstd + c4[j] * nm;
+                    }
                     v4 += bias4[j];
                     if (ACT == SC_ACT_GELU) {
                         const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
@@ -473,22 +531,46 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                                          __builtin_amdgcn_ds_bpermute(bperm, r0[1]), __builtin_amdgcn_ds_bpermute(bperm, r1[1]));
                     const int n = ncol0 + jp * 32;
                     if (m >= m_lo && n >= n_lo) {
-                        if (RES) {
+                        if (RES && EPI != 2) {
                             const uint4 rv = res[i % 3][jp];
                             o.x = pack2bf(lo2f(o.x) + lo2f(rv.x), hi2f(o.x) + hi2f(rv.x));
                             o.y = pack2bf(lo2f(o.y) + lo2f(rv.y), hi2f(o.y) + hi2f(rv.y));
                             o.z = pack2bf(lo2f(o.z) + lo2f(rv.z), hi2f(o.z) + hi2f(rv.z));
                             o.w = pack2bf(lo2f(o.w) + lo2f(rv.w), hi2f(o.w) + hi2f(rv.w));
                         }
+                        if (EPI == 2) {
+                            // residual x = LN(y) rebuilt from the pre-norm row y: x_k = y_k (rstd g_k) + (b_k - mean rstd g_k); the LayerNorm output is
+                            // rounded to bf16 exactly where the separate kernel rounds it, so both paths add the same residual
+                            const uint4 rv = res[i % 3][jp];
+                            const float mean = rstat[i % 3].x, rstd = rstat[i % 3].y;
+                            const f32x4_t g0 = rg[jp][0] * rstd, g1 = rg[jp][1] * rstd;
+                            const f32x4_t b0 = rb[jp][0] - g0 * mean, b1 = rb[jp][1] - g1 * mean;
+                            auto rnd = [](float v) -> float { return bf2f(f2bf(v)); };
+                            const float x0 = rnd(lo2f(rv.x) * g0[0] + b0[0]), x1 = rnd(hi2f(rv.x) * g0[1] + b0[1]);
+                            const float x2 = rnd(lo2f(rv.y) * g0[2] + b0[2]), x3 = rnd(hi2f(rv.y) * g0[3] + b0[3]);
+                            const float x4 = rnd(lo2f(rv.z) * g1[0] + b1[0]), x5 = rnd(hi2f(rv.z) * g1[1] + b1[1]);
+                            const float x6 = rnd(lo2f(rv.w) * g1[2] + b1[2]), x7 = rnd(hi2f(rv.w) * g1[3] + b1[3]);
+                            o.x = pack2bf(lo2f(o.x) + x0, hi2f(o.x) + x1);
+                            o.y = pack2bf(lo2f(o.y) + x2, hi2f(o.y) + x3);
+                            o.z = pack2bf(lo2f(o.z) + x4, hi2f(o.z) + x5);
+                            o.w = pack2bf(lo2f(o.w) + x6, hi2f(o.w) + x7);
+                            // statistics of the STORED (bf16) values, for the next LayerNorm
+                            const float e0 = lo2f(o.x), e1 = hi2f(o.x), e2 = lo2f(o.y), e3 = hi2f(o.y), e4 = lo2f(o.z), e5 = hi2f(o.z), e6 = lo2f(o.w), e7 = hi2f(o.w);
+                            psum += ((e0 + e1) + (e2 + e3)) + ((e4 + e5) + (e6 + e7));
+                            psq += ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7));
+                        }
                         if (ABL != 3) *(uint4*)(Cb + m * p.ldc + n) = o;
                         else asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
                     }
                 }
+                if (EPI == 2) {
+                    // this lane summed 16 of the row's 64 columns in this wave's strip: the other 48 sit in the 3 neighbouring lanes of the quad
+                    psum += __shfl_xor(psum, 1, 64); psq += __shfl_xor(psq, 1, 64);
+                    psum += __shfl_xor(psum, 2, 64); psq += __shfl_xor(psq, 2, 64);
+                    if (schunk == 0 && m >= m_lo) *(float2*)(p.ln_partial + (m * (4 * p.tiles_n) + (tn * 4 + wn)) * 2) = make_float2(psum, psq);
+                    psum = 0.f; psq = 0.f;
+                }
                 if (nhave && emode == 2) { issue_q(2 * i); issue_q(2 * i + 1); }
-            }
-            if (RING3 && nhave && emode == 2) {
-#pragma unroll
-                for (int q = 16; q < NPRO; ++q) issue_q(q);
             }
         } else if (f32_ok) {
             // fp32 outputs (the ViT / pre-LN residual streams): same quad rule as above.  Lane (frow, fk) holds 4 consecutive fp32 =
@@ -581,7 +663,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             const bool full_tile_now = (m0 == m_lo) && (n0 == n_lo);
             tail_ops = 0;
             if (k_counted_wait && nhave) {
-                tail_ops = (nk > 1 ? 8 : 0) + (RING3 && nk > 2 ? 4 : 0);
+                tail_ops = nk > 1 ? 8 : 0;
                 if (emode == 2 && vec_ok && full_tile_now && nk > 1) tail_ops += RES ? 12 : 8;
             }
         }
@@ -598,15 +680,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     }
 }
 
-template <int ABL, bool TRACE, int ACT, bool RES, bool RING3>
+template <int ABL, bool TRACE, int ACT, bool RES, bool RING3, int EPI = 0>
 int launch256_one(const GemmParams& p, int grid, hipStream_t s) {
     constexpr int lds = RING3 ? 5 * 256 * 128 : 2 * SLOT_BYTES;   // 160 KiB (A x3 + W x2) or 128 KiB ([A|W] x2)
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<ABL, TRACE, ACT, RES, RING3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<ABL, TRACE, ACT, RES, RING3, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<ABL, TRACE, ACT, RES, RING3>), dim3(grid), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((gemm256_kernel<ABL, TRACE, ACT, RES, RING3, EPI>), dim3(grid), dim3(512), lds, s, p);
     SC_CHECK_LAUNCH();
     return 0;
 }
@@ -641,6 +723,7 @@ int launch256(const GemmParams& p, hipStream_t s) {
     if (abl && abl[0] == '5') return launch256_var<5, false>(p, grid, s);
     if (abl && abl[0] == '6') return launch256_var<6, false>(p, grid, s);
     if (abl && abl[0] == '7') return launch256_var<7, false>(p, grid, s);
+    if (abl && abl[0] == '8') return launch256_var<8, false>(p, grid, s);
     // SC_GEMM_RING3=1: three-slot A ring (see gemm256_kernel); A/B switch while the default is being decided by measurement
     static const bool ring3 = getenv("SC_GEMM_RING3") && atoi(getenv("SC_GEMM_RING3")) != 0;
     if (ring3) return launch256_var<0, false, true>(p, grid, s);
@@ -719,7 +802,44 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     static const int k_epi = getenv("SC_GEMM_EPI") ? atoi(getenv("SC_GEMM_EPI")) : 2;
     static const int k_epi_res = getenv("SC_GEMM_EPI_RES") ? atoi(getenv("SC_GEMM_EPI_RES")) : 3;
     p.rot = k_rot; p.band = k_band; p.epi_mode = k_epi; p.epi_mode_res = k_epi_res;
+    static const int k_pair = getenv("SC_GEMM_NOKPAIR") ? 0 : 1;
+    if (k_pair && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) p.kpair = (int)(lda / 2 / 64);   // k = 3, stride-2 conv layers of the extractor
     return gemm_dispatch(p, 1, (hipStream_t)stream);
+}
+
+// LayerNorm folded into the GEMMs on both sides of it (eval path of the post-LN transformer layers).  mode 1: A holds PRE-norm rows, W is
+// gamma (.) W, ln_stats [M,2] = (mean, rstd) per row, ln_c [N] = sum_k W'[n,k], bias = W beta + b:  C = act(rstd (A W'^T - mean c) + bias).
+// mode 2: C = A W^T + bias + LN(residual) with the residual's LayerNorm rebuilt per element from res_stats / res_gamma / res_beta, and the
+// per-(row, 64-column strip) partial (sum, sum of squares) of C written to ln_partial [M, N/64, 2] (finished by sc_ln_stats_finalize).
+// Returns 1 (nothing launched) when the shape is outside the 256-tile kernel's rules: the caller then runs the unfused sequence.
+extern "C" int sc_gemm_bf16_ln(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* residual,
+                               int64_t ldr, int64_t M, int N, int K, int flags, int mode, const float* ln_stats, const float* ln_c,
+                               const float* res_stats, const float* res_gamma, const float* res_beta, float* ln_partial, void* stream) {
+    SC_CHECK_ARG(mode == 1 || mode == 2, "sc_gemm_bf16_ln: mode=%d must be 1 (folded input LayerNorm) or 2 (rebuilt residual LayerNorm + output statistics)", mode);
+    SC_CHECK_ARG(A && W && C && bias, "sc_gemm_bf16_ln: null operand");
+    SC_CHECK_ARG(!(flags & SC_GEMM_OUT_F32), "sc_gemm_bf16_ln: bf16 outputs only");
+    if (M < 256 || N < 256 || K <= 0 || K % 64 || N % 8 || ldc % 8 || lda % 8 || ldw % 8 || lda < K) return 1;
+    if (mode == 2 && (N % 256 || !residual || ldr % 8)) return 1;
+    SC_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0, "sc_gemm_bf16_ln: A/W/C must be 16-byte aligned");
+    const int act = flags & SC_GEMM_ACT_MASK;
+    if (mode == 1) SC_CHECK_ARG(ln_stats && ln_c && !residual && (act == SC_ACT_NONE || act == SC_ACT_GELU), "sc_gemm_bf16_ln: mode 1 takes ln_stats + ln_c, no residual, act none / gelu");
+    if (mode == 2) SC_CHECK_ARG(res_stats && res_gamma && res_beta && ln_partial && act == SC_ACT_NONE, "sc_gemm_bf16_ln: mode 2 takes res_stats + res_gamma + res_beta + ln_partial, no activation");
+    g_last_path = 0;
+    GemmParams p{};
+    p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.w_mod = 1;
+    p.C = C; p.ldc = ldc; p.bias = bias; p.residual = residual; p.ldr = ldr;
+    p.M = M; p.N = N; p.K = K; p.act = act; p.out_f32 = 0;
+    p.rot = 1; p.band = 0; p.epi_mode = 2; p.epi_mode_res = 3;
+    p.tiles_m = (int)((M + 255) / 256); p.tiles_n = (N + 255) / 256;
+    p.ln_stats = ln_stats; p.ln_c = ln_c; p.res_stats = res_stats; p.res_gamma = res_gamma; p.res_beta = res_beta; p.ln_partial = ln_partial;
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 2) return launch256_one<0, false, SC_ACT_NONE, true, false, 2>(p, grid, s);
+    if (act == SC_ACT_GELU) return launch256_one<0, false, SC_ACT_GELU, false, false, 1>(p, grid, s);
+    return launch256_one<0, false, SC_ACT_NONE, false, false, 1>(p, grid, s);
 }
 
 extern "C" int sc_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw,

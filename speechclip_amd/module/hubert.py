@@ -18,6 +18,8 @@ import math
 from dataclasses import dataclass, field
 from typing import List, Sequence, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -199,6 +201,24 @@ class HubertModel(nn.Module):
                 ln1=(w32(lyr.self_attn_layer_norm.weight), w32(lyr.self_attn_layer_norm.bias)),
                 w1=w16(lyr.fc1.weight), b1=w32(lyr.fc1.bias), w2=w16(lyr.fc2.weight), b2=w32(lyr.fc2.bias),
                 ln2=(w32(lyr.final_layer_norm.weight), w32(lyr.final_layer_norm.bias))))
+        if not cfg.layer_norm_first:
+            # Folded-LayerNorm operands of the eval path (sc_gemm_bf16_ln): the LayerNorm in FRONT of a GEMM is absorbed as
+            #   LN(y) W^T + b = rstd (y W'^T - mean c) + (W beta + b),   W' = gamma (.) W,  c_n = sum_k W'[n,k]  (c from the bf16 W' the MFMA multiplies)
+            # fc1 absorbs LN1 of its own layer; the QKV projection of layer l absorbs LN2 of layer l-1 (layer 0 reads the normalised state).
+            def fold(w, b, g, be):
+                wf = w.detach().to(dev, f32)
+                wp = (wf * g.detach().to(dev, f32)[None, :]).to(bf).contiguous()
+                return wp, wp.float().sum(dim=1).contiguous(), (wf @ be.detach().to(dev, f32) + b.detach().to(dev, f32)).contiguous()
+            lys = list(self.encoder.layers)
+            for li, (lyr, L) in enumerate(zip(lys, P["layers"])):
+                L["w1f"], L["c1"], L["d1"] = fold(lyr.fc1.weight, lyr.fc1.bias, lyr.self_attn_layer_norm.weight, lyr.self_attn_layer_norm.bias)
+                if li > 0:
+                    prev = lys[li - 1].final_layer_norm
+                    a = lyr.self_attn
+                    L["wqkvf"], L["cqkv"], L["dqkv"] = fold(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0),
+                                                             torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0), prev.weight, prev.bias)
+            P["ln2_gamma"] = torch.stack([L["ln2"][0] for L in P["layers"]]).contiguous()
+            P["ln2_beta"] = torch.stack([L["ln2"][1] for L in P["layers"]]).contiguous()
         return P
 
     def _buf(self, name, shape, dtype, dev, zero=False):
@@ -228,10 +248,24 @@ class HubertModel(nn.Module):
         return [min(T, -(-int(l) // chunk)) for l in lens]
 
     # ------------------------------------------------------------------ forward
+    def fold_ln_supported(self, B: int, lmax: int) -> bool:
+        """The folded-LayerNorm eval path (no separate LayerNorm pass, hidden states kept PRE-norm) exists for post-LN models whose rows
+        fill the 256 x 256-tile GEMM: B*Tp >= 256 and d a multiple of 256 (HuBERT-base: 768).  OPT-IN (SC_FOLD_LN=1): measured on the B = 256
+        step it removes the 24 LayerNorm launches (2.1 ms at the HBM roofline, 71 us each) but pays them back in epilogue time of the
+        out-proj GEMM (+34 us), statistics finalisation (2 x 8 us per layer) and a VALU-bound layer mix (+0.33 ms), and the HBM-bound
+        LayerNorm phases are where the side-stream image tower overlaps best: 46.5 ms folded vs 46.2 ms unfolded."""
+        if self.cfg.layer_norm_first or os.environ.get("SC_FOLD_LN", "0") != "1":
+            return False
+        d = self.cfg.encoder_embed_dim
+        Tp = self.frame_geometry(lmax)[3]
+        return d % 256 == 0 and B * Tp >= 256 and self.cfg.encoder_ffn_embed_dim >= 256
+
     @torch.no_grad()
-    def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int]):
+    def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int], fold_ln: bool = False):
         """wav: f32 [B, Lmax] device tensor (right zero-padded); lens: host ints.
-        Returns (hidden [n_layers+1, B, Tp, d] (bf16 for post-LN, f32 for pre-LN), T, Tp, valid_frames)."""
+        Returns (hidden [n_layers+1, B, Tp, d] (bf16 for post-LN, f32 for pre-LN), T, Tp, valid_frames).
+        fold_ln (caller checked fold_ln_supported): returns ((h0 [M,d], ypre [n_layers, M, d], gamma2, beta2), T, Tp, valid) instead -- layer 0's
+        normalised state and the PRE-LayerNorm outputs of the layers with the affines of their final LayerNorms (ops.weighted_sum_ln mixes them)."""
         cfg = self.cfg
         dev = wav.device
         if self._packed is None:
@@ -275,7 +309,7 @@ class HubertModel(nn.Module):
         nl = cfg.encoder_layers
         pre_ln = cfg.layer_norm_first
         hid_dtype = torch.float32 if pre_ln else bf
-        hidden = self._buf("hidden", (nl + 1, M, d), hid_dtype, dev)
+        hidden = self._buf("hidden0", (1, M, d), hid_dtype, dev) if fold_ln else self._buf("hidden", (nl + 1, M, d), hid_dtype, dev)
         g, bta = (None, None) if pre_ln else P["enc_ln"]
         ops.posconv(xp, valid_i32, P["pos_w"], P["pos_b"], g, bta, B, Tp, d, cfg.conv_pos_groups, cfg.conv_pos, out=hidden[0])
         # ---- transformer layers
@@ -285,6 +319,40 @@ class HubertModel(nn.Module):
         ffn = self._buf("ffn", (M, cfg.encoder_ffn_embed_dim), bf, dev)
         tmp = self._buf("tmp", (M, d), bf, dev)
         tmp2 = self._buf("tmp2", (M, d), bf, dev)
+        if fold_ln:
+            assert not pre_ln
+            # LayerNorm folded into the GEMMs around it: per layer  qkv <- LN2_{l-1} folded;  y1 = att Wo + bo + LN2_{l-1}(y2_{l-1}) (+ stats);
+            # ffn = gelu(LN1 folded);  y2 = ffn W2 + b2 + LN1(y1) (+ stats).  Neither LN1's nor LN2's output is ever written.
+            ypre = self._buf("ypre", (nl, M, d), bf, dev)
+            y1 = tmp
+            npart = d // 64
+            part = self._buf("ln_part", (M, npart, 2), torch.float32, dev)
+            st1 = self._buf("ln_st1", (M, 2), torch.float32, dev)
+            st2 = self._buf("ln_st2", (M, 2), torch.float32, dev)
+            fresh = ("ln_ident", (M, 2), torch.float32) not in self._ws
+            ident = self._buf("ln_ident", (M, 2), torch.float32, dev)          # (mean, rstd) = (0, 1): layer 0's residual is already normalised
+            ones, zeros = self._buf("ln_ones", (d,), torch.float32, dev), self._buf("ln_zeros", (d,), torch.float32, dev, zero=True)
+            if fresh:
+                ident[:, 0] = 0.0
+                ident[:, 1] = 1.0
+                ones.fill_(1.0)
+            for i, L in enumerate(P["layers"]):
+                if i == 0:      # layer 0 reads the normalised state: plain QKV, identity "LayerNorm" on the residual
+                    ops.gemm(hidden[0], L["wqkv"], L["bqkv"], out=qkv)
+                    res, rst, rg, rb = hidden[0], ident, ones, zeros
+                else:
+                    ok = ops.gemm_ln(ypre[i - 1], L["wqkvf"], L["dqkv"], 1, out=qkv, ln_stats=st2, ln_c=L["cqkv"])
+                    assert ok is not None
+                    res, rst, rg, rb = ypre[i - 1], st2, P["layers"][i - 1]["ln2"][0], P["layers"][i - 1]["ln2"][1]
+                ops.attention(qkv, B, Tp, H, valid_i32, out=att)
+                ok = ops.gemm_ln(att, L["wo"], L["bo"], 2, residual=res, out=y1, res_stats=rst, res_gamma=rg, res_beta=rb, ln_partial=part)
+                assert ok is not None
+                ops.ln_stats_finalize(part, d, out=st1)
+                ops.gemm_ln(y1, L["w1f"], L["d1"], 1, ACT_GELU, out=ffn, ln_stats=st1, ln_c=L["c1"])
+                ops.gemm_ln(ffn, L["w2"], L["b2"], 2, residual=y1, out=ypre[i], res_stats=st1, res_gamma=L["ln1"][0], res_beta=L["ln1"][1], ln_partial=part)
+                if i + 1 < nl:
+                    ops.ln_stats_finalize(part, d, out=st2)
+            return (hidden[0], ypre, P["ln2_gamma"], P["ln2_beta"]), T, Tp, valid
         for i, L in enumerate(P["layers"]):
             h = hidden[i]
             if not pre_ln:

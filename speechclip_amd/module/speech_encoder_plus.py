@@ -140,13 +140,25 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             padded = torch.zeros(len(wavs), max(lens), device=dev, dtype=torch.float32)
             for i, w in enumerate(wavs):
                 padded[i, : lens[i]] = w.to(dev, torch.float32)
-        hidden, T, Tp, _valid = self.encoder.extract_all_layers(padded, lens)      # [n, B, Tp, d]
         if self.normalize_hiddenstates and self.normalize_type.startswith("method"):
             raise NotImplementedError("normalize_type method1/method2 are not used by any shipped config")
-        # speech_encoder_plus.py:604-611: Python round() (banker's) of len / 320, clamped to T
-        feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()   # escapes to the caller
         if feat_select_idx is None:
             feat_select_idx = self.feat_select_idx
+        # Eval fast path: nobody asked for the hidden states themselves (only their mix), so the LayerNorms are folded into the GEMMs around
+        # them and the layer mix rebuilds each state from its pre-norm rows (module/hubert.py: fold_ln).  The states are materialised when they
+        # are returned, selected by index, or needed by the training tail's layer-mix gradient.
+        mix_only = (feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE and not return_hidden_states
+                    and not (torch.is_grad_enabled() and self.weightedsum_layer.weights.requires_grad)
+                    and not self.weightedsum_layer.normalize_features)
+        if mix_only and self.encoder.fold_ln_supported(padded.shape[0], padded.shape[1]):
+            (h0, ypre, g2, b2), T, Tp, _valid = self.encoder.extract_all_layers(padded, lens, fold_ln=True)
+            B_, d_ = padded.shape[0], h0.shape[-1]
+            mixed = ops.weighted_sum_ln(h0, ypre, g2, b2, self.weightedsum_layer.weights.detach().float()).view(B_, Tp, d_)[:, :T]
+            feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()
+            return (mixed, feat_len)
+        hidden, T, Tp, _valid = self.encoder.extract_all_layers(padded, lens)      # [n, B, Tp, d]
+        # speech_encoder_plus.py:604-611: Python round() (banker's) of len / 320, clamped to T
+        feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()   # escapes to the caller
         layers = lambda: tuple(hidden[i, :, :T] for i in range(hidden.shape[0]))  # noqa: E731
         out = []
         if feat_select_idx == "all":
