@@ -394,11 +394,10 @@ def main():
             # report the committed per-launch figure of the same command, with its source, or null if it is not there / not this workload
             traffic, tsrc = None, None
             tf = os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")
-            if not os.path.exists(tf):
-                tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
             if os.path.exists(tf) and not args.train and not large and not casc and B == 256 and L == 160000:
                 tj = json.load(open(tf))
-                traffic, tsrc = tj["hand_written_main_stream"]["bytes_per_launch"], tj["source"] + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2; gemm256_kernel + gemm_bf16_kernel launches)"
+                traffic = tj["gemm_main_stream"]["bytes_per_launch"]
+                tsrc = tj["source"] + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; main-stream gemm256_kernel + gemm_bf16_kernel launches of the same command)"
             # the entry serves two kernels (vendor_gemm.hip): the hand-written gemm256_kernel family (everything fused / overlapping rows /
             # small) and hipBLASLt (plain GEMMs).  The DOMINANT kernel of the step is the hand-written one: `achieved` is ITS flops / ITS time;
             # the whole entry and the library part are reported beside it.

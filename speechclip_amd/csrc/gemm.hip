@@ -376,12 +376,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     if (ABL != 1) {   // one LDS-DMA instruction per MFMA group instead of a burst behind the barrier
                         int la = lane_a, lw = lane_w;
                         asm volatile("" : "+v"(la), "+v"(lw));   // keep the 64-bit source addresses out of the loop-invariant set (VGPR pressure)
-                        if (!RING3 && ABL == 8) {   // placement variant (correct results): both pieces of a row group in MFMA groups 4..7, which carry one ds_read instead of two
-                            if (dma_k0 >= 0 && i >= 4) {
-                                glds16(sa.ta + ((i - 4) * lda64 + dma_k0) + la, dma_slot + ((i - 4) * 512 + wave * 64) * 16);
-                                glds16(sa.tw + ((i - 4) * ldw64 + dma_k0) + lw, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
-                            }
-                        } else if (!RING3) {
+                        if (!RING3) {
                             const int dk = (ABL == 7) ? 0 : dma_k0;   // ABL 7 (timing probe, garbage results): the in-loop DMA always re-reads k-chunk 0 = cache hits
                             if (dma_k0 >= 0) {
                                 if (i < 4) glds16(sa.ta + (i * lda64 + dk) + la, dma_slot + (i * 512 + wave * 64) * 16);
@@ -723,10 +718,13 @@ int launch256(const GemmParams& p, hipStream_t s) {
     if (abl && abl[0] == '5') return launch256_var<5, false>(p, grid, s);
     if (abl && abl[0] == '6') return launch256_var<6, false>(p, grid, s);
     if (abl && abl[0] == '7') return launch256_var<7, false>(p, grid, s);
-    if (abl && abl[0] == '8') return launch256_var<8, false>(p, grid, s);
-    // SC_GEMM_RING3=1: three-slot A ring (see gemm256_kernel); A/B switch while the default is being decided by measurement
+#ifdef SC_GEMM_BUILD_RING3
+    // Experiment kept in the source, not in the default build (-DSC_GEMM_BUILD_RING3 + SC_GEMM_RING3=1): the three-slot A ring of
+    // gemm256_kernel.  Round 2 measured both uses of the third slot -- A prefetched one k-step deeper, and the refill spread evenly over both
+    // half-steps -- on every shape of the step: -6 ... +1 %, whole step 47.4 vs 47.5 ms.
     static const bool ring3 = getenv("SC_GEMM_RING3") && atoi(getenv("SC_GEMM_RING3")) != 0;
     if (ring3) return launch256_var<0, false, true>(p, grid, s);
+#endif
     return launch256_var<0, false>(p, grid, s);
 }
 
