@@ -283,6 +283,30 @@ int sc_grad_norm(const float* g, int64_t n, float max_norm, void* workspace, flo
 int sc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* clip_coef, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, void* stream);
 
+/* ---- Fine-tuning HuBERT transformer layers (speech_encoder_plus.py:416-446: `trainable` with `reinit_layers` / `unfreeze_layers`; the feature
+ * extractor, positional conv and projections stay frozen as the reference freezes them in those modes).  The dense products of the backward
+ * run on sc_gemm_bf16 / sc_gemm_bf16_batched (dX = dY W on transposed weight copies; dW = dY^T X as a split-K batched product over
+ * transposed activations); these are the pieces around them.
+ *   sc_transpose_bf16: batch of [rows, cols] -> [cols, rows_padded] (rows >= `rows` zero filled: the TN products' K must be a multiple of 64).
+ *   sc_attn_softmax_bwd: per (batch z, query i): P = softmax(scale S + mask(keys >= klens[z])) and dS = scale P (dP - dO_i . O_i), from
+ *     S = Q K^T and dP = dO V^T (f32 [batch, Lp, ld]); dO / O: bf16 rows (z*rows_per_batch + i) of 64 head dims; P / dS: bf16 [batch, Lp, ld].
+ *   sc_gelu_bwd_bf16: du = dh gelu'(u), exact erf form.   sc_axpy_bf16: y += alpha x.
+ *   sc_layernorm_bwd_bf16: dx per row + partial column sums part f32 [sc_layernorm_bwd_bf16_partials(rows), 2, D] (dgamma, dbeta rows; the
+ *     caller reduces them with sc_colsum).   sc_colsum_bf16: out[c] (=|+=) sum_r x[r,c], two deterministic stages.
+ *   sc_cls_pool_dz: d loss / d (mixed frames) from sc_cls_pool_bwd's workspaces: dz[b,t] = sum_r pp[b,r,NQ+t] dzbar[b,r] + ds[b,r,NQ+t] u[r]. */
+int sc_transpose_bf16(const void* in, int64_t ld_in, int64_t stride_in, void* out, int64_t ld_out, int64_t stride_out, int rows, int cols,
+                      int rows_padded, int batch, void* stream);
+int sc_attn_softmax_bwd(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
+                        int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch, float scale, void* stream);
+int sc_gelu_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, void* stream);
+int64_t sc_layernorm_bwd_bf16_partials(int64_t rows);
+int sc_layernorm_bwd_bf16(const void* x, const void* dy, const float* gamma, void* dx, float* part, int64_t rows, int D, float eps, void* stream);
+int64_t sc_colsum_bf16_workspace_bytes(int64_t rows, int cols);
+int sc_colsum_bf16(const void* x, int64_t ld, int64_t rows, int cols, float* ws, float* out, int accumulate, void* stream);
+int sc_axpy_bf16(void* y, const void* x, float alpha, int64_t n, void* stream);
+int sc_cls_pool_dz(const float* pp, const float* ds, const float* dzbar, const float* u, const int32_t* lens, void* dz, int B, int T, int NQ, int R,
+                   int D, int64_t ld_dz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,15 @@ def _declare(L):
         "sc_gemm_bf16_batched": ([P, L64, L64, P, L64, L64, I, P, L64, L64, P, L64, I, I, I, I, P], c_int),
         "sc_layernorm": ([P, L64, P, P, P, L64, L64, I, F, I, P], c_int),
         "sc_weighted_sum_fwd": ([P, L64, P, P, I, L64, I, I, F, P], c_int),
+        "sc_transpose_bf16": ([P, L64, L64, P, L64, L64, I, I, I, I, P], c_int),
+        "sc_attn_softmax_bwd": ([P, P, L64, L64, P, L64, P, L64, L64, P, P, P, I, I, I, F, P], c_int),
+        "sc_gelu_bwd_bf16": ([P, P, P, L64, P], c_int),
+        "sc_layernorm_bwd_bf16_partials": ([L64], c_int64),
+        "sc_layernorm_bwd_bf16": ([P, P, P, P, P, L64, I, F, P], c_int),
+        "sc_colsum_bf16_workspace_bytes": ([L64, I], c_int64),
+        "sc_colsum_bf16": ([P, L64, L64, I, P, P, I, P], c_int),
+        "sc_axpy_bf16": ([P, P, F, L64, P], c_int),
+        "sc_cls_pool_dz": ([P, P, P, P, P, P, I, I, I, I, I, L64, P], c_int),
         "sc_gemm_bf16_ln": ([P, L64, P, L64, P, L64, P, P, L64, L64, I, I, I, I, P, P, P, P, P, P, P], c_int),
         "sc_ln_stats_finalize": ([P, I, P, L64, I, F, P], c_int),
         "sc_weighted_sum_ln_fwd": ([P, P, L64, P, P, P, P, I, L64, I, F, P], c_int),

@@ -1,0 +1,248 @@
+// Backward pieces for fine-tuning HuBERT transformer layers (reference: speech_encoder_plus.py:416-446
+// `trainable` / `reinit_layers` / `unfreeze_layers` -- the selected fairseq TransformerSentenceEncoderLayers train, the feature extractor,
+// positional conv and projections stay frozen).  The dense products run on the MFMA GEMM of gemm.hip (dX = dY W on transposed weight copies;
+// dW = dY^T X as a split-K batched GEMM over transposed activations); this file holds what the GEMM cannot do:
+//   sc_transpose_bf16        batched, strided [R, C] -> [C, Rpad] transposes (operands of the TN products, zero padded to the GEMM's K rule)
+//   sc_attn_softmax_bwd      rows of P = softmax(scale S + key mask) and dS = scale P (dP - rowsum(dO . O)) from S = Q K^T, dP = dO V^T
+//   sc_gelu_bwd_bf16         du = dh gelu'(u) (exact erf form)
+//   sc_layernorm_bwd_bf16    dx from (x, dy, gamma) per row + per-chunk partial column sums for dgamma / dbeta
+//   sc_colsum_bf16           bias gradients: column sums of a bf16 [rows, cols] matrix (two-stage, deterministic)
+//   sc_axpy_bf16             y += alpha x (the layer mix's share of a hidden state's gradient)
+//   sc_cls_pool_dz           gradient of the mixed frames out of the pooling head's backward workspaces (sc_cls_pool_bwd keeps it in registers)
+#include "common.h"
+#include "../../include/speechclip_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int64_t ld_in, int64_t stride_in, bf16_t* __restrict__ out,
+                                                             int64_t ld_out, int64_t stride_out, int R, int C, int Rpad) {
+    __shared__ bf16_t tile[64][66];
+    const int z = blockIdx.z, r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const bf16_t* src = in + (int64_t)z * stride_in;
+    bf16_t* dst = out + (int64_t)z * stride_out;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 4 row groups of 16
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = r0 + ty * 16 + k, c = c0 + tx;
+        tile[ty * 16 + k][tx] = (r < R && c < C) ? src[(int64_t)r * ld_in + c] : (bf16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = c0 + ty * 16 + k, r = r0 + tx;
+        if (c < C && r < Rpad) dst[(int64_t)c * ld_out + r] = tile[tx][ty * 16 + k];
+    }
+}
+
+// one wave per (batch z, query row i): S / dP rows f32 [L] (row stride ld), keys j >= klen[z] masked
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ S, const float* __restrict__ dP, int64_t ld, int64_t stride,
+                                                               const bf16_t* __restrict__ dO, int64_t ld_do, const bf16_t* __restrict__ O, int64_t ld_o,
+                                                               int64_t row_stride_z, const int32_t* __restrict__ klens, bf16_t* __restrict__ P,
+                                                               bf16_t* __restrict__ dS, int L, int Lp, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), z = blockIdx.y;
+    if (i >= Lp) return;
+    bf16_t* prow = P + (int64_t)z * stride + (int64_t)i * ld;
+    bf16_t* drow = dS + (int64_t)z * stride + (int64_t)i * ld;
+    const int klen = klens ? klens[z] : L;
+    if (i >= L) {                                                       // padding rows of the [Lp, Lp] images: zeros (they are K-dim padding of the TN products)
+        for (int j = lane; j < Lp; j += 64) { prow[j] = 0; drow[j] = 0; }
+        return;
+    }
+    const float* srow = S + (int64_t)z * stride + (int64_t)i * ld;
+    const float* gprow = dP + (int64_t)z * stride + (int64_t)i * ld;
+    // D_i = dO_i . O_i over the 64 head dims (one per lane)
+    const int64_t r = (int64_t)z * row_stride_z + i;
+    const float dd = wave_sum(bf2f(dO[r * ld_do + lane]) * bf2f(O[r * ld_o + lane]));
+    float mx = -INFINITY;
+    for (int j = lane; j < klen; j += 64) mx = fmaxf(mx, srow[j] * scale);
+    mx = wave_max(mx);
+    float den = 0.f;
+    for (int j = lane; j < klen; j += 64) den += __expf(srow[j] * scale - mx);
+    den = wave_sum(den);
+    const float inv = den > 0.f ? 1.0f / den : 0.f;
+    for (int j = lane; j < Lp; j += 64) {
+        float p = 0.f, ds = 0.f;
+        if (j < klen) {
+            p = __expf(srow[j] * scale - mx) * inv;
+            ds = p * (gprow[j] - dd) * scale;
+        }
+        prow[j] = f2bf(p);
+        drow[j] = f2bf(ds);
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_bf16_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ dh, bf16_t* __restrict__ du, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= n) return;
+    const uint32_t uu = *(const uint32_t*)(u + i), gg = *(const uint32_t*)(dh + i);
+    auto d = [](float x) { return 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x); };
+    *(uint32_t*)(du + i) = pack2bf(lo2f(gg) * d(lo2f(uu)), hi2f(gg) * d(hi2f(uu)));
+}
+
+// LayerNorm backward, bf16 rows: dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)); per-chunk partial sums of dy xhat (dgamma) and dy (dbeta).
+// One wave per row, a block (4 waves) owns a chunk of `rows_per_block` consecutive rows and writes ONE partial row: part[chunk][0][D], [1][D].
+__global__ __launch_bounds__(256) void ln_bwd_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ gamma,
+                                                          bf16_t* __restrict__ dx, float* __restrict__ part, int64_t rows, int D, float eps,
+                                                          int rows_per_block) {
+    __shared__ float sg[4][1024], sb[4][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int nd = D / 64;                                             // D % 64 == 0, <= 1024
+    float ag[16], ab[16], g[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { ag[m] = 0.f; ab[m] = 0.f; g[m] = (m < nd) ? gamma[lane + 64 * m] : 0.f; }
+    for (int64_t row = row_begin + w; row < row_begin + rows_per_block && row < rows; row += 4) {
+        float xv[16], gv[16];
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { xv[m] = (m < nd) ? bf2f(x[row * D + lane + 64 * m]) : 0.f; s += xv[m]; }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) if (m < nd) { const float d = xv[m] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) if (m < nd) {
+            const float dyv = bf2f(dy[row * D + lane + 64 * m]);
+            const float xh = (xv[m] - mean) * rstd;
+            gv[m] = dyv * g[m];
+            s1 += gv[m]; s2 += gv[m] * xh;
+            ag[m] += dyv * xh; ab[m] += dyv;
+            xv[m] = xh;
+        }
+        s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) if (m < nd) dx[row * D + lane + 64 * m] = f2bf(rstd * (gv[m] - s1 - xv[m] * s2));
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) if (m < nd) { sg[w][lane + 64 * m] = ag[m]; sb[w][lane + 64 * m] = ab[m]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        part[((int64_t)blockIdx.x * 2 + 0) * D + c] = (sg[0][c] + sg[1][c]) + (sg[2][c] + sg[3][c]);
+        part[((int64_t)blockIdx.x * 2 + 1) * D + c] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_bf16_stage1_kernel(const bf16_t* __restrict__ x, int64_t ld, int64_t rows, int cols, float* __restrict__ part,
+                                                                 int rows_per_block) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    float s = 0.f;
+    for (int64_t r = r0; r < r0 + rows_per_block && r < rows; ++r) s += bf2f(x[r * ld + c]);
+    part[(int64_t)blockIdx.x * cols + c] = s;
+}
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ __launch_bounds__(256) void axpy_bf16_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x, float alpha, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= n) return;
+    const uint32_t yy = *(const uint32_t*)(y + i), xx = *(const uint32_t*)(x + i);
+    *(uint32_t*)(y + i) = pack2bf(lo2f(yy) + alpha * lo2f(xx), hi2f(yy) + alpha * hi2f(xx));
+}
+
+// dz[b, t, :] = sum_r pp[b, r, NQ + t] dzbar[b, r, :] + ds[b, r, NQ + t] u[r, :]   for t < lens[b], else 0  (train.hip's frame-level algebra)
+__global__ __launch_bounds__(256) void cls_pool_dz_kernel(const float* __restrict__ pp, const float* __restrict__ ds, const float* __restrict__ dzbar,
+                                                          const float* __restrict__ u, const int32_t* __restrict__ lens, bf16_t* __restrict__ dz, int T, int NQ,
+                                                          int R, int D, int64_t ld_dz) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    bf16_t* out = dz + ((int64_t)b * T + t) * ld_dz;
+    if (t >= lens[b]) {
+        for (int d = threadIdx.x; d < D; d += 256) out[d] = 0;
+        return;
+    }
+    const int Lk = NQ + T;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const int64_t pi = ((int64_t)b * R + r) * Lk + NQ + t;
+            acc += pp[pi] * dzbar[((int64_t)b * R + r) * D + d] + ds[pi] * u[(int64_t)r * D + d];
+        }
+        out[d] = f2bf(acc);
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_transpose_bf16(const void* in, int64_t ld_in, int64_t stride_in, void* out, int64_t ld_out, int64_t stride_out, int rows, int cols,
+                                 int rows_padded, int batch, void* stream) {
+    SC_CHECK_ARG(in && out && rows > 0 && cols > 0 && rows_padded >= rows && batch > 0 && batch <= 65535, "sc_transpose_bf16: bad arguments");
+    SC_CHECK_ARG(ld_out >= rows_padded && ld_in >= cols, "sc_transpose_bf16: leading dimensions too small");
+    dim3 grid((rows_padded + 63) / 64, (cols + 63) / 64, batch);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, stride_in, (bf16_t*)out, ld_out, stride_out,
+                       rows, cols, rows_padded);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_attn_softmax_bwd(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
+                                   int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch, float scale, void* stream) {
+    SC_CHECK_ARG(S && dP && dO && O && P && dS && L > 0 && Lp >= L && batch > 0 && batch <= 65535 && ld >= Lp, "sc_attn_softmax_bwd: bad arguments");
+    hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((Lp + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, S, dP, ld, stride, (const bf16_t*)dO, ld_do,
+                       (const bf16_t*)O, ld_o, rows_per_batch, klens, (bf16_t*)P, (bf16_t*)dS, L, Lp, scale);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_gelu_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, void* stream) {
+    SC_CHECK_ARG(n % 2 == 0, "sc_gelu_bwd_bf16: n=%lld must be even", (long long)n);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gelu_bwd_bf16_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)u, (const bf16_t*)dh,
+                       (bf16_t*)du, n);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int64_t sc_layernorm_bwd_bf16_partials(int64_t rows) {   // number of partial rows the kernel writes: part is f32 [partials, 2, D]
+    const int64_t rpb = rows >= 65536 ? 128 : (rows >= 4096 ? 32 : 4);
+    return (rows + rpb - 1) / rpb;
+}
+
+extern "C" int sc_layernorm_bwd_bf16(const void* x, const void* dy, const float* gamma, void* dx, float* part, int64_t rows, int D, float eps, void* stream) {
+    SC_CHECK_ARG(D > 0 && D <= 1024 && D % 64 == 0, "sc_layernorm_bwd_bf16: D=%d must be a multiple of 64, <= 1024", D);
+    if (rows <= 0) return 0;
+    const int rpb = rows >= 65536 ? 128 : (rows >= 4096 ? 32 : 4);
+    hipLaunchKernelGGL(ln_bwd_bf16_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, gamma,
+                       (bf16_t*)dx, part, rows, D, eps, rpb);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int64_t sc_colsum_bf16_workspace_bytes(int64_t rows, int cols) {
+    const int64_t rpb = rows >= 65536 ? 512 : 64;
+    return ((rows + rpb - 1) / rpb) * (int64_t)cols * 4;
+}
+
+extern "C" int sc_colsum_bf16(const void* x, int64_t ld, int64_t rows, int cols, float* ws, float* out, int accumulate, void* stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const int rpb = rows >= 65536 ? 512 : 64;
+    const int nparts = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum_bf16_stage1_kernel, dim3(nparts, (cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows, cols, ws, rpb);
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, nparts, cols, out, accumulate);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_axpy_bf16(void* y, const void* x, float alpha, int64_t n, void* stream) {
+    SC_CHECK_ARG(n % 2 == 0, "sc_axpy_bf16: n=%lld must be even", (long long)n);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(axpy_bf16_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)y, (const bf16_t*)x, alpha, n);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sc_cls_pool_dz(const float* pp, const float* ds, const float* dzbar, const float* u, const int32_t* lens, void* dz, int B, int T, int NQ, int R,
+                              int D, int64_t ld_dz, void* stream) {
+    SC_CHECK_ARG(pp && ds && dzbar && u && lens && dz && B > 0 && T > 0 && B <= 65535, "sc_cls_pool_dz: bad arguments");
+    hipLaunchKernelGGL(cls_pool_dz_kernel, dim3(T, B), dim3(256), 0, (hipStream_t)stream, pp, ds, dzbar, u, lens, (bf16_t*)dz, T, NQ, R, D, ld_dz);
+    SC_CHECK_LAUNCH();
+    return 0;
+}

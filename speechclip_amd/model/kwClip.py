@@ -239,7 +239,8 @@ def _kw_parallel_forward_train(self, audio_feat: torch.Tensor, audio_len: torch.
     seed = int(torch.randint(0, 2 ** 31 - 8, (1,)).item()) if drop_p > 0 else 0
     meta = dict(heads=self.self_att.nhead, eps=self.self_att.eps, drop_p=drop_p, seed=seed, normalize=normalize)
     proj = (self.linear_proj.weight, self.linear_proj.bias) if hasattr(self, "linear_proj") else (None, None)
-    return ParallelBranchTrainFn.apply(meta, hidden, audio_feat.detach(), audio_len, mixw, self.cls, sa.in_proj_weight, sa.in_proj_bias,
+    frames = audio_feat if audio_feat.requires_grad else audio_feat.detach()       # requires_grad: fine-tuned encoder layers below (train_hubert.py)
+    return ParallelBranchTrainFn.apply(meta, hidden, frames, audio_len, mixw, self.cls, sa.in_proj_weight, sa.in_proj_bias,
                                        sa.out_proj.weight, sa.out_proj.bias, L.norm1.weight, L.norm1.bias, L.linear1.weight, L.linear1.bias,
                                        L.linear2.weight, L.linear2.bias, L.norm2.weight, L.norm2.bias, self.self_att.model.norm.weight,
                                        self.self_att.model.norm.bias, *proj)
@@ -309,7 +310,8 @@ def _kw_cascaded_forward_train(self, audio_feat: torch.Tensor, audio_len: torch.
     seed = int(torch.randint(0, 2 ** 31 - 8, (1,)).item()) if drop_p > 0 else 0
     meta = dict(heads=self.self_att.nhead, eps=self.self_att.eps, drop_p=drop_p, seed=seed, normalize=normalize)
     n = self.self_att.attentionBlock_Norm
-    kw = CascadedPoolTrainFn.apply(meta, hidden, audio_feat.detach(), audio_len, mixw, self.cls, mha.in_proj_weight, mha.in_proj_bias,
+    frames = audio_feat if audio_feat.requires_grad else audio_feat.detach()       # requires_grad: fine-tuned encoder layers below (train_hubert.py)
+    kw = CascadedPoolTrainFn.apply(meta, hidden, frames, audio_len, mixw, self.cls, mha.in_proj_weight, mha.in_proj_bias,
                                    mha.out_proj.weight, mha.out_proj.bias, n.weight, n.bias, self.linear_proj.weight,
                                    self.linear_proj.bias).view(B, K, self.text_dim)
     if hasattr(self, "bn_layer"):

@@ -261,15 +261,20 @@ class HubertModel(nn.Module):
         return d % 256 == 0 and B * Tp >= 256 and self.cfg.encoder_ffn_embed_dim >= 256
 
     @torch.no_grad()
-    def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int], fold_ln: bool = False):
+    def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int], fold_ln: bool = False, stop_layer: int = None):
         """wav: f32 [B, Lmax] device tensor (right zero-padded); lens: host ints.
-        Returns (hidden [n_layers+1, B, Tp, d] (bf16 for post-LN, f32 for pre-LN), T, Tp, valid_frames).
+        Returns (hidden [n_layers+1, B, Tp, d] (bf16 for post-LN, f32 for pre-LN), T, Tp, valid_frames); with `stop_layer` = L only
+        hidden[0..L] are computed.
         fold_ln (caller checked fold_ln_supported): returns ((h0 [M,d], ypre [n_layers, M, d], gamma2, beta2), T, Tp, valid) instead -- layer 0's
         normalised state and the PRE-LayerNorm outputs of the layers with the affines of their final LayerNorms (ops.weighted_sum_ln mixes them)."""
         cfg = self.cfg
         dev = wav.device
-        if self._packed is None:
+        # packed bf16 operands are rebuilt when a load replaced the weights (post-hook) or an optimizer step moved TRAINABLE encoder weights
+        # (fine-tuning: ops.param_epoch; frozen encoders never repack)
+        epoch = ops.param_epoch(*[p for p in self.parameters() if p.requires_grad]) if any(p.requires_grad for p in self.parameters()) else -1
+        if self._packed is None or getattr(self, "_packed_epoch", -1) != epoch:
             self._packed = self._pack(dev)
+            self._packed_epoch = epoch
         P = self._packed
         B, lmax = wav.shape
         T0, T, P0, Tp = self.frame_geometry(lmax)
@@ -354,6 +359,8 @@ class HubertModel(nn.Module):
                     ops.ln_stats_finalize(part, d, out=st2)
             return (hidden[0], ypre, P["ln2_gamma"], P["ln2_beta"]), T, Tp, valid
         for i, L in enumerate(P["layers"]):
+            if stop_layer is not None and i >= stop_layer:      # fine-tuning: the layers from here on run as one autograd node (train_hubert.py)
+                break
             h = hidden[i]
             if not pre_ln:
                 ops.gemm(h, L["wqkv"], L["bqkv"], out=qkv)

@@ -56,9 +56,13 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         super().__init__()
         assert name in self.MODEL2URL, "Model name({}) should be in {}".format(name, self.MODEL2URL.keys())
         assert normalize_type in ["s3prl", "method1", "method2"], normalize_type
-        if trainable or len(reinit_layers) > 0 or len(unfreeze_layers) > 0:
-            raise NotImplementedError("fine-tuning HuBERT needs backward kernels (SURVEY.md section 8f rank 4); "
-                                      "all shipped configs freeze it (trainable: false)")
+        assert not (len(reinit_layers) > 0 and len(unfreeze_layers) > 0)            # speech_encoder_plus.py:415
+        if (len(reinit_layers) > 0 or len(unfreeze_layers) > 0) and not trainable:
+            raise AssertionError("reinit_layers / unfreeze_layers need trainable=True (speech_encoder_plus.py:418,:433)")
+        if trainable and not (len(reinit_layers) > 0 or len(unfreeze_layers) > 0):
+            raise NotImplementedError("trainable=True without reinit_layers / unfreeze_layers also trains the conv feature extractor and the positional "
+                                      "conv, whose backward kernels are not built; list the transformer layers to train (the modes in which the "
+                                      "reference freezes everything below them, speech_encoder_plus.py:416-446)")
         if not (layer_drop == "original" or (isinstance(layer_drop, float) and 0.0 <= layer_drop <= 1.0)):
             raise ValueError(f"layer_drop = {layer_drop} is not supported.")
         self.name, self.pretrained, self.trainable = name, pretrained, trainable
@@ -85,6 +89,28 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         for p in self.encoder.parameters():
             p.requires_grad = False
         self.encoder.eval()
+        # speech_encoder_plus.py:416-446: the listed transformer layers train (reinit_layers: re-initialised first, fairseq init_bert_params);
+        # every other layer, pos_conv, layer_norm, the feature extractor and post_extract_proj stay frozen (feature_grad_mult = 0)
+        self.train_layers = sorted(set(int(i) for i in (list(reinit_layers) + list(unfreeze_layers))))
+        if self.train_layers:
+            if cfg.layer_norm_first:
+                raise NotImplementedError("fine-tuning pre-LN (HuBERT-large) layers is not built; HuBERT-base layers are (train_hubert.py)")
+            if isinstance(layer_drop, float) and layer_drop > 0.0:
+                raise NotImplementedError("layerdrop > 0 while training encoder layers is not supported (every shipped config uses 0.0)")
+            assert 0 <= self.train_layers[0] and self.train_layers[-1] < cfg.encoder_layers, self.train_layers
+            for i in self.train_layers:
+                lyr = self.encoder.encoder.layers[i]
+                if i in reinit_layers:
+                    for m in lyr.modules():
+                        if isinstance(m, nn.Linear):
+                            nn.init.normal_(m.weight, mean=0.0, std=0.02)
+                            nn.init.zeros_(m.bias)
+                        elif isinstance(m, nn.LayerNorm):
+                            nn.init.ones_(m.weight)
+                            nn.init.zeros_(m.bias)
+                for p in lyr.parameters():
+                    p.requires_grad = True
+            self.encoder.feature_grad_mult = 0
         self.downsample_rate = self.MODEL_DOWNSAMPLE_RATE[name]
         self.out_dim = cfg.encoder_embed_dim
         self.upstream_model_hiddenstates_len = cfg.encoder_layers + 1
@@ -93,9 +119,10 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                                                       normalize_features=self.normalize_hiddenstates and self.normalize_type == "s3prl")
 
     def trainable_params(self) -> list:
+        params = [p for p in self.encoder.parameters() if p.requires_grad]            # speech_encoder_plus.py:636-648: encoder parameters when trainable
         if self.feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
-            return list(self.weightedsum_layer.parameters())
-        return []
+            params += list(self.weightedsum_layer.parameters())
+        return params
 
     @staticmethod
     def _to_list(wav, wav_len):
@@ -156,6 +183,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             mixed = ops.weighted_sum_ln(h0, ypre, g2, b2, self.weightedsum_layer.weights.detach().float()).view(B_, Tp, d_)[:, :T]
             feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()
             return (mixed, feat_len)
+        if self.train_layers and torch.is_grad_enabled():
+            return self._forward_finetune(padded, lens, feat_select_idx, return_hidden_states)
         hidden, T, Tp, _valid = self.encoder.extract_all_layers(padded, lens)      # [n, B, Tp, d]
         # speech_encoder_plus.py:604-611: Python round() (banker's) of len / 320, clamped to T
         feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()   # escapes to the caller
@@ -183,6 +212,39 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if return_hidden_states:
             out.append(layers())
         return tuple(out)
+
+
+def _forward_finetune(self, padded, lens, feat_select_idx, return_hidden_states):
+    """Training forward with encoder layers L0.. as ONE autograd node (train_hubert.HubertLayersTrainFn): the frozen part below the lowest
+    trainable layer runs on the eval path, the layer mix carries the gradient to the hidden states (WeightedSumTrainFn)."""
+    from ..train_hubert import HubertLayersTrainFn, WeightedSumTrainFn, layer_params
+    if feat_select_idx != FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
+        raise NotImplementedError("fine-tuning is wired for feat_select_idx = weighted_sum (every shipped config)")
+    enc = self.encoder
+    cfg = enc.cfg
+    dev = padded.device
+    L0, nl = self.train_layers[0], cfg.encoder_layers
+    hidden, T, Tp, valid = enc.extract_all_layers(padded, lens, stop_layer=L0)        # hidden[0 .. L0] are valid
+    B, d = padded.shape[0], cfg.encoder_embed_dim
+    M = B * Tp
+    params = []
+    for i in range(L0, nl):
+        params += layer_params(enc.encoder.layers[i])
+    meta = dict(B=B, Tp=Tp, H=cfg.encoder_attention_heads, eps=1e-5, train=[i in self.train_layers for i in range(L0, nl)])
+    h_in = hidden[L0].reshape(M, d).clone()          # the engine's hidden buffer is a reused workspace: the autograd node keeps its own copy
+    hi = HubertLayersTrainFn.apply(meta, h_in, ops.dev_ints(valid, torch.int32, dev), *params)      # [nl - L0, M, d]
+    hidden_all = torch.cat([hidden[:L0 + 1].reshape(L0 + 1, M, d).detach(), hi], 0)
+    ws = self.weightedsum_layer
+    mixed = WeightedSumTrainFn.apply(hidden_all, ws.weights, ws.normalize_features).view(B, Tp, d)[:, :T]
+    mixed._mix_src = (hidden_all.detach().view(nl + 1, B, Tp, d), ws)                  # the mix weights' gradient comes out of the head's backward
+    feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()
+    out = [mixed, feat_len]
+    if return_hidden_states:
+        out.append(tuple(hidden_all[i].view(B, Tp, d)[:, :T] for i in range(nl + 1)))
+    return tuple(out)
+
+
+FairseqSpeechEncoder_Hubert._forward_finetune = _forward_finetune
 
 
 class S3prlSpeechEncoderPlus(nn.Module):

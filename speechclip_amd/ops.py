@@ -154,13 +154,16 @@ def weighted_sum_ln(h0, ypre, gamma, beta, weights, eps=1e-5):
     return out
 
 
-def gemm_batched(a, lda, stride_a, w, stride_w, w_mod, out, ldc, stride_c, bias, M, N, K, batch, act=ACT_NONE):
+def gemm_batched(a, lda, stride_a, w, stride_w, w_mod, out, ldc, stride_c, bias, M, N, K, batch, act=ACT_NONE, ldw=None):
+    """`batch` products out_z[M,N] = a_z[M,K] w_{z % w_mod}[N,K]^T (+ bias); operand z at base + z * stride (elements); `a`, `w`, `out` may be
+    views whose data_ptr is operand 0.  out dtype f32 => fp32 outputs."""
     _need_cuda(a, w, out)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib().sc_gemm_bf16_batched(ptr(a), lda, stride_a, ptr(w), K, stride_w, w_mod, ptr(out), ldc, stride_c, ptr(bias),
-                                     M, N, K, batch, act, stream()), "sc_gemm_bf16_batched")
+    flags = act | (GEMM_OUT_F32 if out.dtype == torch.float32 else 0)
+    check(lib().sc_gemm_bf16_batched(ptr(a), lda, stride_a, ptr(w), K if ldw is None else ldw, stride_w, w_mod, ptr(out), ldc, stride_c, ptr(bias),
+                                     M, N, K, batch, flags, stream()), "sc_gemm_bf16_batched")
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, act, False, False, 0, batch),   # tag[6] = path (0 hand-written), tag[7] = batch
@@ -497,7 +500,7 @@ def cls_pool_train_fwd(x_rows, cls_tok, scores, cls_scores, lens_i32, B, T, NQ, 
     return p, xbar
 
 
-def cls_pool_bwd(x_rows, cls_tok, hidden, p, dzbar, u, lens_i32, B, T, NQ, R, D, normalize=False, drop_p=0.0, seed=0, nsplit=None):
+def cls_pool_bwd(x_rows, cls_tok, hidden, p, dzbar, u, lens_i32, B, T, NQ, R, D, normalize=False, drop_p=0.0, seed=0, nsplit=None, return_ws=False):
     """-> (du f32 [B*S,R,D], dcls_key f32 [B*S,NQ,D], dalpha f32 [B*S,n] or None): PARTIAL rows (S = nsplit key-splits per utterance); the
     caller sums over rows.  hidden: bf16 / f32 [n, B*T, D] contiguous or None."""
     _need_cuda(x_rows)
@@ -516,6 +519,8 @@ def cls_pool_bwd(x_rows, cls_tok, hidden, p, dzbar, u, lens_i32, B, T, NQ, R, D,
     check(lib().sc_cls_pool_bwd(ptr(x_rows), x_rows.stride(0), ptr(cls_tok), ptr(hidden), int(n > 0 and hidden.dtype == torch.float32), hidden.stride(0) if n else 0, n,
                                 int(normalize), ptr(p), ptr(dzbar), ptr(u), ptr(lens_i32), ptr(ds), ptr(pp), ptr(du), ptr(dck), ptr(dalpha), B, T, NQ, R, D,
                                 int(nsplit), float(drop_p), int(seed) & 0xFFFFFFFF, stream()), "sc_cls_pool_bwd")
+    if return_ws:          # (ds, pp): score gradients and post-dropout probabilities [B,R,NQ+T], what sc_cls_pool_dz needs
+        return du, dck, dalpha, ds, pp
     return du, dck, dalpha
 
 
@@ -728,3 +733,75 @@ def image_normalize_u8(u8, mean=CLIP_MEAN, std=CLIP_STD):
     check(lib().sc_image_normalize_u8(ptr(u8), ptr(out), B, H, W, ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), stream()),
           "sc_image_normalize_u8")
     return out
+
+
+# ---- fine-tuning HuBERT layers (train_hubert.hip) ----
+def transpose_bf16(src, ld_in, stride_in, rows, cols, batch, rows_padded=None, out=None):
+    """batch of [rows, cols] bf16 matrices (row r of matrix z at src + z*stride_in + r*ld_in) -> out bf16 [batch, cols, rows_padded] (zero padded)."""
+    _need_cuda(src)
+    rp = rows if rows_padded is None else rows_padded
+    if out is None:
+        out = torch.empty(batch, cols, rp, device=src.device, dtype=bf16)
+    check(lib().sc_transpose_bf16(ptr(src), ld_in, stride_in, ptr(out), rp, cols * rp, rows, cols, rp, batch, stream()), "sc_transpose_bf16")
+    return out
+
+
+def attn_softmax_bwd(S, dP, dO_head, ld_do, O_head, ld_o, rows_per_batch, klens_i32, L, scale):
+    """S, dP f32 [Z, Lp, Lp]; dO_head / O_head: views at the head's first column, rows of stride ld_*; -> (P, dS) bf16 [Z, Lp, Lp]."""
+    _need_cuda(S, dP)
+    Z, Lp, _ = S.shape
+    P = torch.empty(Z, Lp, Lp, device=S.device, dtype=bf16)
+    dS = torch.empty_like(P)
+    check(lib().sc_attn_softmax_bwd(ptr(S), ptr(dP), Lp, Lp * Lp, ptr(dO_head), ld_do, ptr(O_head), ld_o, rows_per_batch, ptr(klens_i32), ptr(P), ptr(dS),
+                                    L, Lp, Z, float(scale), stream()), "sc_attn_softmax_bwd")
+    return P, dS
+
+
+def gelu_bwd_bf16(u, dh):
+    _need_cuda(u, dh)
+    assert u.dtype == bf16 and dh.dtype == bf16 and u.is_contiguous() and dh.is_contiguous() and u.shape == dh.shape
+    du = torch.empty_like(u)
+    check(lib().sc_gelu_bwd_bf16(ptr(u), ptr(dh), ptr(du), u.numel(), stream()), "sc_gelu_bwd_bf16")
+    return du
+
+
+def layernorm_bwd_bf16(x, dy, gamma, eps=1e-5, want_param_grads=True):
+    """x, dy bf16 [rows, D] -> (dx bf16, dgamma f32 [D] | None, dbeta f32 [D] | None)."""
+    _need_cuda(x, dy, gamma)
+    rows, D = x.shape
+    assert x.dtype == bf16 and dy.dtype == bf16 and x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    npart = int(lib().sc_layernorm_bwd_bf16_partials(rows))
+    part = torch.empty(npart, 2 * D, device=x.device, dtype=torch.float32)
+    check(lib().sc_layernorm_bwd_bf16(ptr(x), ptr(dy), ptr(gamma), ptr(dx), ptr(part), rows, D, eps, stream()), "sc_layernorm_bwd_bf16")
+    if not want_param_grads:
+        return dx, None, None
+    sums = colsum(part)
+    return dx, sums[:D].contiguous(), sums[D:].contiguous()
+
+
+def colsum_bf16(x, out=None, accumulate=False):
+    _need_cuda(x)
+    assert x.dtype == bf16 and x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    ws = torch.empty(int(lib().sc_colsum_bf16_workspace_bytes(rows, cols)), device=x.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty(cols, device=x.device, dtype=torch.float32)
+        accumulate = False
+    check(lib().sc_colsum_bf16(ptr(x), x.stride(0), rows, cols, ptr(ws), ptr(out), int(accumulate), stream()), "sc_colsum_bf16")
+    return out
+
+
+def axpy_bf16(y, x, alpha):
+    _need_cuda(y, x)
+    assert y.dtype == bf16 and x.dtype == bf16 and y.is_contiguous() and x.is_contiguous() and y.numel() == x.numel()
+    check(lib().sc_axpy_bf16(ptr(y), ptr(x), float(alpha), y.numel(), stream()), "sc_axpy_bf16")
+    return y
+
+
+def cls_pool_dz(pp, ds, dzbar, u, lens_i32, B, T, NQ, R, D):
+    """-> dz bf16 [B*T, D]: gradient of the mixed frames from sc_cls_pool_bwd's workspaces."""
+    _f32c(pp, ds, dzbar, u)
+    dz = torch.empty(B * T, D, device=pp.device, dtype=bf16)
+    check(lib().sc_cls_pool_dz(ptr(pp), ptr(ds), ptr(dzbar), ptr(u), ptr(lens_i32), ptr(dz), B, T, NQ, R, D, D, stream()), "sc_cls_pool_dz")
+    return dz

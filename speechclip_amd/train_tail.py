@@ -102,7 +102,7 @@ class ParallelBranchTrainFn(torch.autograd.Function):
         x2 = ops.layernorm(y2, _c(n2w), _c(n2b), eps, out_f32=True)
         x3 = ops.layernorm(x2, _c(nfw), _c(nfb), 1e-5, out_f32=True)
         out = ops.sgemm(x3, _c(pw), transb=True, bias=_c(pb)) if pw is not None else x3.clone()
-        ctx.meta = dict(meta, B=B, Tp=Tp, D=D, NQ=NQ, R=R, hd=hd, scale=scale)
+        ctx.meta = dict(meta, B=B, T=T, Tp=Tp, D=D, NQ=NQ, R=R, hd=hd, scale=scale)
         ctx.hidden = hidden
         ctx.has = (mixw is not None, pw is not None)
         ctx.save_for_backward(rows, lens_i, c, Win, qt, U, p, zbar, att, y, x1, z1, hm, y2, x2, x3,
@@ -156,7 +156,13 @@ class ParallelBranchTrainFn(torch.autograd.Function):
         ops.sgemm_batched(B, D, hd, datt, D, hd, Wv, D, hd * D, dzbar, R * D, D, H)                               # dzbar_h = datt_h Wv_h
         hid = ctx.hidden
         hid2 = hid.reshape(hid.shape[0], B * Tp, D) if (has_mix and hid is not None) else None
-        du, dck, dalpha = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)), drop_p=pd, seed=seed)
+        dx16 = None
+        if ctx.needs_input_grad[2]:      # the frames themselves carry a gradient (fine-tuned encoder layers: train_hubert.py)
+            du, dck, dalpha, ds_ws, pp_ws = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)),
+                                                             drop_p=pd, seed=seed, return_ws=True)
+            dx16 = ops.cls_pool_dz(pp_ws, ds_ws, dzbar, U, lens_i, B, Tp, NQ, R, D).view(B, Tp, D)[:, :m["T"]]
+        else:
+            du, dck, dalpha = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)), drop_p=pd, seed=seed)
         dU = ops.colsum(du.view(-1, R * D)).view(R, D)                                        # rows: B x key-splits
         ops.colsum(dck.view(-1, NQ * D), out=dcls.view(NQ * D), accumulate=True)               # CLS token as a key / value
         # parameter-only chain: u_r = scale Wk_h^T q_h (beta carries no gradient: softmax is shift invariant)
@@ -170,7 +176,7 @@ class ParallelBranchTrainFn(torch.autograd.Function):
         if has_mix and dalpha is not None:
             dmix = z(mixw.shape[0])
             ops.mix_softmax_bwd(mixw, dalpha, dmix)
-        return (None, None, None, None, dmix, dcls.view(1, NQ, D), dWin, dbin, dWo, dbo, dn1w, dn1b, dl1w, dl1b, dl2w, dl2b, dn2w, dn2b, dnfw, dnfb,
+        return (None, None, dx16, None, dmix, dcls.view(1, NQ, D), dWin, dbin, dWo, dbo, dn1w, dn1b, dl1w, dl1b, dl2w, dl2b, dn2w, dn2b, dnfw, dnfb,
                 dpw, dpb)
 
 
@@ -218,7 +224,7 @@ class CascadedPoolTrainFn(torch.autograd.Function):
         y = ops.add_rows(sa, c)                                                               # + src rows (the CLS tokens)
         kn = ops.layernorm(y, _c(nw), _c(nb), eps, out_f32=True)
         kp = ops.sgemm(kn, _c(pw), transb=True, bias=_c(pb))
-        ctx.meta = dict(meta, B=B, Tp=Tp, D=D, NQ=NQ, R=R, hd=hd, scale=scale)
+        ctx.meta = dict(meta, B=B, T=T, Tp=Tp, D=D, NQ=NQ, R=R, hd=hd, scale=scale)
         ctx.hidden = hidden
         ctx.has_mix = mixw is not None
         ctx.save_for_backward(rows, lens_i, c, Win, qt, U, p, zbar, att, y, kn, _c(out_w), _c(nw), _c(pw), _c(mixw) if mixw is not None else c)
@@ -249,7 +255,13 @@ class CascadedPoolTrainFn(torch.autograd.Function):
         ops.sgemm_batched(B * NQ, D, hd, datt, D, hd, Wv, D, hd * D, dzbar, H * D, D, H)                          # dzbar_h = datt_h Wv_h
         hid = ctx.hidden
         hid2 = hid.reshape(hid.shape[0], B * Tp, D) if (ctx.has_mix and hid is not None) else None
-        du, dck, dalpha = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)), drop_p=pd, seed=seed)
+        dx16 = None
+        if ctx.needs_input_grad[2]:      # fine-tuned encoder layers below: the frames carry a gradient (train_hubert.py)
+            du, dck, dalpha, ds_ws, pp_ws = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)),
+                                                             drop_p=pd, seed=seed, return_ws=True)
+            dx16 = ops.cls_pool_dz(pp_ws, ds_ws, dzbar, U, lens_i, B, Tp, NQ, R, D).view(B, Tp, D)[:, :m["T"]]
+        else:
+            du, dck, dalpha = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)), drop_p=pd, seed=seed)
         dU = ops.colsum(du.view(-1, R * D)).view(R, D)
         ops.colsum(dck.view(-1, NQ * D), out=dcls.view(NQ * D), accumulate=True)
         dqt = torch.empty(NQ, D, device=dev, dtype=torch.float32)
@@ -262,7 +274,7 @@ class CascadedPoolTrainFn(torch.autograd.Function):
         if ctx.has_mix and dalpha is not None:
             dmix = z(mixw.shape[0])
             ops.mix_softmax_bwd(mixw, dalpha, dmix)
-        return None, None, None, None, dmix, dcls.view(1, NQ, D), dWin, dbin, dWo, dbo, dnw, dnb, dpw, dpb
+        return None, None, dx16, None, dmix, dcls.view(1, NQ, D), dWin, dbin, dWo, dbo, dnw, dnb, dpw, dpb
 
 
 class KwBatchNormTrainFn(torch.autograd.Function):
