@@ -493,3 +493,34 @@ def test_reference_yaml_builds_through_the_task_entry_point(rel, tmp_path, monke
     assert model.config.audio_encoder.name == cfg["audio_encoder"]["name"] and model.config.seed == 7122
     opt, sched = model.configure_optimizers()
     assert len(opt) == 1 and len(model.getTrainableParams()) > 0
+
+
+def test_encoder_fine_tuning_flags_follow_the_reference():
+    """speech_encoder_plus.py:416-446 on the host side: `trainable` + `unfreeze_layers` / `reinit_layers` mark exactly the listed transformer
+    layers trainable (pos_conv, layer_norm, the feature extractor and post_extract_proj stay frozen, feature_grad_mult = 0), reinit_layers
+    re-initialises them, and the argument combinations the reference asserts on are rejected."""
+    import dataclasses
+    from oracle.hubert_ref import HubertRefConfig
+    from speechclip_amd.module import FairseqSpeechEncoder_Hubert
+    from speechclip_amd.module.hubert import HubertConfig
+    hc = HubertConfig(**dataclasses.asdict(dataclasses.replace(HubertRefConfig.tiny(), encoder_layers=3)))
+    torch.manual_seed(0)
+    enc = FairseqSpeechEncoder_Hubert("hubert", trainable=True, unfreeze_layers=[1, 2], feat_select_idx="weighted_sum", hubert_config=hc)
+    names = [k for k, p in enc.encoder.named_parameters() if p.requires_grad]
+    assert len(names) == 32 and all(k.startswith(("encoder.layers.1.", "encoder.layers.2.")) for k in names)
+    assert enc.encoder.feature_grad_mult == 0 and enc.train_layers == [1, 2]
+    assert len(enc.trainable_params()) == 32 + 1                      # + the layer-mix weights
+    torch.manual_seed(0)
+    base = FairseqSpeechEncoder_Hubert("hubert", feat_select_idx="weighted_sum", hubert_config=hc)
+    torch.manual_seed(0)
+    re = FairseqSpeechEncoder_Hubert("hubert", trainable=True, reinit_layers=[2], feat_select_idx="weighted_sum", hubert_config=hc)
+    l2b, l2r = base.encoder.encoder.layers[2], re.encoder.encoder.layers[2]
+    assert not torch.equal(l2b.fc1.weight, l2r.fc1.weight) and torch.equal(base.encoder.encoder.layers[1].fc1.weight, re.encoder.encoder.layers[1].fc1.weight)
+    assert float(l2r.fc1.bias.abs().max()) == 0.0 and abs(float(l2r.fc1.weight.std()) - 0.02) < 2e-3
+    assert len(base.trainable_params()) == 1 and not any(p.requires_grad for p in base.encoder.parameters())
+    with pytest.raises(NotImplementedError):
+        FairseqSpeechEncoder_Hubert("hubert", trainable=True, hubert_config=hc)                      # would also train the conv stack: not built
+    with pytest.raises(AssertionError):
+        FairseqSpeechEncoder_Hubert("hubert", trainable=False, unfreeze_layers=[1], hubert_config=hc)
+    with pytest.raises(AssertionError):
+        FairseqSpeechEncoder_Hubert("hubert", trainable=True, unfreeze_layers=[1], reinit_layers=[2], hubert_config=hc)
