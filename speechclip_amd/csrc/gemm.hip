@@ -10,6 +10,7 @@
 // L2 hit).  The MFMA is issued with W as the "A operand" so that each lane ends up holding four
 // consecutive output columns of one row => 8-byte epilogue stores.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "../../include/speechclip_hip.h"
 
@@ -187,6 +188,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 //  * epilogue: bias/activation in registers -> bf16 -> wave-private LDS image -> full-row 16-byte stores
 //    (the direct fragment-shaped store is 32 x 8-byte stores per lane touching 16 lines each: issue-bound).
 constexpr int BK2 = 64;
+// -DSC_GEMM_BUFDMA=1 (build option, off): the LDS-DMA pieces go out as `buffer_load_dwordx4 ... offen lds` (one SGPR resource per operand and tile,
+// ONE loop-invariant 32-bit lane offset, the k / row-group offset in an SGPR) instead of `global_load_lds_dwordx4` on a 64-bit per-lane address.
+// Round-2 PMC (profiles/r02_gemm_qkv_pmc_stalls.txt) showed the global form costing 8 scalar + 5 vector instructions per piece -- 120 of the ~290
+// instructions a wave issues per k-step next to its 64 MFMAs; the buffer form needs 2 scalar ones (197 per k-step).  Same results on the whole GEMM test
+// suite, and the SAME time on every shape of the step (qkv 851 vs 850, fc1 812-828 vs 802-816, fc2 1104 vs 1131-1138, conv1 1076-1078 vs 1068-1071 TF/s;
+// step 46.66 vs 46.58 ms): the loop is not instruction-issue bound either.  The k-loop peeling that came with it (no piece behind a branch) is kept.
+#ifndef SC_GEMM_BUFDMA
+#define SC_GEMM_BUFDMA 0
+#endif
 constexpr int SLOT_BYTES = 2 * 256 * BK2 * 2;  // 64 KiB: A [256][128 B] then B [256][128 B]
 
 // Source addressing of one tile: two WAVE-UNIFORM tile base pointers (SGPRs) + two 32-bit per-lane offsets fixed for the whole
@@ -291,23 +301,50 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int64_t lda64 = 64 * p.lda, ldw64 = 64 * p.ldw;
     const int lane_a = (tid >> 3) * (int)p.lda + (((tid & 7) ^ ((tid >> 3) & 7)) << 3);   // row (tid>>3), swizzled k-chunk
     const int lane_w = (tid >> 3) * (int)p.ldw + (((tid & 7) ^ ((tid >> 3) & 7)) << 3);
+    const int lane_a_b = lane_a * 2, lane_w_b = lane_w * 2;       // byte offsets of this lane inside a 64-row group (buffer form)
     auto tile_m0 = [&](int t) -> int64_t { const int64_t m = (int64_t)t * 256; return m + 256 <= p.M ? m : p.M - 256; };
     auto tile_n0 = [&](int t) -> int { const int n = t * 256; return n + 256 <= p.N ? n : p.N - 256; };
     int tm, tn;
     bool have = tile_of(0, tm, tn);
     StageAddr sa{nullptr, nullptr};
+#if SC_GEMM_BUFDMA
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
+#endif
+    auto set_tile = [&](const bf16_t* ta, const bf16_t* tw) {
+        sa = StageAddr{ta, tw};
+#if SC_GEMM_BUFDMA
+        ra = __builtin_amdgcn_make_buffer_rsrc((void*)ta, 0, 0x7fffffff, 0x00020000);      // per-tile bases: every offset below stays far inside 2 GiB
+        rw = __builtin_amdgcn_make_buffer_rsrc((void*)tw, 0, 0x7fffffff, 0x00020000);
+#endif
+    };
+    // one LDS-DMA piece (64 rows x 128 B... 8 rows per wave): row group g of A / W at k offset k0 (elements) into LDS at dst
+    auto piece_a = [&](int g, int k0, char* dst) {
+#if SC_GEMM_BUFDMA
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, lane_a_b, (int)((g * lda64 + k0) * 2), 0, 0);
+#else
+        glds16(sa.ta + (g * lda64 + k0) + lane_a, dst);
+#endif
+    };
+    auto piece_w = [&](int g, int k0, char* dst) {
+#if SC_GEMM_BUFDMA
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, lane_w_b, (int)((g * ldw64 + k0) * 2), 0, 0);
+#else
+        glds16(sa.tw + (g * ldw64 + k0) + lane_w, dst);
+#endif
+    };
     int tail_ops = 0;   // vector-memory operations the previous epilogue issued after the next tile's stage-0 pieces (0 = unknown: drain)
     // q-th prologue DMA instruction of a tile, in issue order: A(0) x4, W(0) x4, A(1) x4, W(1) x4
     constexpr int NPRO = 16;
     auto issue_q = [&](int q) {
         const int st = q >> 3, g = q & 7;
         if (st >= nk) return;
-        if (g < 4) glds16(sa.ta + (g * lda64 + kofs(st)) + lane_a, a_slot(st) + (g * 512 + wave * 64) * 16);
-        else if (st < 2) glds16(sa.tw + ((g - 4) * ldw64 + kofs(st)) + lane_w, w_dst(st) + ((g - 4) * 512 + wave * 64) * 16);
+        if (g < 4) piece_a(g, kofs(st), a_slot(st) + (g * 512 + wave * 64) * 16);
+        else if (st < 2) piece_w(g - 4, kofs(st), w_dst(st) + ((g - 4) * 512 + wave * 64) * 16);
     };
     if (have) {
         rot = p.rot ? tm % nk : 0;
-        sa = StageAddr{A + tile_m0(tm) * p.lda, W + (int64_t)tile_n0(tn) * p.ldw};
+        set_tile(A + tile_m0(tm) * p.lda, W + (int64_t)tile_n0(tn) * p.ldw);
 #pragma unroll
         for (int q = 0; q < NPRO; ++q) issue_q(q);
     }
@@ -349,7 +386,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         // fragments of the next half go into bn right after the first MFMA group, so no LDS wait gates the group head.
         // srcA / srcW: slots the next half's fragments are read from; dma_k0 >= 0: refill stage (2-ring: A and W of one stage into dma_slot;
         // RING3: W of that stage into dma_slot and, dma_ka0 >= 0, A of the stage after it into dma_aslot)
-        auto half_step = [&](const char* srcA, const char* srcW, int off, bool load_next, int dma_k0, char* dma_slot, int dma_ka0, char* dma_aslot) {
+        auto half_step = [&](auto dma_tag, const char* srcA, const char* srcW, int off, bool load_next, int dma_k0, char* dma_slot, int dma_ka0, char* dma_aslot) {
+            constexpr bool DMA = decltype(dma_tag)::value;      // compile-time: the loop is peeled, no piece sits behind a run-time test
             bf16x8_t bn[4];
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -373,18 +411,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     if (!((ABL == 5 || ABL == 6) && (i & 1))) af[i] = *(const bf16x8_t*)(srcA + a_base + off + i * 16 * 128);
                     if (i < 4 && !(ABL == 6 && (i & 1))) bn[i] = *(const bf16x8_t*)(srcW + b_base + off + i * 16 * 128);
                     if (ABL == 6 && i < 4 && (i & 1)) bn[i] = bn[i - 1];
-                    if (ABL != 1) {   // one LDS-DMA instruction per MFMA group instead of a burst behind the barrier
-                        int la = lane_a, lw = lane_w;
-                        asm volatile("" : "+v"(la), "+v"(lw));   // keep the 64-bit source addresses out of the loop-invariant set (VGPR pressure)
+                    if (DMA && ABL != 1) {   // one LDS-DMA instruction per MFMA group instead of a burst behind the barrier
                         if (!RING3) {
                             const int dk = (ABL == 7) ? 0 : dma_k0;   // ABL 7 (timing probe, garbage results): the in-loop DMA always re-reads k-chunk 0 = cache hits
-                            if (dma_k0 >= 0) {
-                                if (i < 4) glds16(sa.ta + (i * lda64 + dk) + la, dma_slot + (i * 512 + wave * 64) * 16);
-                                else glds16(sa.tw + ((i - 4) * ldw64 + dk) + lw, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
-                            }
+                            if (i < 4) piece_a(i, dk, dma_slot + (i * 512 + wave * 64) * 16);
+                            else piece_w(i - 4, dk, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
                         } else if (i >= 4) {   // one piece per MFMA group in groups 4..7 (they carry one fragment read, groups 0..3 two): W or A of a stage
-                            if (dma_k0 >= 0) glds16(sa.tw + ((i - 4) * ldw64 + dma_k0) + lw, dma_slot + ((i - 4) * 512 + wave * 64) * 16);
-                            else if (dma_ka0 >= 0) glds16(sa.ta + ((i - 4) * lda64 + dma_ka0) + la, dma_aslot + ((i - 4) * 512 + wave * 64) * 16);
+                            if (dma_k0 >= 0) piece_w(i - 4, dma_k0, dma_slot + ((i - 4) * 512 + wave * 64) * 16);
+                            else if (dma_ka0 >= 0) piece_a(i - 4, dma_ka0, dma_aslot + ((i - 4) * 512 + wave * 64) * 16);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -404,20 +438,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };
-        for (int kt = 0; kt + 1 < nk; ++kt) {
+        using T_ = std::integral_constant<bool, true>;
+        using F_ = std::integral_constant<bool, false>;
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) {       // steady state: stage kt + 2 exists, every refill piece is issued unconditionally
             // MFMAs of (kt, h0); read (kt, h1); RING3: A pieces of stage kt+2 into the A slot stage kt-1 left free
-            if (!RING3) half_step(a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, -1, nullptr);
-            else half_step(a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, kt + 2 < nk ? kofs(kt + 2) : -1, a_slot(kt + 2));
+            if (!RING3) half_step(F_{}, a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, -1, nullptr);
+            else half_step(T_{}, a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, kofs(kt + 2), a_slot(kt + 2));
             mid_sync(kt);
             // MFMAs of (kt, h1); read (kt+1, h0); refill: 2-ring = stage kt+2 (A and W) into slot kt; RING3 = W(kt+2) into W slot kt
-            if (!RING3) half_step(a_slot(kt + 1), w_slot(kt + 1), off_h0, true, kt + 2 < nk ? kofs(kt + 2) : -1, a_slot(kt), -1, nullptr);
-            else half_step(a_slot(kt + 1), w_slot(kt + 1), off_h0, true, kt + 2 < nk ? kofs(kt + 2) : -1, w_slot(kt), -1, nullptr);
+            if (!RING3) half_step(T_{}, a_slot(kt + 1), w_slot(kt + 1), off_h0, true, kofs(kt + 2), a_slot(kt), -1, nullptr);
+            else half_step(T_{}, a_slot(kt + 1), w_slot(kt + 1), off_h0, true, kofs(kt + 2), w_slot(kt), -1, nullptr);
+        }
+        if (kt + 1 < nk) {                // k-step nk - 2: nothing left to refill
+            half_step(F_{}, a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, -1, nullptr);
+            mid_sync(kt);
+            half_step(F_{}, a_slot(kt + 1), w_slot(kt + 1), off_h0, true, -1, nullptr, -1, nullptr);
         }
         {   // last k-step (peeled: nothing left to prefetch after its first half)
-            const int kt = nk - 1;
-            half_step(a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, -1, nullptr);
+            const int kl = nk - 1;
+            half_step(F_{}, a_slot(kl), w_slot(kl), off_h1, true, -1, nullptr, -1, nullptr);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            half_step(nullptr, nullptr, 0, false, -1, nullptr, -1, nullptr);
+            half_step(F_{}, nullptr, nullptr, 0, false, -1, nullptr, -1, nullptr);
         }
         // bias for this lane's 4 x 4 output columns: loaded BEFORE the next tile's LDS-DMA is issued (an ordinary load
         // issued behind the DMA would have to drain it first: vmcnt is in-order)
@@ -445,7 +487,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int nrot = (nhave && p.rot) ? ntm % nk : 0;
-        if (nhave) sa = StageAddr{A + tile_m0(ntm) * p.lda, W + (int64_t)tile_n0(ntn) * p.ldw};
+        if (nhave) set_tile(A + tile_m0(ntm) * p.lda, W + (int64_t)tile_n0(ntn) * p.ldw);
         rot = nrot;   // the k-loop of THIS tile is over; from here on kofs() addresses the next tile
         const int emode = (RES ? p.epi_mode_res : p.epi_mode) & 0xff;
         if (nhave && emode == 0) {
