@@ -201,25 +201,28 @@ class HubertModel(nn.Module):
                 ln1=(w32(lyr.self_attn_layer_norm.weight), w32(lyr.self_attn_layer_norm.bias)),
                 w1=w16(lyr.fc1.weight), b1=w32(lyr.fc1.bias), w2=w16(lyr.fc2.weight), b2=w32(lyr.fc2.bias),
                 ln2=(w32(lyr.final_layer_norm.weight), w32(lyr.final_layer_norm.bias))))
-        if not cfg.layer_norm_first:
-            # Folded-LayerNorm operands of the eval path (sc_gemm_bf16_ln): the LayerNorm in FRONT of a GEMM is absorbed as
-            #   LN(y) W^T + b = rstd (y W'^T - mean c) + (W beta + b),   W' = gamma (.) W,  c_n = sum_k W'[n,k]  (c from the bf16 W' the MFMA multiplies)
-            # fc1 absorbs LN1 of its own layer; the QKV projection of layer l absorbs LN2 of layer l-1 (layer 0 reads the normalised state).
-            def fold(w, b, g, be):
-                wf = w.detach().to(dev, f32)
-                wp = (wf * g.detach().to(dev, f32)[None, :]).to(bf).contiguous()
-                return wp, wp.float().sum(dim=1).contiguous(), (wf @ be.detach().to(dev, f32) + b.detach().to(dev, f32)).contiguous()
-            lys = list(self.encoder.layers)
-            for li, (lyr, L) in enumerate(zip(lys, P["layers"])):
-                L["w1f"], L["c1"], L["d1"] = fold(lyr.fc1.weight, lyr.fc1.bias, lyr.self_attn_layer_norm.weight, lyr.self_attn_layer_norm.bias)
-                if li > 0:
-                    prev = lys[li - 1].final_layer_norm
-                    a = lyr.self_attn
-                    L["wqkvf"], L["cqkv"], L["dqkv"] = fold(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0),
-                                                             torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0), prev.weight, prev.bias)
-            P["ln2_gamma"] = torch.stack([L["ln2"][0] for L in P["layers"]]).contiguous()
-            P["ln2_beta"] = torch.stack([L["ln2"][1] for L in P["layers"]]).contiguous()
         return P
+
+    def _pack_fold(self, P, dev):
+        """Folded-LayerNorm operands of the opt-in eval path (sc_gemm_bf16_ln), built on first use: the LayerNorm in FRONT of a GEMM is absorbed as
+          LN(y) W^T + b = rstd (y W'^T - mean c) + (W beta + b),   W' = gamma (.) W,  c_n = sum_k W'[n,k]  (c from the bf16 W' the MFMA multiplies)
+        fc1 absorbs LN1 of its own layer; the QKV projection of layer l absorbs LN2 of layer l-1 (layer 0 reads the normalised state)."""
+        bf, f32 = torch.bfloat16, torch.float32
+
+        def fold(w, b, g, be):
+            wf = w.detach().to(dev, f32)
+            wp = (wf * g.detach().to(dev, f32)[None, :]).to(bf).contiguous()
+            return wp, wp.float().sum(dim=1).contiguous(), (wf @ be.detach().to(dev, f32) + b.detach().to(dev, f32)).contiguous()
+        lys = list(self.encoder.layers)
+        for li, (lyr, L) in enumerate(zip(lys, P["layers"])):
+            L["w1f"], L["c1"], L["d1"] = fold(lyr.fc1.weight, lyr.fc1.bias, lyr.self_attn_layer_norm.weight, lyr.self_attn_layer_norm.bias)
+            if li > 0:
+                prev = lys[li - 1].final_layer_norm
+                a = lyr.self_attn
+                L["wqkvf"], L["cqkv"], L["dqkv"] = fold(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0),
+                                                         torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0), prev.weight, prev.bias)
+        P["ln2_gamma"] = torch.stack([L["ln2"][0] for L in P["layers"]]).contiguous()
+        P["ln2_beta"] = torch.stack([L["ln2"][1] for L in P["layers"]]).contiguous()
 
     def _buf(self, name, shape, dtype, dev, zero=False):
         key = (name, tuple(shape), dtype)
@@ -326,6 +329,8 @@ class HubertModel(nn.Module):
         tmp2 = self._buf("tmp2", (M, d), bf, dev)
         if fold_ln:
             assert not pre_ln
+            if "ln2_gamma" not in P:
+                self._pack_fold(P, dev)
             # LayerNorm folded into the GEMMs around it: per layer  qkv <- LN2_{l-1} folded;  y1 = att Wo + bo + LN2_{l-1}(y2_{l-1}) (+ stats);
             # ffn = gelu(LN1 folded);  y2 = ffn W2 + b2 + LN1(y1) (+ stats).  Neither LN1's nor LN2's output is ever written.
             ypre = self._buf("ypre", (nl, M, d), bf, dev)

@@ -279,3 +279,50 @@ def test_short_finetuning_run_moves_the_encoder_layer_and_the_eval_path_sees_it(
     with torch.no_grad():
         after = model(batch)[0]["parallel_audio_feat"]
     assert (after - before).abs().max().item() > 1e-3           # the eval path repacked the trained layer's weights (parameter epoch)
+
+
+def test_cascaded_branch_passes_the_frame_gradient_down_too(tmp_path):
+    """C-base layout with a fine-tuned encoder layer: the cascaded head's backward (K keyword queries, BatchNorm with batch statistics, straight-through
+    VQ, frozen text tower) also returns d loss / d frames (sc_cls_pool_dz), the encoder layer receives finite, non-zero gradients, and a few
+    FusedAdam steps on one batch lower the loss."""
+    from helpers import make_config
+    from oracle.clip_ref import ClipRefConfig
+    from oracle.hubert_ref import HubertRefConfig
+    from speechclip_amd.model import KWClip_GeneralTransformer
+    from speechclip_amd.module.clip_model import ClipConfig
+    from speechclip_amd.module.hubert import HubertConfig
+    vocab = np.array([0, 320, 510, 511] + list(range(5, 300, 3)))
+    vp = str(tmp_path / "vocab.npy")
+    np.save(vp, np.stack([vocab, np.arange(len(vocab))[::-1] + 1], axis=1))
+    href, cref = HubertRefConfig.tiny(), ClipRefConfig.tiny()
+    cfg = make_config(d_model=128, branch_heads=4, parallel=False, cascaded=True, reduce_vocab=vp, hubert_config=HubertConfig(**dataclasses.asdict(href)),
+                      clip_config=ClipConfig(**dataclasses.asdict(cref)))
+    cfg.audio_encoder.trainable = True
+    cfg.audio_encoder.unfreeze_layers = [1]
+    torch.manual_seed(3)
+    model = KWClip_GeneralTransformer(cfg).cuda().train()
+    g = _g(4)
+    lens = [8000, 6100, 8000, 4000]
+    wav = torch.zeros(4, 8000)
+    for i, l in enumerate(lens):
+        wav[i, :l] = 0.3 * torch.randn(l, generator=g)
+    batch = {"wav": wav.cuda(), "wav_len": torch.tensor(lens).cuda(), "image": torch.randn(4, 3, 64, 64, generator=g).cuda(), "id": torch.arange(4).cuda()}
+    model.config.audio_encoder.optim.args.lr = 1e-3
+    model.config.audio_encoder.scheduler.warmup = 1
+    (opt,), (sch,) = model.configure_optimizers()
+    losses = []
+    torch.manual_seed(0)
+    for step in range(20):
+        opt.zero_grad()
+        loss = model.training_step_end(model.training_step(batch, step))["loss"]
+        loss.backward()
+        if step == 0:
+            lyr = model.audio_encoder.encoder.encoder.layers[1]
+            for k, p in lyr.named_parameters():
+                assert p.grad is not None and torch.isfinite(p.grad).all(), k
+            assert lyr.fc1.weight.grad.abs().max().item() > 0 and lyr.self_attn.q_proj.weight.grad.abs().max().item() > 0
+            assert model.audio_encoder.encoder.encoder.layers[0].fc1.weight.grad is None
+        opt.step()
+        sch["scheduler"].step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and np.mean(losses[-4:]) < np.mean(losses[:3]), losses

@@ -333,3 +333,25 @@ def test_cosine_scores_mfma_path_keeps_the_fp32_argmax(R, V, E):
     t_fast, _, _ = ops.vq_fwd(fast, 8)
     t_exact, _, _ = ops.vq_fwd(exact, 8)
     assert torch.equal(t_fast, t_exact)
+
+
+def test_flash_attention_creeping_and_jumping_maxima():
+    """Online-softmax stress: scores that creep upwards tile after tile (the running maximum moves in every tile), one jump far beyond everything
+    seen before, rows that never move, ragged key lengths.  (Round 2 also measured a deferred-rescale variant -- keep the old maximum unless a tile
+    exceeds it by 2^10 -- against this test: same results, 0.376-0.395 vs 0.387-0.400 ms per layer, i.e. noise; not adopted.)"""
+    from speechclip_amd import ops
+    B, T, H = 2, 500, 2
+    g = _g(31)
+    qkv = (torch.randn(B * T, 3 * H * 64, generator=g) * 0.6)
+    q = qkv[:, :H * 64].view(B, T, H, 64)
+    k = qkv[:, H * 64:2 * H * 64].view(B, T, H, 64)
+    k[0, :, 0, :] *= torch.linspace(0.5, 3.0, T).view(T, 1)          # head 0 of utterance 0: key norms (hence score maxima) grow along the sequence
+    q[0, :, 0, :] *= 1.5
+    k[1, 400, 1, :] = 6.0
+    q[1, 7, 1, :] = 6.0                                                 # one query / key pair with a score of 288: a jump beyond any threshold
+    lens = torch.tensor([500, 431], dtype=torch.int32)
+    qkv = qkv.to("cuda", BF)
+    y = ops.attention(qkv, B, T, H, lens.cuda())
+    ref = _attn_ref(qkv, B, T, H, lens.cuda())
+    valid = torch.cat([torch.arange(T) < n for n in lens.tolist()])
+    torch.testing.assert_close(y.float()[valid.cuda()], ref[valid.cuda()], atol=2e-2, rtol=2e-2)
