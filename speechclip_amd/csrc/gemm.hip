@@ -519,7 +519,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     dst[jp] = (m >= m_lo && n >= n_lo) ? *(const uint4*)((const bf16_t*)p.residual + m * p.ldr + n) : make_uint4(0, 0, 0, 0);
                 }
             };
-            uint4 res[3][2];
+            // Residual rows: a ring of row blocks loaded ahead of their use.  Plain residual variant with the interleaved prologue (emode 2): FOUR
+            // blocks ahead, the first four issued before the first prologue DMA piece -- vmcnt retires in order, so a residual load issued BEHIND
+            // DMA pieces can only be waited for together with them; four row blocks (8 pieces) later those pieces have long landed.  With two ahead
+            // the wait sat right behind fresh pieces, which is why this variant used to issue the whole prologue after the epilogue (emode 3),
+            // exposing its latency at the next tile's start.  (All eight up front does not fit: 128 accumulators + 64 residual registers spill.)
+            constexpr int NRES = (RES && EPI == 0) ? 4 : 3;
+            const int rahead = (NRES == 4 && emode == 2) ? 4 : 2;
+            uint4 res[NRES][2];
             float2 rstat[3];
             float psum = 0.f, psq = 0.f;
             f32x4_t rg[2][2], rb[2][2];      // EPI 2: gamma / beta of the residual's LayerNorm for this lane's 2 x 8 columns
@@ -536,11 +543,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 }
                 rstat[0] = load_rstat(0); rstat[1] = load_rstat(1);
             }
-            if (RES) { load_res(0, res[0]); load_res(1, res[1]); }
+            if (RES) {
+                load_res(0, res[0]); load_res(1, res[1]);
+                if (NRES == 4 && rahead == 4) { load_res(2, res[2]); load_res(3, res[3]); }
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int64_t m = mrow0 + i * 16;
-                if (RES && i + 2 < 8) { load_res(i + 2, res[(i + 2) % 3]); if (EPI == 2) rstat[(i + 2) % 3] = load_rstat(i + 2); }
+                if (RES && rahead == 2 && i + 2 < 8) { load_res(i + 2, res[(i + 2) % NRES]); if (EPI == 2) rstat[(i + 2) % 3] = load_rstat(i + 2); }
                 uint2 pk[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -569,7 +579,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     const int n = ncol0 + jp * 32;
                     if (m >= m_lo && n >= n_lo) {
                         if (RES && EPI != 2) {
-                            const uint4 rv = res[i % 3][jp];
+                            const uint4 rv = res[i % NRES][jp];
                             o.x = pack2bf(lo2f(o.x) + lo2f(rv.x), hi2f(o.x) + hi2f(rv.x));
                             o.y = pack2bf(lo2f(o.y) + lo2f(rv.y), hi2f(o.y) + hi2f(rv.y));
                             o.z = pack2bf(lo2f(o.z) + lo2f(rv.z), hi2f(o.z) + hi2f(rv.z));
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                         if (EPI == 2) {
                             // residual x = LN(y) rebuilt from the pre-norm row y: x_k = y_k (rstd g_k) + (b_k - mean rstd g_k); the LayerNorm output is
                             // rounded to bf16 exactly where the separate kernel rounds it, so both paths add the same residual
-                            const uint4 rv = res[i % 3][jp];
+                            const uint4 rv = res[i % NRES][jp];
                             const float mean = rstat[i % 3].x, rstd = rstat[i % 3].y;
                             const f32x4_t g0 = rg[jp][0] * rstd, g1 = rg[jp][1] * rstd;
                             const f32x4_t b0 = rb[jp][0] - g0 * mean, b1 = rb[jp][1] - g1 * mean;
@@ -600,6 +610,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                         else asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
                     }
                 }
+                if (RES && NRES == 4 && rahead == 4 && i + 4 < 8) load_res(i + 4, res[i % NRES]);      // slot i was consumed just above
                 if (EPI == 2) {
                     // this lane summed 16 of the row's 64 columns in this wave's strip: the other 48 sit in the 3 neighbouring lanes of the quad
                     psum += __shfl_xor(psum, 1, 64); psq += __shfl_xor(psq, 1, 64);
@@ -701,7 +712,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             tail_ops = 0;
             if (k_counted_wait && nhave) {
                 tail_ops = nk > 1 ? 8 : 0;
-                if (emode == 2 && vec_ok && full_tile_now && nk > 1) tail_ops += RES ? 12 : 8;
+                // row blocks 4..7 of an interleaved epilogue: 8 stores; the 2-ahead residual ring (EPI 2) also loads blocks 6, 7 there (4 loads),
+                // the 4-ahead ring of the plain residual variant has issued everything by row block 3
+                if (emode == 2 && vec_ok && full_tile_now && nk > 1) tail_ops += (RES && EPI != 0) ? 12 : 8;
             }
         }
         have = nhave;
