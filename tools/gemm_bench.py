@@ -20,20 +20,20 @@ def main():
     for name, M, N, K, lda, act, *rest in SHAPES:
         if only and name not in only:
             continue
-        res = (torch.randn(M, N, device="cuda")).to(torch.bfloat16) if rest and rest[0] else None
+        resid = (torch.randn(M, N, device="cuda")).to(torch.bfloat16) if rest and rest[0] else None
         lda_ = lda or K
         a = (torch.randn(M * lda_ + K + 64, device="cuda") * 0.5).to(torch.bfloat16)
         w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
         bias = torch.randn(N, device="cuda")
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         for _ in range(2):
-            ops.gemm(a, w, bias, act, res, out=out, M=M, K=K, lda=lda_)
+            ops.gemm(a, w, bias, act, resid, out=out, M=M, K=K, lda=lda_)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
         e0.record()
         for _ in range(reps):
-            ops.gemm(a, w, bias, act, res, out=out, M=M, K=K, lda=lda_)
+            ops.gemm(a, w, bias, act, resid, out=out, M=M, K=K, lda=lda_)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
