@@ -214,13 +214,14 @@ __device__ __forceinline__ void stage256(const StageAddr& sa, int lane_a, int la
     for (int i = 0; i < 4; ++i) glds16(sa.tw + (i * ldw64 + k0) + lane_w, slot + 256 * 128 + (i * 512 + wave * 64) * 16);
 }
 
-// RING3: the A operand gets a THREE-slot ring, W keeps two (3 x 32 KiB + 2 x 32 KiB = all 160 KiB of LDS), which lets the refill of a stage
-// be spread over BOTH half-steps of a k-step instead of being packed into the second one: with the two-slot [A|W] ring a slot is free only
-// after the mid-step barrier, so its 8 pieces per wave are issued during half of the time -- 64 KiB per half k-step = the CU's whole L2 -> LDS
-// path for that half, nothing in the other.  Here the A pieces of stage kt+2 go out during the FIRST half of k-step kt (their slot held stage
-// kt-1, free since the previous barrier) and the W pieces during the second half: 4 pieces per wave per half-step, and the mid-step wait is
-// `vmcnt(4)` (in-order retirement: everything but the A pieces just issued).  (Round 2 also measured the other use of the third slot -- A
-// prefetched a full k-step deeper, all 8 pieces still in the second half: neutral to -6 %: the loop is not latency-bound.)
+// RING3 (default): the A operand gets a THREE-slot ring, W keeps two (3 x 32 KiB + 2 x 32 KiB = all 160 KiB of LDS), which lets the refill of a
+// stage be spread over the WHOLE k-step instead of being packed into its second half: with the two-slot [A|W] ring a slot is free only after the
+// mid-step barrier, so its 8 pieces per wave go out during half of the time -- 64 KiB per half k-step = the CU's whole L2 -> LDS path for that
+// half, nothing in the other.  Here the A pieces of stage kt+2 go out during the FIRST half of k-step kt (their slot held stage kt-1, free since
+// the previous barrier) and the W pieces during the second half, one piece every other MFMA group, and the mid-step wait is `vmcnt(4)` (in-order
+// retirement: everything but the A pieces just issued).  Round 2, same box: whole step 46.1-46.3 ms vs 47.5 with the two-slot ring (GEMM 953-955
+// vs 919-921 TF/s in the step; QKV +4-6 % isolated).  What did NOT help with the third slot: prefetching A a k-step deeper with all 8 pieces still
+// in the second half (-6 ... +1 %: the loop is not latency-bound), and 4 + 4 pieces in two bursts (groups 4..7 of each half: -5 ... 0 %).
 // EPI: 0 plain; 1 the A operand is a pre-LayerNorm tensor (LN folded: W pre-scaled by gamma, per-row (mean, rstd) applied to the accumulator);
 // 2 the residual operand is a pre-LayerNorm tensor (reconstructed per element from its row statistics) and the per-row partial statistics of
 // the output are emitted for the NEXT LayerNorm.  bf16 vector path only (the dispatcher checks the shape rules).
@@ -416,9 +417,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                             const int dk = (ABL == 7) ? 0 : dma_k0;   // ABL 7 (timing probe, garbage results): the in-loop DMA always re-reads k-chunk 0 = cache hits
                             if (i < 4) piece_a(i, dk, dma_slot + (i * 512 + wave * 64) * 16);
                             else piece_w(i - 4, dk, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
-                        } else if (i >= 4) {   // one piece per MFMA group in groups 4..7 (they carry one fragment read, groups 0..3 two): W or A of a stage
-                            if (dma_k0 >= 0) piece_w(i - 4, dma_k0, dma_slot + ((i - 4) * 512 + wave * 64) * 16);
-                            else if (dma_ka0 >= 0) piece_a(i - 4, dma_ka0, dma_aslot + ((i - 4) * 512 + wave * 64) * 16);
+                        } else {
+#ifndef SC_GEMM_RING3_LATE     // one piece every other MFMA group (1, 3, 5, 7): the 8 pieces of a k-step spread evenly over its 16 groups
+#ifndef SC_GEMM_RING3_PHASE
+#define SC_GEMM_RING3_PHASE 0
+#endif
+                            const bool slot_ = (i & 1) == SC_GEMM_RING3_PHASE; const int g_ = i >> 1;
+#else                          // (measured alternative: groups 4..7 of each half-step -- two bursts per k-step: -5 ... 0 %)
+                            const bool slot_ = i >= 4; const int g_ = i - 4;
+#endif
+                            if (slot_) {
+                                if (dma_k0 >= 0) piece_w(g_, dma_k0, dma_slot + (g_ * 512 + wave * 64) * 16);
+                                else if (dma_ka0 >= 0) piece_a(g_, dma_ka0, dma_aslot + (g_ * 512 + wave * 64) * 16);
+                            }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -773,13 +784,10 @@ int launch256(const GemmParams& p, hipStream_t s) {
     if (abl && abl[0] == '5') return launch256_var<5, false>(p, grid, s);
     if (abl && abl[0] == '6') return launch256_var<6, false>(p, grid, s);
     if (abl && abl[0] == '7') return launch256_var<7, false>(p, grid, s);
-#ifdef SC_GEMM_BUILD_RING3
-    // Experiment kept in the source, not in the default build (-DSC_GEMM_BUILD_RING3 + SC_GEMM_RING3=1): the three-slot A ring of
-    // gemm256_kernel.  Round 2 measured both uses of the third slot -- A prefetched one k-step deeper, and the refill spread evenly over both
-    // half-steps -- on every shape of the step: -6 ... +1 %, whole step 47.4 vs 47.5 ms.
-    static const bool ring3 = getenv("SC_GEMM_RING3") && atoi(getenv("SC_GEMM_RING3")) != 0;
+    // Default: the three-slot A ring with the refill spread over all 16 MFMA groups of a k-step (RING3 in gemm256_kernel).  SC_GEMM_RING3=0 selects
+    // the two-slot [A|W] ring (A/B; also what the folded-LayerNorm epilogue variants use).
+    static const bool ring3 = !(getenv("SC_GEMM_RING3") && atoi(getenv("SC_GEMM_RING3")) == 0);
     if (ring3) return launch256_var<0, false, true>(p, grid, s);
-#endif
     return launch256_var<0, false>(p, grid, s);
 }
 
