@@ -137,6 +137,18 @@ int sc_cls_attention_fwd(const void* cls_qkv, const void* kv_x, int64_t ld_kv, c
 int sc_attention_rows_fwd(const void* q, const void* k, const void* v, void* out, const uint8_t* key_padding_mask, int B, int H, int L,
                           int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, void* stream);
 
+/* Per-head attention probabilities of the same attention for the query rows [0, n_rows) of every (b, h): probs f32 [B, H, n_rows, L],
+ * softmax over the non-padding keys, exactly 0 at padding -- what torch.nn.MultiheadAttention returns with need_weights=True,
+ * average_attn_weights=False in MultiheadAttentionAndNorm.extract_attention_map (avssl/module/kw_modules/TransformerModels.py:130-135);
+ * n_rows = keyword_num is all KW_CascadedBranch.getAttentionMap keeps (avssl/model/kwClip.py:941-949), n_rows = L the full map. */
+int sc_attention_probs_fwd(const void* q, const void* k, float* probs, const uint8_t* key_padding_mask, int B, int H, int L, int head_dim,
+                           int n_rows, int64_t ld_qkv, float scale, void* stream);
+
+/* torch.topk(x, K, dim=-1) of f32 rows (row r at x + r*ld, V entries): vals f32 [rows, K] descending, idx i32 [rows, K]; ties go to the
+ * lowest index.  The K nearest sub-words of every keyword: getAttentionMap (avssl/model/kwClip.py:990) and the de-tokenisation of
+ * validation_epoch_end (:357-375, K = detokenized_K_neighbors). */
+int sc_topk_rows_f32(const float* x, int64_t ld, int64_t rows, int V, int K, float* vals, int32_t* idx, void* stream);
+
 /* Algebraic form of the same pooling attention (no K/V of the frames is formed): score_r(x) = x . u_r + beta_r with
  * u_r = scale * Wk_h^T Q_{q,h}, r = (q,h), R = NQ*H <= 8.  `scores` f32 [B*T, R] are the frame scores (one skinny sc_gemm_bf16 with
  * W = u, bias = beta), `cls_scores` f32 [NQ, R] those of the CLS tokens; the kernel soft-maxes over [CLS tokens ; frames t < lens[b]]

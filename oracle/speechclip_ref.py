@@ -87,7 +87,7 @@ def mutual_retrieval(score_a: torch.Tensor, score_b: torch.Tensor, ab_answers: t
 
 
 # ----------------------------------------------------------------------------- attention helpers [3P torch.nn]
-def _mha_packed(x, in_w, in_b, out_w, out_b, heads, key_padding_mask=None, attn_mask=None):
+def _mha_packed(x, in_w, in_b, out_w, out_b, heads, key_padding_mask=None, attn_mask=None, return_probs=False):
     """torch nn.MultiheadAttention arithmetic (packed in_proj, scale head_dim^-0.5).  x: [B, L, D]."""
     B, L, D = x.shape
     hd = D // heads
@@ -98,8 +98,10 @@ def _mha_packed(x, in_w, in_b, out_w, out_b, heads, key_padding_mask=None, attn_
         s = s + attn_mask
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
-    o = torch.softmax(s, dim=-1) @ v
-    return F.linear(o.transpose(1, 2).reshape(B, L, D), out_w, out_b)
+    p = torch.softmax(s, dim=-1)
+    o = p @ v
+    y = F.linear(o.transpose(1, 2).reshape(B, L, D), out_w, out_b)
+    return (y, p) if return_probs else y
 
 
 def post_ln_encoder_layer(x, layer: nn.TransformerEncoderLayer, key_padding_mask):
@@ -161,6 +163,13 @@ class _MHAAndNorm(nn.Module):
         y = _mha_packed(src, m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads,
                         key_padding_mask)
         return self.attentionBlock_Norm(y + src)
+
+    def extract_attention_map(self, src, key_padding_mask):
+        """TransformerModels.py:130-135: need_weights=True, average_attn_weights=False -> per-head probabilities [B, H, L, L]."""
+        m = self.multihead_attn_layer
+        y, p = _mha_packed(src, m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads,
+                           key_padding_mask, return_probs=True)
+        return self.attentionBlock_Norm(y + src), p
 
 
 class _KwBatchNorm(nn.Module):
@@ -250,6 +259,61 @@ class CascadedBranchRef(nn.Module):
         keywords = vq["subword_prob"] @ emb                                       # :909
         feat = encode_keywords(self._clip, keywords, K, self.sot, self.eot)       # :912
         return feat, vq, keywords
+
+
+def get_attention_map(branch: "CascadedBranchRef", audio_feat, audio_len, decoder=None, reduced_to_original=None, topk: int = 10):
+    """KW_CascadedBranch.getAttentionMap (avssl/model/kwClip.py:918-1001): per-utterance keyword-row attention maps
+    [H, K, len_i + K] and the `topk` nearest sub-words of every keyword (special ids 0 / 2 / 3 pushed down by 100, :977-979).
+    Returns (cls_weights, topk_kw strings or None when no decoder is given, topk ids [B, K, topk], cos scores)."""
+    B, T, D = audio_feat.shape
+    K = branch.keyword_num
+    src = torch.cat([branch.cls.expand(B, -1, -1), audio_feat], dim=1)
+    mask = keypadding_mask(T + K, audio_len + K)
+    _, w = branch.self_att.extract_attention_map(src, mask)
+    cls_weights = [w[i, :, :K, : int(audio_len[i]) + K] for i in range(B)]
+    kw = branch.bn_layer(branch.linear_proj(branch.self_att(src, mask)[:, :K]))
+    emb = branch._clip.token_embedding.weight
+    cos = F.cosine_similarity(kw[:, :, None, :], emb[None, None, :, :], dim=-1).clone()
+    cos[..., 0] -= 100
+    cos[..., 2] -= 100
+    cos[..., 3] -= 100
+    ids = torch.topk(cos, dim=-1, k=topk)[1]
+    names = None
+    if decoder is not None:
+        o = (lambda i: reduced_to_original[i]) if reduced_to_original is not None else (lambda i: i)
+        names = [[[decoder[o(x.item())].replace("</w>", "") for x in ids[b, k]] for k in range(K)] for b in range(B)]
+    return cls_weights, names, ids, cos
+
+
+def detokenize_keywords(keywords, gold_token_sets, token_embedding, K: int = 10, method: str = "cosine", reduced_to_original=None,
+                        chunk: int = 8):
+    """The numerical half of KWClipBase.validation_epoch_end's keyword de-tokenisation (avssl/model/kwClip.py:332-420): keywords
+    [N, Kw, D], gold_token_sets = one set of ORIGINAL token ids per utterance.  Returns (hit_rate % [Kw], values [N, Kw, K],
+    indices [N, Kw, K] into `token_embedding`, first hit token per keyword lists)."""
+    N, Kw, D = keywords.shape
+    emb = token_embedding.detach().float()
+    pinv = torch.linalg.pinv(emb.T).float() if method == "pseudo_inverse" else None
+    o = (lambda i: reduced_to_original[i]) if reduced_to_original is not None else (lambda i: i)
+    hit = [0] * Kw
+    first_hits = [[] for _ in range(Kw)]
+    vals, idxs = [], []
+    for i in range(0, N, chunk):
+        flat = keywords[i:i + chunk].reshape(-1, D).float()
+        if pinv is not None:
+            score = (pinv @ flat.permute(1, 0)).permute(1, 0)                                              # :362-371
+        else:
+            score = F.cosine_similarity(flat.view(-1, D, 1), emb.transpose(0, 1).unsqueeze(0), dim=1)     # :372-379
+        v, ix = torch.topk(score, K)
+        v, ix = v.view(-1, Kw, K), ix.view(-1, Kw, K)
+        vals.append(v)
+        idxs.append(ix)
+        for x in range(v.shape[0]):
+            for k in range(Kw):
+                common = set(o(t.item()) for t in ix[x, k]) & gold_token_sets[i + x]
+                if common:
+                    hit[k] += 1
+                    first_hits[k].append(int(list(common)[0]))
+    return torch.tensor(hit, dtype=torch.float32) / N * 100, torch.cat(vals), torch.cat(idxs), first_hits
 
 
 # ----------------------------------------------------------------------------- full model

@@ -10,6 +10,7 @@ Multi-GPU: the reference runs single-process `nn.DataParallel` and computes the 
 feature dicts over RCCL (speechclip_amd/parallel.py) in rank-major order (= DP's dim-0 concat order) and every rank
 evaluates the loss on the global batch.
 """
+import json
 import logging
 import os
 from typing import List, Tuple, Union
@@ -126,8 +127,83 @@ class KWClipBase(BaseLightningModel):
                 others[k] = others[k].detach().cpu()
         return others
 
+    def detokenize_keywords(self, outputs: list):
+        """Keyword de-tokenisation of validation_epoch_end (kwClip.py:277-466): the K nearest sub-words of every keyword embedding (cosine,
+        or the pseudo-inverse read-out), the per-keyword hit rate against the gold caption's sub-word set, and the two JSON logs under
+        <default_root_dir>/detokenizeText/.  The reference runs the [N*K, V] similarity + top-K on the CPU in dev-batch chunks; here they run
+        on the device (sc_cosine_scores fp32 / sc_sgemm + sc_topk_rows_f32), the set logic stays on the host, chunking and output format
+        unchanged.  Returns (hit_rate [keyword_num] in %, kw_top_ret, all_retok_outputs) -- the reference returns nothing and only logs."""
+        root = os.path.join(self.config.trainer.default_root_dir, "detokenizeText")
+        os.makedirs(root, exist_ok=True)
+        epoch = int(getattr(self, "current_epoch", 0) or 0)
+        if hasattr(self, "log_detokenize_results_every_n_epoch") and epoch % self.log_detokenize_results_every_n_epoch != 0:
+            return None
+        tok = self.clip.tokenizer
+        gold_texts = [tok.decode(sent.squeeze().tolist()) for x in outputs for sent in x["gold_text"]]
+        kw = torch.cat([x["keywords"] for x in outputs], dim=0)
+        kw = kw.view(kw.shape[0], self.keyword_num, kw.shape[-1])
+        assert kw.dim() == 3 and kw.shape[2] == self.subword_embd_dim, kw.shape
+        emb = self.clip.model.token_embedding.weight.detach()
+        kwcfg = self.config.model_settings.cascaded_branch.keyword
+        K = kwcfg.get("detokenized_K_neighbors", 10)
+        if not hasattr(kwcfg, "retrieve_method"):
+            kwcfg.retrieve_method = "cosine"
+        assert kwcfg.retrieve_method in ["cosine", "pseudo_inverse"]
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("detokenize_keywords runs its similarity / top-K kernels on the GPU; move the model to cuda")
+        emb_dev = emb.to(dev).float().contiguous()
+        if kwcfg.retrieve_method == "pseudo_inverse":
+            emb_pinv = torch.linalg.pinv(emb.detach().cpu().float().T).float().to(dev).contiguous()      # [V, D]
+        reduced = self.clip.selected_text_emb_ids is not None
+        orig = (lambda i: self.clip.reducedl2Original[i]) if reduced else (lambda i: i)
+        hit_rate = [0] * self.keyword_num
+        kw_top_ret = [[] for _ in range(self.keyword_num)]
+        all_retok_outputs = []
+        bs = self.config.data.dev_batch_size
+        print("Detokenizing K={}".format(K))
+        for i in range(0, len(gold_texts) + bs, bs):
+            _gold_texts = gold_texts[i:i + bs]
+            _bsz = len(_gold_texts)
+            if _bsz == 0:
+                break
+            gold_sets = [set(tok.encode(_text)) for _text in _gold_texts]
+            flat = kw[i:i + _bsz].reshape(-1, self.subword_embd_dim).float().to(dev).contiguous()
+            if kwcfg.retrieve_method == "pseudo_inverse":
+                score = ops.sgemm(flat, emb_pinv, transb=True)                     # (pinv @ kw^T)^T, kwClip.py:362-371
+            else:
+                score = ops.cosine_scores(flat, emb_dev, exact=True)               # F.cosine_similarity, fp32 (:372-379)
+            k_values, k_indices = ops.topk_rows(score, K)
+            k_values = k_values.view(_bsz, self.keyword_num, K).cpu()
+            k_indices = k_indices.view(_bsz, self.keyword_num, K).cpu()
+            for x in range(_bsz):
+                tmp_outputs = {}
+                for kw_i in range(self.keyword_num):
+                    name = "keyword_{}".format(kw_i)
+                    tmp_outputs[name] = []
+                    top_k_toks = set(orig(_ind.item()) for _ind in k_indices[x, kw_i])
+                    common = top_k_toks & gold_sets[x]
+                    if bool(common):
+                        hit_rate[kw_i] += 1
+                        kw_top_ret[kw_i].append(int(list(common)[0]))
+                    for _ind, _dist in zip(k_indices[x, kw_i], k_values[x, kw_i]):
+                        tmp_outputs[name].append([tok.decoder[orig(_ind.item())], _dist.item()])
+                # "gold" is the chunk's FIRST caption for every row of the chunk, as in the reference (kwClip.py:428 indexes with i)
+                all_retok_outputs.append({"gold": gold_texts[i], "neighbors": tmp_outputs})
+        hit_rate = torch.FloatTensor(hit_rate) / len(gold_texts) * 100
+        print("kw_hit_rate", hit_rate)
+        if getattr(self, "logger", None) is not None:
+            self.log("kw_hit_rate", {"kw_{}".format(i): hit_rate[i].item() for i in range(self.keyword_num)}, sync_dist=True)
+        with open(os.path.join(root, "kw_hit_ep{}.json".format(epoch)), "w") as f:
+            json.dump(kw_top_ret, f)
+        with open(os.path.join(root, "keywords_ep{}.json".format(epoch)), "w") as f:
+            json.dump(all_retok_outputs, f)
+        return hit_rate, kw_top_ret, all_retok_outputs
+
     def validation_epoch_end(self, outputs: list):
-        """Retrieval half of kwClip.py:468-502 (keyword de-tokenisation logging :277-466 is analysis-only, out of scope)."""
+        """kwClip.py:270-502: keyword de-tokenisation logging when the step outputs carry keywords (:277-466), then retrieval (:468-502)."""
+        if "keywords" in outputs[0].keys():
+            self.last_kw_hit_rate = self.detokenize_keywords(outputs)
         all_ids = torch.cat([x["id"] for x in outputs], dim=0)
         all_imgs = torch.cat([x["image_feat"] for x in outputs], dim=0)
         first = {}
@@ -279,6 +355,40 @@ class KW_CascadedBranch(nn.Module):
     def extract_hidden_states(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> tuple:
         """kwClip.py:828-856."""
         return _branch_hidden_states(self, audio_feat, audio_len, self.keyword_num)
+
+    @torch.no_grad()
+    def getAttentionMap(self, audio_feat: torch.Tensor, audio_len: torch.Tensor):
+        """kwClip.py:918-1001: (cls_weights, topk_kw, None) for visualisation.  cls_weights[i] = the per-head attention probabilities of the
+        keyword rows of utterance i over its valid positions, fp32 [H, K, len_i + K]; topk_kw[i][k] = the 10 nearest sub-words (special
+        tokens 0 / 2 / 3 pushed down by 100, :977-979) of keyword k as printed by the tokenizer's decoder.  Eval-mode arithmetic."""
+        bsz, K = audio_feat.size(0), self.keyword_num
+        total_max_len = audio_feat.size(1) + K
+        dev = audio_feat.device
+        src = torch.cat([self.cls.detach().to(dev, torch.float32).expand(bsz, -1, -1), audio_feat.detach().float()], dim=1)
+        audio_len = torch.as_tensor(audio_len).to(dev)
+        key_padding_mask = get_keypadding_mask(max_length=total_max_len, data_lens=audio_len + K).to(dev)
+        out, attn = self.self_att.extract_attention_map(src=src, key_padding_mask=key_padding_mask, query_rows=K)
+        lens = audio_len.tolist()
+        cls_weights = [attn[i, :, :K, :lens[i] + K] for i in range(bsz)]
+        keywords = out[:, :K].reshape(bsz * K, self.audio_dim)
+        keywords = ops.gemm(keywords.to(torch.bfloat16), TransformerModels.cached_cast(self.linear_proj.weight, torch.bfloat16),
+                            TransformerModels.cached_cast(self.linear_proj.bias, torch.float32), out_f32=True).view(bsz, K, self.text_dim)
+        if hasattr(self, "bn_layer"):
+            was_training = self.bn_layer.training
+            self.bn_layer.eval()
+            keywords = self.bn_layer(keywords)
+            self.bn_layer.train(was_training)
+        emb = self.clip.model.token_embedding.weight
+        cos = ops.cosine_scores(keywords.reshape(bsz * K, self.text_dim), emb, exact=True).view(bsz, K, emb.shape[0])
+        cos[..., 0] -= 100
+        cos[..., 2] -= 100
+        cos[..., 3] -= 100
+        _, topk_ids = ops.topk_rows(cos, 10)
+        topk_ids = topk_ids.cpu()
+        dec = self.clip.tokenizer.decoder
+        orig = (lambda i: self.clip.reducedl2Original[i]) if self.clip.selected_text_emb_ids is not None else (lambda i: i)
+        topk_kw = [[[dec[orig(x.item())].replace("</w>", "") for x in topk_ids[b, k]] for k in range(K)] for b in range(bsz)]
+        return cls_weights, topk_kw, None
 
     def forward(self, audio_feat: torch.Tensor, audio_len: torch.Tensor):
         if self.training and torch.is_grad_enabled() and self.cls.requires_grad:

@@ -19,11 +19,29 @@ _clip_models = {"RN50", "RN101", "RN50x4", "RN50x16", "RN50x64", "ViT-B/32", "Vi
 SOT_ID, EOT_ID = 49406, 49407
 
 
+class _IdDecoder(dict):
+    """decoder[i] of the id-literal tokenizer: "<i></w>" for every id."""
+
+    def __missing__(self, i):
+        return "<{}></w>".format(int(i))
+
+
 class _TokenizerIds:
-    """The two ids of openai's SimpleTokenizer that the hot path needs (clip_official.py:95-101,235-240)."""
+    """Stand-in for openai's SimpleTokenizer (clip/simple_tokenizer.py [3P], not installed and its BPE vocabulary file is not
+    available offline).  The hot path needs two ids (clip_official.py:95-101,235-240); the analysis surface (kwClip.py:277-466,
+    :918-1001) needs `decoder[id]`, `decode(ids)` and `encode(text)`.  Without the vocabulary, sub-word i prints as the literal "<i>":
+    decode / encode are exact inverses of each other on id lists, so hit rates and neighbour lists are computed on the true token ids and
+    only their printed form differs.  Assign a real SimpleTokenizer-compatible object to `ClipModel.tokenizer` to get words."""
 
     def __init__(self, vocab_size=49408):
         self.encoder = {"<|startoftext|>": vocab_size - 2, "<|endoftext|>": vocab_size - 1}
+        self.decoder = _IdDecoder()
+
+    def decode(self, tokens) -> str:
+        return "".join(self.decoder[t] for t in tokens).replace("</w>", " ")
+
+    def encode(self, text: str) -> list:
+        return [int(w[1:-1]) for w in text.split() if w.startswith("<") and w.endswith(">") and w[1:-1].isdigit()]
 
 
 class ClipModel(nn.Module):

@@ -205,3 +205,20 @@ class MultiheadAttentionAndNorm(nn.Module):
     def extract_hidden_states(self, src: torch.Tensor, key_padding_mask: torch.Tensor = None):
         """TransformerModels.py:127-128."""
         return tuple([src, self.forward(src, key_padding_mask)])
+
+    @torch.no_grad()
+    def extract_attention_map(self, src: torch.Tensor, key_padding_mask: torch.Tensor = None, query_rows: int = None):
+        """TransformerModels.py:130-135: (LN(MHA(src) + src) fp32 [B, L, D], per-head attention probabilities fp32 [B, H, L, L]) -- torch's
+        need_weights=True, average_attn_weights=False.  `query_rows=n` (an extension; the reference has no such argument) keeps the first n
+        query rows of the map only: [B, H, n, L], which is all getAttentionMap reads (kwClip.py:941-949)."""
+        m = self.multihead_attn_layer
+        B, Lq, D = src.shape
+        x = src.detach().float().contiguous().view(B * Lq, D)
+        qkv = ops.gemm(x.to(BF), cached_cast(m.in_proj_weight, BF), cached_cast(m.in_proj_bias, torch.float32))
+        hd = D // self.nhead
+        att = ops.attention_rows(qkv, B, Lq, self.nhead, hd, key_padding_mask)
+        probs = ops.attention_probs(qkv, B, Lq, self.nhead, hd, key_padding_mask, n_rows=query_rows)
+        y = ops.gemm(att, cached_cast(m.out_proj.weight, BF), cached_cast(m.out_proj.bias, torch.float32), residual=x, out_f32=True)
+        n = self.attentionBlock_Norm
+        out = ops.layernorm(y, cached_cast(n.weight, torch.float32), cached_cast(n.bias, torch.float32), self.eps, out_f32=True).view(B, Lq, D)
+        return out, probs

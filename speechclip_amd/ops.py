@@ -250,6 +250,34 @@ def attention_rows(qkv, B, L, H, hd, key_padding_mask=None, scale=None):
     return out
 
 
+def attention_probs(qkv, B, L, H, hd, key_padding_mask=None, n_rows=None, scale=None):
+    """Per-head attention probabilities (need_weights=True, average_attn_weights=False) of the first `n_rows` query rows (default: all):
+    qkv bf16 [B*L, 3*H*hd] packed (q|k|v) -> f32 [B, H, n_rows, L]; exactly 0 at padded keys."""
+    _need_cuda(qkv, key_padding_mask)
+    D = H * hd
+    assert qkv.dtype == bf16 and qkv.shape == (B * L, 3 * D) and qkv.is_contiguous()
+    n_rows = L if n_rows is None else int(n_rows)
+    m = None
+    if key_padding_mask is not None:
+        assert key_padding_mask.shape == (B, L)
+        m = key_padding_mask.to(torch.uint8).contiguous()
+    probs = torch.empty(B, H, n_rows, L, device=qkv.device, dtype=torch.float32)
+    check(lib().sc_attention_probs_fwd(qkv.data_ptr(), qkv.data_ptr() + D * 2, ptr(probs), ptr(m), B, H, L, hd, n_rows, 3 * D,
+                                       hd ** -0.5 if scale is None else scale, stream()), "sc_attention_probs_fwd")
+    return probs
+
+
+def topk_rows(x, k):
+    """torch.topk(x, k, dim=-1) for f32 [..., V] on the device: (values f32 [..., k] descending, indices i64 [..., k]); ties -> lowest index."""
+    _need_cuda(x)
+    x2 = x.float().contiguous().view(-1, x.shape[-1])
+    R, V = x2.shape
+    vals = torch.empty(R, k, device=x.device, dtype=torch.float32)
+    idx = torch.empty(R, k, device=x.device, dtype=torch.int32)
+    check(lib().sc_topk_rows_f32(ptr(x2), V, R, V, int(k), ptr(vals), ptr(idx), stream()), "sc_topk_rows_f32")
+    return vals.view(*x.shape[:-1], k), idx.long().view(*x.shape[:-1], k)
+
+
 def cls_attention(cls_qkv, kv_x, lens_i32, B, T, NQ, H, hd):
     """cls_qkv bf16 [NQ, 3D]; kv_x bf16 [B*T, 2D]; returns bf16 [B, NQ, D]."""
     _need_cuda(cls_qkv, kv_x)

@@ -70,9 +70,23 @@ def install_stubs():
     _mod("pytorch_lightning.loggers.wandb", WandbLogger=_Dummy)
     pl.loggers = sys.modules["pytorch_lightning.loggers"]
 
+    class _IdDecoder(dict):
+        def __missing__(self, i):
+            return "<{}></w>".format(int(i))
+
     class SimpleTokenizer:
+        """id-literal stand-in for openai's tokenizer (its BPE vocabulary is not available offline): sub-word i prints as "<i>"; decode /
+        encode have the real tokenizer's call signatures and are inverses of each other on id lists."""
+
         def __init__(self):
             self.encoder = {"<|startoftext|>": 49406, "<|endoftext|>": 49407}
+            self.decoder = _IdDecoder()
+
+        def decode(self, tokens):
+            return "".join(self.decoder[t] for t in tokens).replace("</w>", " ")
+
+        def encode(self, text):
+            return [int(w[1:-1]) for w in text.split()]
 
     def clip_load(name, device="cpu"):
         torch.manual_seed(1234)
@@ -317,8 +331,59 @@ def plant_decisive_keywords(model, batch, gen):
     return (top2[:, 0] - top2[:, 1]).min().item()
 
 
+def gen_analysis(model, batch, feat, feat_len, others, tag):
+    """Analysis surface of the cascaded model, from the reference's own code: KW_CascadedBranch.getAttentionMap (kwClip.py:918-1001) and the
+    keyword de-tokenisation of KWClipBase.validation_epoch_end (:277-466) -> tests/golden/analysis_<tag>.npz."""
+    import json
+    import tempfile
+    cb, clip = model.cascaded_branch, model.clip
+    with torch.no_grad():
+        cls_weights, topk_kw, _ = cb.getAttentionMap(feat, feat_len)
+    B, K = feat.shape[0], cb.keyword_num
+    H = cls_weights[0].shape[0]
+    amap = np.zeros((B, H, K, feat.shape[1] + K), dtype=np.float32)
+    for i, w in enumerate(cls_weights):
+        assert w.shape == (H, K, int(feat_len[i]) + K)
+        amap[i, :, :, : w.shape[-1]] = w.numpy()
+    # gold captions: SOT, six sub-words, EOT, padding; every second utterance holds the 3rd-nearest neighbour of keyword (x mod K)
+    emb = clip.model.token_embedding.weight.detach()
+    kw = others["keywords"].view(B, K, -1)
+    nn_ids = torch.topk(torch.nn.functional.cosine_similarity(kw.reshape(-1, kw.shape[-1], 1), emb.T.unsqueeze(0), dim=1), 10)[1].view(B, K, 10)
+    g = torch.Generator().manual_seed(4242)
+    ids = np.array(clip.selected_text_emb_ids)
+    text = torch.zeros(B, 1, 77, dtype=torch.long)
+    for x in range(B):
+        words = ids[4:][torch.randperm(len(ids) - 4, generator=g)[:6].numpy()].tolist()
+        if x % 2 == 0:
+            words[2] = clip.reducedl2Original[int(nn_ids[x, x % K, 2])]
+        row = [clip.tokenizer.encoder["<|startoftext|>"]] + words + [clip.tokenizer.encoder["<|endoftext|>"]]
+        text[x, 0, : len(row)] = torch.tensor(row)
+    root = tempfile.mkdtemp()
+    model.config.trainer.default_root_dir = root
+    model.config.data.dev_batch_size = 3            # 4 utterances -> chunks of 3 + 1
+    if not hasattr(type(model), "current_epoch"):
+        type(model).current_epoch = 0
+    with torch.no_grad():
+        out = model.validation_step_end(model.validation_step(dict(batch, text=text), 0))
+        try:
+            model.validation_epoch_end([out])
+        except Exception as e:                      # the retrieval half after the keyword logging is covered by its own fixtures
+            print("validation_epoch_end after the keyword logs:", type(e).__name__, e)
+    kw_hit = json.load(open(os.path.join(root, "detokenizeText", "kw_hit_ep0.json")))
+    retok = json.load(open(os.path.join(root, "detokenizeText", "keywords_ep0.json")))
+    assert len(retok) == B and len(kw_hit) == K
+    nb_ids = np.array([[[int(t[0][1:-5]) for t in r["neighbors"]["keyword_%d" % k]] for k in range(K)] for r in retok])     # "<id></w>"
+    nb_val = np.array([[[t[1] for t in r["neighbors"]["keyword_%d" % k]] for k in range(K)] for r in retok], dtype=np.float64)
+    hits = np.array([len(h) for h in kw_hit])
+    print(f"analysis_{tag}: hits per keyword {hits.tolist()}, attention map {amap.shape}")
+    assert hits.sum() >= B // 2
+    save(f"analysis_{tag}.npz", text=text.numpy(), attn_map=amap, topk_kw=np.array(json.dumps(topk_kw)), kw_hit=np.array(json.dumps(kw_hit)),
+         retok=np.array(json.dumps(retok)), neighbor_ids=nb_ids, neighbor_vals=nb_val, hits_per_keyword=hits,
+         keywords=others["keywords"].numpy())
+
+
 def gen_end_to_end(kwclip_mod, OrderedNamespace, tag, hubert_cfg, clip_cfg, cascaded, parallel, lens, normalize_hiddenstates,
-                   reduce_vocab_ids=None, plant_margins=False):
+                   reduce_vocab_ids=None, plant_margins=False, analysis_only=False):
     STATE["hubert_cfg"], STATE["clip_cfg"] = hubert_cfg, clip_cfg
     vocab_path = None
     if reduce_vocab_ids is not None:
@@ -327,7 +392,13 @@ def gen_end_to_end(kwclip_mod, OrderedNamespace, tag, hubert_cfg, clip_cfg, casc
     # the reference tokenizer stub reports 49406/49407; map them to the tiny vocab's last two ids
     import clip.simple_tokenizer as st
     st_enc = {"<|startoftext|>": clip_cfg.vocab_size - 2, "<|endoftext|>": clip_cfg.vocab_size - 1}
-    st.SimpleTokenizer.__init__ = lambda self: setattr(self, "encoder", st_enc)
+    _plain_init = getattr(st.SimpleTokenizer, "_plain_init", None) or st.SimpleTokenizer.__init__
+    st.SimpleTokenizer._plain_init = _plain_init
+
+    def _tok_init(self):
+        _plain_init(self)
+        self.encoder = st_enc
+    st.SimpleTokenizer.__init__ = _tok_init
     d = hubert_cfg.encoder_embed_dim
     cfg = tiny_config(OrderedNamespace, f"{REF}/config/speechCLIP/model_base/spchclp_{'c' if cascaded else 'p'}.yaml",
                       d_model=d, cascaded=cascaded, parallel=parallel, branch_heads=4,
@@ -391,6 +462,29 @@ def gen_end_to_end(kwclip_mod, OrderedNamespace, tag, hubert_cfg, clip_cfg, casc
             assert int(others["vq_results"]["targets"].min()) >= 4 and int(others["vq_results"]["targets"].max()) < 4 + len(lens) * 8
     my_loss = sc.compute_loss(o, w_par=1.0 if parallel else 0.0, w_casc=1.0 if cascaded else 0.0)["loss"].item()
     assert abs(my_loss - loss["loss"].item()) < 1e-5
+    if cascaded:
+        gen_analysis(model, batch, feat, feat_len, others, tag)
+        # the oracle's restatement of the two analysis functions agrees with the reference on the same weights
+        ana = np.load(os.path.join(HERE, f"analysis_{tag}.npz"))
+        r2o = model.clip.reducedl2Original
+        cw, names, _, _ = speechclip_ref.get_attention_map(sc.cascaded_branch, feat, feat_len, decoder=model.clip.tokenizer.decoder,
+                                                          reduced_to_original=r2o)
+        for i, w in enumerate(cw):
+            assert torch.allclose(w, torch.from_numpy(ana["attn_map"][i, :, :, : w.shape[-1]]), atol=1e-6)
+        import json as _json
+        assert names == _json.loads(str(ana["topk_kw"]))
+        gold = [set(int(t) for t in row[0]) for row in ana["text"]]
+        hr, v, ix, fh = speechclip_ref.detokenize_keywords(torch.from_numpy(ana["keywords"]).view(len(lens), -1, ana["keywords"].shape[-1]),
+                                                          gold, model.clip.model.token_embedding.weight, K=ana["neighbor_ids"].shape[-1], reduced_to_original=r2o, chunk=3)
+        assert np.array_equal(np.array([r2o[int(t)] for t in ix.reshape(-1)]).reshape(ix.shape), ana["neighbor_ids"])
+        assert np.allclose(v.numpy(), ana["neighbor_vals"], atol=1e-6)
+        assert fh == _json.loads(str(ana["kw_hit"])), (fh, _json.loads(str(ana["kw_hit"])))
+    if analysis_only:
+        saved = np.load(os.path.join(HERE, f"e2e_{tag}.npz"))
+        for k, v in np_state(sd).items():           # same seeds -> the same weights the committed e2e fixture carries
+            if "sd/" + k in saved.files:
+                assert np.array_equal(saved["sd/" + k], v), k
+        return
     if parallel and not cascaded:
         # gradients of the trainable tail from the reference's own modules (eval mode: dropout off; HuBERT / CLIP frozen):
         # loss.backward() as Lightning would call it after training_step_end (kwClip.py:147-191)
@@ -503,6 +597,7 @@ def gen_feat_len_table(kwclip_mod, OrderedNamespace):
 
 
 def main():
+    only_analysis = "--only-analysis" in sys.argv
     install_stubs()
     import avssl.module.losses as losses_mod
     import avssl.module.retrieval as retrieval_mod
@@ -511,22 +606,25 @@ def main():
     from avssl.base import OrderedNamespace
     import avssl.model.kwClip as kwclip_mod
 
-    gen_loss(losses_mod)
-    gen_retrieval(retrieval_mod)
-    gen_small_ops(ws_mod, du_mod)
-    gen_feat_len_table(kwclip_mod, OrderedNamespace)
+    if not only_analysis:
+        gen_loss(losses_mod)
+        gen_retrieval(retrieval_mod)
+        gen_small_ops(ws_mod, du_mod)
+        gen_feat_len_table(kwclip_mod, OrderedNamespace)
     tiny_b = hubert_ref.HubertRefConfig.tiny()
     tiny_l = hubert_ref.HubertRefConfig.tiny(layer_norm_first=True, extractor_mode="layer_norm", conv_bias=True)
     tiny_clip = clip_ref.ClipRefConfig.tiny()
-    gen_end_to_end(kwclip_mod, OrderedNamespace, "tiny_base_p", tiny_b, tiny_clip, cascaded=False, parallel=True,
-                   lens=[8000, 5000, 6777, 1200], normalize_hiddenstates=False)
-    gen_end_to_end(kwclip_mod, OrderedNamespace, "tiny_large_p", tiny_l, tiny_clip, cascaded=False, parallel=True,
-                   lens=[6400, 8000, 3999], normalize_hiddenstates=True)
+    if not only_analysis:
+        gen_end_to_end(kwclip_mod, OrderedNamespace, "tiny_base_p", tiny_b, tiny_clip, cascaded=False, parallel=True,
+                       lens=[8000, 5000, 6777, 1200], normalize_hiddenstates=False)
+        gen_end_to_end(kwclip_mod, OrderedNamespace, "tiny_large_p", tiny_l, tiny_clip, cascaded=False, parallel=True,
+                       lens=[6400, 8000, 3999], normalize_hiddenstates=True)
     vocab = np.array([0, 320, 510, 511] + list(range(5, 300, 3)))
     gen_end_to_end(kwclip_mod, OrderedNamespace, "tiny_base_c", tiny_b, tiny_clip, cascaded=True, parallel=False,
-                   lens=[8000, 5000, 6777, 1200], normalize_hiddenstates=False, reduce_vocab_ids=vocab)
+                   lens=[8000, 5000, 6777, 1200], normalize_hiddenstates=False, reduce_vocab_ids=vocab, analysis_only=only_analysis)
     gen_end_to_end(kwclip_mod, OrderedNamespace, "tiny_base_c2", tiny_b, tiny_clip, cascaded=True, parallel=False,
-                   lens=[8000, 7600, 7777, 7100], normalize_hiddenstates=False, reduce_vocab_ids=vocab, plant_margins=True)
+                   lens=[8000, 7600, 7777, 7100], normalize_hiddenstates=False, reduce_vocab_ids=vocab, plant_margins=True,
+                   analysis_only=only_analysis)
 
 
 if __name__ == "__main__":

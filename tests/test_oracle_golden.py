@@ -104,3 +104,37 @@ def test_e2e_cascaded_golden(tag):
     np.testing.assert_allclose(o["cascaded_audio_feat"].numpy(), g["cascaded_audio_feat"], atol=1e-5)
     np.testing.assert_allclose(o["keywords"].numpy(), g["keywords"], atol=1e-6)
     assert abs(m.compute_loss(o, w_par=0.0, w_casc=1.0)["loss"].item() - float(g["loss"])) < 1e-5
+
+
+class _IdDecoder(dict):
+    def __missing__(self, i):
+        return "<{}></w>".format(int(i))
+
+
+@pytest.mark.parametrize("tag", ["tiny_base_c", "tiny_base_c2"])
+def test_cascaded_analysis_golden(tag):
+    """tests/golden/analysis_<tag>.npz: KW_CascadedBranch.getAttentionMap and the keyword de-tokenisation of validation_epoch_end run by the
+    reference's OWN code (make_golden.gen_analysis); the oracle's restatements reproduce both."""
+    import json
+    vocab = [0, 320, 510, 511] + list(range(5, 300, 3))
+    g, m, batch = _build(tag, HubertRefConfig.tiny(), cascaded=True, parallel=False, norm_hidden=False, vocab=torch.tensor(vocab))
+    a = _load(f"analysis_{tag}.npz")
+    r2o = {n: o for n, o in enumerate(vocab)}
+    feat, feat_len = torch.from_numpy(g["audio_feat"]), torch.from_numpy(g["feat_len"])
+    with torch.no_grad():
+        cw, names, ids, _ = R.get_attention_map(m.cascaded_branch, feat, feat_len, decoder=_IdDecoder(), reduced_to_original=r2o)
+    for i, w in enumerate(cw):
+        L = int(feat_len[i]) + 8
+        assert w.shape == (1, 8, L)
+        np.testing.assert_allclose(w.numpy(), a["attn_map"][i, :, :, :L], atol=1e-6)
+        assert np.all(a["attn_map"][i, :, :, L:] == 0)
+        np.testing.assert_allclose(w.sum(-1).numpy(), 1.0, atol=1e-5)
+    assert names == json.loads(str(a["topk_kw"]))
+    gold = [set(int(t) for t in row[0]) for row in a["text"]]
+    K = a["neighbor_ids"].shape[-1]
+    hr, v, ix, first_hits = R.detokenize_keywords(torch.from_numpy(a["keywords"]).view(4, 8, -1), gold, m.clip.token_embedding.weight, K=K,
+                                                  reduced_to_original=r2o, chunk=3)
+    assert np.array_equal(np.vectorize(r2o.get)(ix.numpy()), a["neighbor_ids"])
+    np.testing.assert_allclose(v.numpy(), a["neighbor_vals"], atol=1e-6)
+    assert first_hits == json.loads(str(a["kw_hit"]))
+    np.testing.assert_allclose(hr.numpy(), a["hits_per_keyword"] / 4 * 100)
