@@ -19,6 +19,7 @@ from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
 import math
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -200,9 +201,11 @@ class TransformerEncoderRef(nn.Module):
             x = self.layer_norm(x)                                     # :39-40
         x = x.transpose(0, 1)                                          # :45 B,T,C -> T,B,C
         layer_results = [x.transpose(0, 1)]                            # :47
-        for layer in self.layers:                                      # :49-53 (layerdrop off in eval)
-            x, _ = layer(x, self_attn_padding_mask=padding_mask, need_weights=False)
-            layer_results.append(x.transpose(0, 1))
+        for layer in self.layers:                                      # :49-53: one draw per layer in EVERY mode; skipped only when training
+            dropout_probability = np.random.random()
+            if not self.training or (dropout_probability > self.layerdrop):
+                x, _ = layer(x, self_attn_padding_mask=padding_mask, need_weights=False)
+                layer_results.append(x.transpose(0, 1))
         return x.transpose(0, 1), layer_results
 
 

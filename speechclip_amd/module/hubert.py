@@ -42,6 +42,8 @@ class HubertConfig:
     conv_pos: int = 128
     conv_pos_groups: int = 16
     normalize: bool = False              # fairseq task.cfg.normalize (per-utterance wave layer-norm)
+    encoder_layerdrop: float = 0.05      # the checkpoint's own rate [3P fairseq hubert_base_librispeech: 0.05, hubert_large_librivox: 0.0]; used
+                                         # only with audio_encoder.layer_drop: "original" (speech_encoder_plus.py:411-412)
 
     @staticmethod
     def from_name(name: str) -> "HubertConfig":
@@ -49,7 +51,8 @@ class HubertConfig:
             return HubertConfig()
         if name == "hubert_large_ll60k":
             return HubertConfig(extractor_mode="layer_norm", conv_bias=True, encoder_layers=24, encoder_embed_dim=1024,
-                                encoder_ffn_embed_dim=4096, encoder_attention_heads=16, layer_norm_first=True, normalize=True)
+                                encoder_ffn_embed_dim=4096, encoder_attention_heads=16, layer_norm_first=True, normalize=True,
+                                encoder_layerdrop=0.0)
         raise KeyError(name)
 
 
@@ -105,7 +108,7 @@ class _Encoder(nn.Module):
         self.pos_conv.add_module("0", pc)
         self.layers = nn.ModuleList([_EncLayer(cfg) for _ in range(cfg.encoder_layers)])
         self.layer_norm = nn.LayerNorm(d)
-        self.layerdrop = 0.0
+        self.layerdrop = cfg.encoder_layerdrop       # fairseq TransformerEncoder.layerdrop; FairseqSpeechEncoder_Hubert overrides it (layer_drop)
         self.layer_norm_first = cfg.layer_norm_first
 
 
@@ -264,10 +267,11 @@ class HubertModel(nn.Module):
         return d % 256 == 0 and B * Tp >= 256 and self.cfg.encoder_ffn_embed_dim >= 256
 
     @torch.no_grad()
-    def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int], fold_ln: bool = False, stop_layer: int = None):
+    def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int], fold_ln: bool = False, stop_layer: int = None, drop_layers=()):
         """wav: f32 [B, Lmax] device tensor (right zero-padded); lens: host ints.
         Returns (hidden [n_layers+1, B, Tp, d] (bf16 for post-LN, f32 for pre-LN), T, Tp, valid_frames); with `stop_layer` = L only
-        hidden[0..L] are computed.
+        hidden[0..L] are computed.  `drop_layers` (layerdrop, speech_encoder_plus.py:49-53): the listed layers are skipped and leave NO entry
+        in the result -- hidden has 1 + (layers run) states, as the reference's `layer_results`.
         fold_ln (caller checked fold_ln_supported): returns ((h0 [M,d], ypre [n_layers, M, d], gamma2, beta2), T, Tp, valid) instead -- layer 0's
         normalised state and the PRE-LayerNorm outputs of the layers with the affines of their final LayerNorms (ops.weighted_sum_ln mixes them)."""
         cfg = self.cfg
@@ -363,10 +367,15 @@ class HubertModel(nn.Module):
                 if i + 1 < nl:
                     ops.ln_stats_finalize(part, d, out=st2)
             return (hidden[0], ypre, P["ln2_gamma"], P["ln2_beta"]), T, Tp, valid
+        assert not (fold_ln and drop_layers)
+        kept = 0
         for i, L in enumerate(P["layers"]):
             if stop_layer is not None and i >= stop_layer:      # fine-tuning: the layers from here on run as one autograd node (train_hubert.py)
                 break
-            h = hidden[i]
+            if i in drop_layers:
+                continue
+            h, h_out = hidden[kept], hidden[kept + 1]
+            kept += 1
             if not pre_ln:
                 ops.gemm(h, L["wqkv"], L["bqkv"], out=qkv)
                 ops.attention(qkv, B, Tp, H, valid_i32, out=att)
@@ -374,7 +383,7 @@ class HubertModel(nn.Module):
                 ops.layernorm(tmp, *L["ln1"], out=tmp2)
                 ops.gemm(tmp2, L["w1"], L["b1"], ACT_GELU, out=ffn)
                 ops.gemm(ffn, L["w2"], L["b2"], residual=tmp2, out=tmp)
-                ops.layernorm(tmp, *L["ln2"], out=hidden[i + 1])
+                ops.layernorm(tmp, *L["ln2"], out=h_out)
             else:
                 xmid = self._buf("xmid", (M, d), torch.float32, dev)
                 ops.layernorm(h, *L["ln1"], out=tmp)
@@ -383,5 +392,7 @@ class HubertModel(nn.Module):
                 ops.gemm(att, L["wo"], L["bo"], residual=h, out=xmid, out_f32=True)
                 ops.layernorm(xmid, *L["ln2"], out=tmp)
                 ops.gemm(tmp, L["w1"], L["b1"], ACT_GELU, out=ffn)
-                ops.gemm(ffn, L["w2"], L["b2"], residual=xmid, out=hidden[i + 1], out_f32=True)
+                ops.gemm(ffn, L["w2"], L["b2"], residual=xmid, out=h_out, out_f32=True)
+        if drop_layers:
+            return hidden[: kept + 1].view(kept + 1, B, Tp, d), T, Tp, valid
         return hidden.view(nl + 1, B, Tp, d), T, Tp, valid

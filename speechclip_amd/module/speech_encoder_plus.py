@@ -86,6 +86,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 sd = sd.get("model", sd)
                 missing, unexpected = self.encoder.load_state_dict(sd, strict=False)
                 logger.info(f"Loaded {ckpt}: missing={missing} unexpected={unexpected}")
+        if layer_drop != "original":          # speech_encoder_plus.py:405-412: a float overrides the checkpoint's rate, "original" keeps it
+            self.encoder.encoder.layerdrop = float(layer_drop)
         for p in self.encoder.parameters():
             p.requires_grad = False
         self.encoder.eval()
@@ -95,8 +97,6 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if self.train_layers:
             if cfg.layer_norm_first:
                 raise NotImplementedError("fine-tuning pre-LN (HuBERT-large) layers is not built; HuBERT-base layers are (train_hubert.py)")
-            if isinstance(layer_drop, float) and layer_drop > 0.0:
-                raise NotImplementedError("layerdrop > 0 while training encoder layers is not supported (every shipped config uses 0.0)")
             assert 0 <= self.train_layers[0] and self.train_layers[-1] < cfg.encoder_layers, self.train_layers
             for i in self.train_layers:
                 lyr = self.encoder.encoder.layers[i]
@@ -171,13 +171,23 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             raise NotImplementedError("normalize_type method1/method2 are not used by any shipped config")
         if feat_select_idx is None:
             feat_select_idx = self.feat_select_idx
+        # layerdrop (speech_encoder_plus.py:49-53): ONE np.random.random() per layer per forward, in layer order and in every mode (the
+        # reference draws before it looks at self.training, so the draws also advance the stream the random crops use); a layer is skipped
+        # when the module is in train mode and its draw is <= layerdrop -- and then contributes no hidden state.
+        nl_ = self.encoder.cfg.encoder_layers
+        draws = np.random.random(nl_)
+        rate = float(self.encoder.encoder.layerdrop)
+        drop = tuple(i for i in range(nl_) if self.training and not (draws[i] > rate))
         # Eval fast path: nobody asked for the hidden states themselves (only their mix), so the LayerNorms are folded into the GEMMs around
         # them and the layer mix rebuilds each state from its pre-norm rows (module/hubert.py: fold_ln).  The states are materialised when they
         # are returned, selected by index, or needed by the training tail's layer-mix gradient.
         mix_only = (feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE and not return_hidden_states
                     and not (torch.is_grad_enabled() and self.weightedsum_layer.weights.requires_grad)
                     and not self.weightedsum_layer.normalize_features)
-        if mix_only and self.encoder.fold_ln_supported(padded.shape[0], padded.shape[1]):
+        if drop and feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
+            # WeightedSumLayer.forward asserts one weight per hidden state (weighted_sum.py:36): the reference fails here too
+            raise AssertionError(self.upstream_model_hiddenstates_len - len(drop))
+        if mix_only and not drop and self.encoder.fold_ln_supported(padded.shape[0], padded.shape[1]):
             (h0, ypre, g2, b2), T, Tp, _valid = self.encoder.extract_all_layers(padded, lens, fold_ln=True)
             B_, d_ = padded.shape[0], h0.shape[-1]
             mixed = ops.weighted_sum_ln(h0, ypre, g2, b2, self.weightedsum_layer.weights.detach().float()).view(B_, Tp, d_)[:, :T]
@@ -185,7 +195,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             return (mixed, feat_len)
         if self.train_layers and torch.is_grad_enabled():
             return self._forward_finetune(padded, lens, feat_select_idx, return_hidden_states)
-        hidden, T, Tp, _valid = self.encoder.extract_all_layers(padded, lens)      # [n, B, Tp, d]
+        hidden, T, Tp, _valid = self.encoder.extract_all_layers(padded, lens, drop_layers=drop)      # [n, B, Tp, d]
         # speech_encoder_plus.py:604-611: Python round() (banker's) of len / 320, clamped to T
         feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()   # escapes to the caller
         layers = lambda: tuple(hidden[i, :, :T] for i in range(hidden.shape[0]))  # noqa: E731

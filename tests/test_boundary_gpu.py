@@ -154,3 +154,57 @@ def test_feature_extractor_s3prl_appends_branch_hidden_states():
         assert F.cosine_similarity(hs[n_enc - 1][b, :n].float().cpu().reshape(1, -1), hidden[-1][b, :n].reshape(1, -1)).item() > 0.998
         assert F.cosine_similarity(hs[n_enc][b, :n].float().cpu().reshape(1, -1), c_out[b, :n].reshape(1, -1)).item() > 0.998
         assert F.cosine_similarity(hs[n_enc + 1][b, :n].float().cpu().reshape(1, -1), p_layer[b, :n].reshape(1, -1)).item() > 0.998
+
+
+def test_layerdrop_in_train_mode_follows_the_reference_draws():
+    """speech_encoder_plus.py:49-53: in train mode a layer whose np.random.random() draw is <= layerdrop is skipped and leaves no hidden
+    state; one draw per layer per forward in every mode.  Same numpy seed -> the engine and the oracle drop the same layers."""
+    import dataclasses
+    import numpy as np
+    from oracle.hubert_ref import HubertModelRef, HubertRefConfig, hubert_forward
+    from speechclip_amd.module import FairseqSpeechEncoder_Hubert
+    from speechclip_amd.module.hubert import HubertConfig
+    href = dataclasses.replace(HubertRefConfig.tiny(), encoder_layers=6)
+    torch.manual_seed(3)
+    enc = FairseqSpeechEncoder_Hubert("hubert", feat_select_idx="hidden_states", layer_drop=0.4, max_audio_len=100000,
+                                      hubert_config=HubertConfig(**dataclasses.asdict(href)))
+    assert enc.encoder.encoder.layerdrop == 0.4
+    ref = HubertModelRef(href)
+    ref.load_state_dict(enc.encoder.state_dict())
+    ref.encoder.layerdrop = 0.4
+    enc = enc.cuda()
+    g = torch.Generator().manual_seed(1)
+    lens = [8000, 6100, 3000]
+    wav = torch.zeros(3, 8000)
+    for i, l in enumerate(lens):
+        wav[i, :l] = 0.3 * torch.randn(l, generator=g)
+    n_states = []
+    for seed in (0, 1, 2, 3):
+        enc.train()
+        ref.train()
+        np.random.seed(seed)
+        with torch.no_grad():
+            hs, flen = enc(wav.cuda(), torch.tensor(lens))
+        after = np.random.random()
+        np.random.seed(seed)
+        draws = np.random.random(6)
+        assert np.random.random() == after                                   # exactly six draws were consumed
+        np.random.seed(seed)
+        out = hubert_forward(ref, wav, torch.arange(8000)[None, :] >= torch.tensor(lens)[:, None])
+        ref_states = out["layer_results"]
+        assert len(hs) == len(ref_states) == 1 + int((draws > 0.4).sum())
+        n_states.append(len(hs))
+        for a, b in zip(hs, ref_states):
+            for r, n in enumerate(flen.tolist()):
+                assert F.cosine_similarity(a[r, :n].float().cpu().reshape(1, -1), b[r, :n].reshape(1, -1)).item() > 0.995
+    assert min(n_states) < 7                                                 # something was dropped in these seeds
+    enc.eval()
+    np.random.seed(0)
+    with torch.no_grad():
+        hs, _ = enc(wav.cuda(), torch.tensor(lens))
+    assert len(hs) == 7 and np.random.random() == np.random.RandomState(0).random_sample(7)[-1]      # eval: nothing dropped, six draws all the same
+    # the layer mix cannot take a shortened list: the reference's WeightedSumLayer asserts (weighted_sum.py:36), so does this build
+    enc2 = FairseqSpeechEncoder_Hubert("hubert", feat_select_idx="weighted_sum", layer_drop=1.0, hubert_config=HubertConfig(**dataclasses.asdict(href))).cuda().train()
+    with pytest.raises(AssertionError):
+        enc2(wav.cuda(), torch.tensor(lens))
+    assert FairseqSpeechEncoder_Hubert("hubert", layer_drop="original", hubert_config=HubertConfig(**dataclasses.asdict(href))).encoder.encoder.layerdrop == 0.05
