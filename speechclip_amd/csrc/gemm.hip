@@ -305,6 +305,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int lane_a_b = lane_a * 2, lane_w_b = lane_w * 2;       // byte offsets of this lane inside a 64-row group (buffer form)
     auto tile_m0 = [&](int t) -> int64_t { const int64_t m = (int64_t)t * 256; return m + 256 <= p.M ? m : p.M - 256; };
     auto tile_n0 = [&](int t) -> int { const int n = t * 256; return n + 256 <= p.N ? n : p.N - 256; };
+    // ABL 8 (timing probe, garbage results): every tile reads its A rows from the first 2048 rows -- distinct lines per k-step, but L2-resident:
+    // what the first-touch (MALL / HBM) latency of the A panels costs the loop
+    auto a_row0 = [&](int t) -> int64_t { const int64_t m = tile_m0(t); return ABL == 8 ? (m & 2047) : m; };
     int tm, tn;
     bool have = tile_of(0, tm, tn);
     StageAddr sa{nullptr, nullptr};
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     };
     if (have) {
         rot = p.rot ? tm % nk : 0;
-        set_tile(A + tile_m0(tm) * p.lda, W + (int64_t)tile_n0(tn) * p.ldw);
+        set_tile(A + a_row0(tm) * p.lda, W + (int64_t)tile_n0(tn) * p.ldw);
 #pragma unroll
         for (int q = 0; q < NPRO; ++q) issue_q(q);
     }
@@ -422,7 +425,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #ifndef SC_GEMM_RING3_PHASE
 #define SC_GEMM_RING3_PHASE 0
 #endif
+#ifndef SC_GEMM_RING3_EARLY
+#define SC_GEMM_RING3_EARLY 0
+#endif
+#if SC_GEMM_RING3_EARLY == 1   // pieces in MFMA groups 0..3 of their half-step: the last W piece gets 0.81 instead of 0.63 k-steps of lead
+                            const bool slot_ = i < 4; const int g_ = i;
+#elif SC_GEMM_RING3_EARLY == 2 // groups 0, 1, 2, 4
+                            const bool slot_ = i < 3 || i == 4; const int g_ = i < 3 ? i : 3;
+#else
                             const bool slot_ = (i & 1) == SC_GEMM_RING3_PHASE; const int g_ = i >> 1;
+#endif
 #else                          // (measured alternative: groups 4..7 of each half-step -- two bursts per k-step: -5 ... 0 %)
                             const bool slot_ = i >= 4; const int g_ = i - 4;
 #endif
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int nrot = (nhave && p.rot) ? ntm % nk : 0;
-        if (nhave) set_tile(A + tile_m0(ntm) * p.lda, W + (int64_t)tile_n0(ntn) * p.ldw);
+        if (nhave) set_tile(A + a_row0(ntm) * p.lda, W + (int64_t)tile_n0(ntn) * p.ldw);
         rot = nrot;   // the k-loop of THIS tile is over; from here on kofs() addresses the next tile
         const int emode = (RES ? p.epi_mode_res : p.epi_mode) & 0xff;
         if (nhave && emode == 0) {
@@ -784,6 +796,7 @@ int launch256(const GemmParams& p, hipStream_t s) {
     if (abl && abl[0] == '5') return launch256_var<5, false>(p, grid, s);
     if (abl && abl[0] == '6') return launch256_var<6, false>(p, grid, s);
     if (abl && abl[0] == '7') return launch256_var<7, false>(p, grid, s);
+    if (abl && abl[0] == '8') return launch256_var<8, false, true>(p, grid, s);
     // Default: the three-slot A ring with the refill spread over all 16 MFMA groups of a k-step (RING3 in gemm256_kernel).  SC_GEMM_RING3=0 selects
     // the two-slot [A|W] ring (A/B; also what the folded-LayerNorm epilogue variants use).
     static const bool ring3 = !(getenv("SC_GEMM_RING3") && atoi(getenv("SC_GEMM_RING3")) == 0);

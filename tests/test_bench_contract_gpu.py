@@ -36,6 +36,9 @@ def test_bench_json_contract_forward():
     v = d["vendor_comparator"]
     assert v["value"] > 0 and v["unit"] == "pairs/s" and v["ms_per_step"] > 0
     assert d["rccl_ranks_seen"] == 1 and d["exchange_ms_per_step"] is None
+    k = d["clock"]                  # rocm-smi reading beside the timed region (None only where rocm-smi cannot read the device)
+    assert k is None or (500 < k["sclk_mhz_under_load"] <= 2500 and k["socket_power_w"] > 100 and
+                         abs(k["mfma_peak_at_this_clock_tflops"] - 2500.0 * k["sclk_mhz_under_load"] / 2400) < 0.1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert c["timed_iterations"] >= 3 and len(c["fixed_length"]["iter_s"]) >= 3 and c["host_hw_threads"] >= c["cores"] and c["cpu_model"]

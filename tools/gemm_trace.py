@@ -4,7 +4,8 @@ import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from speechclip_amd import ops, _lib
-SH = {"qkv": (128000, 2304, 768, 0), "fc1": (128000, 3072, 768, 1), "fc2": (128000, 768, 3072, 0), "conv1": (4096000, 512, 1536, 1), "sq8k": (8192, 8192, 8192, 0)}
+SH = {"qkv": (128000, 2304, 768, 0), "fc1": (128000, 3072, 768, 1), "fc2": (128000, 768, 3072, 0), "conv1": (4096000, 512, 1536, 1), "sq8k": (8192, 8192, 8192, 0),
+      "out": (128000, 768, 768, 0), "n1536": (128000, 1536, 768, 0), "out6": (131072, 768, 768, 0), "out5": (109056, 768, 768, 0)}
 L = _lib.lib()
 L.sc_debug_set_gemm_trace.argtypes = [ctypes.c_void_p]
 for name in sys.argv[1:] or list(SH):
