@@ -308,6 +308,24 @@ int sc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const 
  *   sc_cls_pool_dz: d loss / d (mixed frames) from sc_cls_pool_bwd's workspaces: dz[b,t] = sum_r pp[b,r,NQ+t] dzbar[b,r] + ds[b,r,NQ+t] u[r]. */
 int sc_transpose_bf16(const void* in, int64_t ld_in, int64_t stride_in, void* out, int64_t ld_out, int64_t stride_out, int rows, int cols,
                       int rows_padded, int batch, void* stream);
+
+/* ---- backward of the HuBERT front end: `audio_encoder.trainable: true` with no layer lists trains the conv feature extractor, post_extract_proj,
+ * layer_norm and the positional conv as well (avssl/module/speech_encoder_plus.py:399-401: freeze_model is not called; [3P fairseq]
+ * HubertModel.forward_features scales the extractor's gradient by feature_grad_mult).  GEMM-shaped parts reuse sc_gemm_bf16 / sc_gemm_bf16_batched /
+ * sc_posconv_conv (speechclip_amd/train_front.py); these entries are the rest:
+ *   sc_posconv_finish_train: training forward of the positional-conv tail (speech_encoder_plus.py:35-37): u = conv + bias regrouped from
+ *     [B, G, Tp, D/G] to bf16 [B*Tp, D], s = mask(x) + gelu(u) (bf16; the LayerNorm after it runs as sc_layernorm_fwd) -- both kept for the backward.
+ *   sc_posconv_dgrad_finish: dx = mask(ds + time-reversed regroup of convT), convT = sc_posconv_conv of the time-reversed du with the in/out
+ *     channel-swapped weights (the adjoint of "pad Kw/2, drop the last output" is the same conv on the reversed sequence).
+ *   sc_reverse_rows_bf16: out[b, t, :] = in[b, T-1-t, :].
+ *   sc_conv0_bwd: conv layer 0 = Conv1d(1 -> C, k 10, s 5, no bias) -> GroupNorm(C groups, statistics over the T0 frames) -> GELU, from the wave:
+ *     dy bf16 [B, P, C] -> part f32 [B, C, 12] = per-utterance (dw[0..9], dgamma, dbeta); sum over B for the parameter gradients. */
+int sc_posconv_finish_train(const void* x, const int32_t* valid, const void* conv, const float* bias, void* u, void* s, int B, int Tp, int D, int G,
+                            void* stream);
+int sc_posconv_dgrad_finish(const void* convT, const void* ds, const int32_t* valid, void* dx, int B, int Tp, int D, int G, void* stream);
+int sc_reverse_rows_bf16(const void* in, void* out, int B, int T, int D, void* stream);
+int sc_conv0_bwd(const float* wav, int64_t ld, const float* w, const float* gamma, const float* beta, const void* dy, float* part, int B, int C, int T0,
+                 int P, float eps, void* stream);
 int sc_attn_softmax_bwd(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
                         int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch, float scale, void* stream);
 int sc_gelu_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, void* stream);

@@ -209,6 +209,19 @@ class TransformerEncoderRef(nn.Module):
         return x.transpose(0, 1), layer_results
 
 
+class _GradMultiply(torch.autograd.Function):
+    """[3P fairseq modules/grad_multiply.py]: identity forward, gradient scaled."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x.new(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad * ctx.scale, None
+
+
 class HubertModelRef(nn.Module):
     def __init__(self, cfg: HubertRefConfig):
         super().__init__()
@@ -226,7 +239,15 @@ class HubertModelRef(nn.Module):
         self.apply(_init_bert_params)
 
     def forward_features(self, source):
-        return self.feature_extractor(source)
+        """[3P fairseq hubert.py HubertModel.forward_features]: the extractor's output carries feature_grad_mult times the gradient
+        (GradMultiply); feature_grad_mult == 0 runs it without autograd."""
+        if self.feature_grad_mult > 0:
+            features = self.feature_extractor(source)
+            if self.feature_grad_mult != 1.0:
+                features = _GradMultiply.apply(features, self.feature_grad_mult)
+            return features
+        with torch.no_grad():
+            return self.feature_extractor(source)
 
     def forward_padding_mask(self, features, padding_mask):
         """[3P hubert.py] trim Lmax % T samples, view [B, T, -1], frame is pad iff all samples pad."""

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void cls_pool_dz_kernel(const float* __restric
 extern "C" int sc_transpose_bf16(const void* in, int64_t ld_in, int64_t stride_in, void* out, int64_t ld_out, int64_t stride_out, int rows, int cols,
                                  int rows_padded, int batch, void* stream) {
     SC_CHECK_ARG(in && out && rows > 0 && cols > 0 && rows_padded >= rows && batch > 0 && batch <= 65535, "sc_transpose_bf16: bad arguments");
-    SC_CHECK_ARG(ld_out >= rows_padded && ld_in >= cols, "sc_transpose_bf16: leading dimensions too small");
+    // ld_in < cols is allowed: an overlapping-row (sliding-window) view of the input, read-only
+    SC_CHECK_ARG(ld_out >= rows_padded && ld_in >= 1, "sc_transpose_bf16: leading dimensions too small");
     dim3 grid((rows_padded + 63) / 64, (cols + 63) / 64, batch);
     hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, stride_in, (bf16_t*)out, ld_out, stride_out,
                        rows, cols, rows_padded);

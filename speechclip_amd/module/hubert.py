@@ -42,6 +42,7 @@ class HubertConfig:
     conv_pos: int = 128
     conv_pos_groups: int = 16
     normalize: bool = False              # fairseq task.cfg.normalize (per-utterance wave layer-norm)
+    feature_grad_mult: float = 0.1       # [3P fairseq hubert_base_librispeech: 0.1; hubert_large_librivox: 1.0]: scale of the gradient entering the conv extractor
     encoder_layerdrop: float = 0.05      # the checkpoint's own rate [3P fairseq hubert_base_librispeech: 0.05, hubert_large_librivox: 0.0]; used
                                          # only with audio_encoder.layer_drop: "original" (speech_encoder_plus.py:411-412)
 
@@ -52,7 +53,7 @@ class HubertConfig:
         if name == "hubert_large_ll60k":
             return HubertConfig(extractor_mode="layer_norm", conv_bias=True, encoder_layers=24, encoder_embed_dim=1024,
                                 encoder_ffn_embed_dim=4096, encoder_attention_heads=16, layer_norm_first=True, normalize=True,
-                                encoder_layerdrop=0.0)
+                                encoder_layerdrop=0.0, feature_grad_mult=1.0)
         raise KeyError(name)
 
 

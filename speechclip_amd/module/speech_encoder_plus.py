@@ -59,10 +59,6 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         assert not (len(reinit_layers) > 0 and len(unfreeze_layers) > 0)            # speech_encoder_plus.py:415
         if (len(reinit_layers) > 0 or len(unfreeze_layers) > 0) and not trainable:
             raise AssertionError("reinit_layers / unfreeze_layers need trainable=True (speech_encoder_plus.py:418,:433)")
-        if trainable and not (len(reinit_layers) > 0 or len(unfreeze_layers) > 0):
-            raise NotImplementedError("trainable=True without reinit_layers / unfreeze_layers also trains the conv feature extractor and the positional "
-                                      "conv, whose backward kernels are not built; list the transformer layers to train (the modes in which the "
-                                      "reference freezes everything below them, speech_encoder_plus.py:416-446)")
         if not (layer_drop == "original" or (isinstance(layer_drop, float) and 0.0 <= layer_drop <= 1.0)):
             raise ValueError(f"layer_drop = {layer_drop} is not supported.")
         self.name, self.pretrained, self.trainable = name, pretrained, trainable
@@ -94,7 +90,19 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # speech_encoder_plus.py:416-446: the listed transformer layers train (reinit_layers: re-initialised first, fairseq init_bert_params);
         # every other layer, pos_conv, layer_norm, the feature extractor and post_extract_proj stay frozen (feature_grad_mult = 0)
         self.train_layers = sorted(set(int(i) for i in (list(reinit_layers) + list(unfreeze_layers))))
-        if self.train_layers:
+        # speech_encoder_plus.py:399-401: trainable without layer lists -- nothing is frozen: the conv feature extractor (its gradient scaled by
+        # the checkpoint's feature_grad_mult [3P fairseq forward_features]), layer_norm, post_extract_proj, the positional conv and all layers train
+        self.train_front = bool(trainable) and not self.train_layers
+        if self.train_front:
+            if cfg.layer_norm_first or cfg.extractor_mode != "default" or cfg.conv_bias:
+                raise NotImplementedError("trainable=True is built for the GroupNorm / post-LN architecture (HuBERT-base); the LayerNorm-extractor, "
+                                          "pre-LN large model is not (train_front.py, train_hubert.py)")
+            self.train_layers = list(range(cfg.encoder_layers))
+            unused = ("mask_emb", "final_proj", "label_embs_concat")      # never reached by customHubertForward: torch's Adam skips their None gradients
+            for k, p in self.encoder.named_parameters():
+                p.requires_grad = not k.startswith(unused)
+            self.encoder.feature_grad_mult = cfg.feature_grad_mult
+        elif self.train_layers:
             if cfg.layer_norm_first:
                 raise NotImplementedError("fine-tuning pre-LN (HuBERT-large) layers is not built; HuBERT-base layers are (train_hubert.py)")
             assert 0 <= self.train_layers[0] and self.train_layers[-1] < cfg.encoder_layers, self.train_layers
@@ -111,6 +119,8 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 for p in lyr.parameters():
                     p.requires_grad = True
             self.encoder.feature_grad_mult = 0
+        if self.train_front:
+            assert 0.0 < float(self.encoder.feature_grad_mult) <= 1.0, "feature_grad_mult = 0 would freeze the extractor: use unfreeze_layers"
         self.downsample_rate = self.MODEL_DOWNSAMPLE_RATE[name]
         self.out_dim = cfg.encoder_embed_dim
         self.upstream_model_hiddenstates_len = cfg.encoder_layers + 1
@@ -234,16 +244,27 @@ def _forward_finetune(self, padded, lens, feat_select_idx, return_hidden_states)
     cfg = enc.cfg
     dev = padded.device
     L0, nl = self.train_layers[0], cfg.encoder_layers
-    hidden, T, Tp, valid = enc.extract_all_layers(padded, lens, stop_layer=L0)        # hidden[0 .. L0] are valid
     B, d = padded.shape[0], cfg.encoder_embed_dim
+    if self.train_front:          # the wave -> hidden state 0 as an autograd node too (train_front.HubertFrontTrainFn)
+        from ..train_front import HubertFrontTrainFn, front_params
+        T0, T, P0, Tp = enc.frame_geometry(padded.shape[1])
+        valid = enc.valid_frames(lens, padded.shape[1], T)
+        fmeta = dict(conv_layers=[tuple(c) for c in cfg.conv_layers], T0=T0, P0=P0, Tp=Tp, d=d, G=cfg.conv_pos_groups, Kw=cfg.conv_pos,
+                     grad_mult=float(enc.feature_grad_mult))
+        h_front = HubertFrontTrainFn.apply(fmeta, padded.contiguous(), ops.dev_ints(valid, torch.int32, dev), *front_params(enc))      # [B*Tp, d]
+        hidden = None
+    else:
+        hidden, T, Tp, valid = enc.extract_all_layers(padded, lens, stop_layer=L0)        # hidden[0 .. L0] are valid
     M = B * Tp
     params = []
     for i in range(L0, nl):
         params += layer_params(enc.encoder.layers[i])
     meta = dict(B=B, Tp=Tp, H=cfg.encoder_attention_heads, eps=1e-5, train=[i in self.train_layers for i in range(L0, nl)])
-    h_in = hidden[L0].reshape(M, d).clone()          # the engine's hidden buffer is a reused workspace: the autograd node keeps its own copy
+    # (the engine's hidden buffer is a reused workspace: the autograd node keeps its own copy)
+    h_in = h_front if self.train_front else hidden[L0].reshape(M, d).clone()
     hi = HubertLayersTrainFn.apply(meta, h_in, ops.dev_ints(valid, torch.int32, dev), *params)      # [nl - L0, M, d]
-    hidden_all = torch.cat([hidden[:L0 + 1].reshape(L0 + 1, M, d).detach(), hi], 0)
+    below = h_front.view(1, M, d) if self.train_front else hidden[:L0 + 1].reshape(L0 + 1, M, d).detach()
+    hidden_all = torch.cat([below, hi], 0)
     ws = self.weightedsum_layer
     mixed = WeightedSumTrainFn.apply(hidden_all, ws.weights, ws.normalize_features).view(B, Tp, d)[:, :T]
     mixed._mix_src = (hidden_all.detach().view(nl + 1, B, Tp, d), ws)                  # the mix weights' gradient comes out of the head's backward

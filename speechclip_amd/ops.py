@@ -764,13 +764,15 @@ def image_normalize_u8(u8, mean=CLIP_MEAN, std=CLIP_STD):
 
 
 # ---- fine-tuning HuBERT layers (train_hubert.hip) ----
-def transpose_bf16(src, ld_in, stride_in, rows, cols, batch, rows_padded=None, out=None):
-    """batch of [rows, cols] bf16 matrices (row r of matrix z at src + z*stride_in + r*ld_in) -> out bf16 [batch, cols, rows_padded] (zero padded)."""
+def transpose_bf16(src, ld_in, stride_in, rows, cols, batch, rows_padded=None, out=None, ld_out=None, stride_out=None):
+    """batch of [rows, cols] bf16 matrices (row r of matrix z at src + z*stride_in + r*ld_in) -> out bf16 [batch, cols, rows_padded] (zero padded);
+    ld_out / stride_out place matrix z at out + z*stride_out with rows of stride ld_out instead (e.g. side by side in one wide matrix)."""
     _need_cuda(src)
     rp = rows if rows_padded is None else rows_padded
     if out is None:
         out = torch.empty(batch, cols, rp, device=src.device, dtype=bf16)
-    check(lib().sc_transpose_bf16(ptr(src), ld_in, stride_in, ptr(out), rp, cols * rp, rows, cols, rp, batch, stream()), "sc_transpose_bf16")
+    check(lib().sc_transpose_bf16(ptr(src), ld_in, stride_in, ptr(out), rp if ld_out is None else ld_out, cols * rp if stride_out is None else stride_out,
+                                  rows, cols, rp, batch, stream()), "sc_transpose_bf16")
     return out
 
 
@@ -833,3 +835,60 @@ def cls_pool_dz(pp, ds, dzbar, u, lens_i32, B, T, NQ, R, D):
     dz = torch.empty(B * T, D, device=pp.device, dtype=bf16)
     check(lib().sc_cls_pool_dz(ptr(pp), ptr(ds), ptr(dzbar), ptr(u), ptr(lens_i32), ptr(dz), B, T, NQ, R, D, D, stream()), "sc_cls_pool_dz")
     return dz
+
+
+# ---------------------------------------------------------------------------------------------- front-end backward (train_front.py)
+def posconv_conv(x, valid_i32, wg, B, Tp, D, G, Kw):
+    """The grouped positional conv alone: x bf16 [B*Tp, D] (frames >= valid[b] read as zero), wg bf16 [G, D/G, Kw*D/G] -> bf16 [B, G, Tp, D/G]."""
+    _need_cuda(x, wg)
+    cg = D // G
+    conv = torch.empty(B * G * Tp * cg, device=x.device, dtype=bf16)
+    rc = lib().sc_posconv_conv(ptr(x), ptr(valid_i32), ptr(wg), ptr(conv), B, Tp, D, G, Kw, stream())
+    if rc == 1:
+        xg = posconv_pack(x, valid_i32, B, Tp, D, G, Kw)
+        gemm_batched(xg, cg, (Tp + Kw) * cg, wg, cg * Kw * cg, G, conv, cg, Tp * cg, None, Tp, cg, Kw * cg, B * G)
+    else:
+        check(rc, "sc_posconv_conv")
+    return conv
+
+
+def posconv_pack(x, valid_i32, B, Tp, D, G, Kw):
+    """Sliding-window layout of the masked input: bf16 [B, G, Tp + Kw, D/G] (+64 slack elements), Kw/2 zero rows in front."""
+    cg = D // G
+    xg = torch.empty(B * G * (Tp + Kw) * cg + 64, device=x.device, dtype=bf16)
+    check(lib().sc_posconv_pack(ptr(x), ptr(valid_i32), ptr(xg), B, Tp, D, G, Kw, stream()), "sc_posconv_pack")
+    return xg
+
+
+def posconv_finish_train(x, valid_i32, conv, bias, B, Tp, D, G):
+    """-> (u, s) bf16 [B*Tp, D]: u = conv + bias regrouped, s = mask(x) + gelu(u)."""
+    u = torch.empty(B * Tp, D, device=x.device, dtype=bf16)
+    s = torch.empty_like(u)
+    check(lib().sc_posconv_finish_train(ptr(x), ptr(valid_i32), ptr(conv), ptr(bias), ptr(u), ptr(s), B, Tp, D, G, stream()), "sc_posconv_finish_train")
+    return u, s
+
+
+def posconv_dgrad_finish(convT, ds, valid_i32, B, Tp, D, G):
+    dx = torch.empty(B * Tp, D, device=ds.device, dtype=bf16)
+    assert ds.dtype == bf16 and ds.is_contiguous()
+    check(lib().sc_posconv_dgrad_finish(ptr(convT), ptr(ds), ptr(valid_i32), ptr(dx), B, Tp, D, G, stream()), "sc_posconv_dgrad_finish")
+    return dx
+
+
+def reverse_rows_bf16(x, B, T, D):
+    assert x.dtype == bf16 and x.is_contiguous() and x.numel() == B * T * D
+    out = torch.empty_like(x)
+    check(lib().sc_reverse_rows_bf16(ptr(x), ptr(out), B, T, D, stream()), "sc_reverse_rows_bf16")
+    return out
+
+
+def conv0_bwd(wav, w, gamma, beta, dy, T0, P, eps=1e-5):
+    """wav f32 [B, L]; w f32 [C, 10]; dy bf16 [B*P (+ slack), C] -> (dw f32 [C, 10], dgamma f32 [C], dbeta f32 [C])."""
+    _need_cuda(wav, dy)
+    B, L = wav.shape
+    C = w.shape[0]
+    assert wav.dtype == torch.float32 and wav.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous() and dy.dtype == bf16 and dy.is_contiguous()
+    part = torch.empty(B, C * 12, device=wav.device, dtype=torch.float32)
+    check(lib().sc_conv0_bwd(ptr(wav), L, ptr(w), ptr(gamma), ptr(beta), ptr(dy), ptr(part), B, C, T0, P, eps, stream()), "sc_conv0_bwd")
+    tot = colsum(part).view(C, 12)
+    return tot[:, :10].contiguous(), tot[:, 10].contiguous(), tot[:, 11].contiguous()

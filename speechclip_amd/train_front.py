@@ -1,0 +1,193 @@
+"""Training the HuBERT front end on MI355X: `audio_encoder.trainable: true` WITHOUT `reinit_layers` / `unfreeze_layers`
+(avssl/module/speech_encoder_plus.py:399-401 -- `freeze_model` is simply not called, so the conv feature extractor, `post_extract_proj`,
+`layer_norm`, the positional conv and every transformer layer train; [3P fairseq] `HubertModel.forward_features` multiplies the gradient that
+enters the feature extractor by `feature_grad_mult`, 0.1 in the released base checkpoint).
+
+`HubertFrontTrainFn` = wave -> hidden state 0 (the input of transformer layer 0) as ONE autograd node, post-LN / GroupNorm models (HuBERT-base):
+  forward   the eval path's kernels (sc_conv0_fwd, conv-as-GEMM with fused GELU, LayerNorm, projection, sc_posconv_conv), keeping the layer outputs,
+            plus sc_posconv_finish_train (pre-activation and LayerNorm input of the positional-conv tail)
+  backward  encoder LayerNorm      sc_layernorm_bwd_bf16
+            positional conv        dX: the SAME grouped conv on the time-reversed gradient with in/out channels swapped (sc_posconv_conv +
+                                   sc_posconv_dgrad_finish); dW: per group, split-K sc_gemm_bf16_batched over the transposed sliding-window
+                                   view (sc_posconv_pack + sc_transpose_bf16); weight-norm (g, v) from dW in fp32 on the [d, d/G, Kw] tensors
+            projection, feature LN sc_gemm_bf16 on the transposed weight, train_hubert.wgrad, sc_layernorm_bwd_bf16
+            conv layers 6..1       pre-activation recomputed (sc_gemm_bf16 without the GELU), sc_gelu_bwd_bf16, dW = split-K TN GEMM over the
+                                   overlapping-row view, dX = one GEMM per group of taps written straight into the channels-last input gradient
+                                   (taps 0..s-1 tile it exactly; tap s.. accumulate through the residual epilogue, in place)
+            conv layer 0           sc_conv0_bwd (GroupNorm + GELU + conv from the wave)
+The dropouts fairseq applies in train mode (features 0.1, after the positional conv) are not applied -- the same documented deviation as in the
+frozen towers.
+"""
+import torch
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE
+from .train_hubert import wgrad
+
+BF = torch.bfloat16
+N_FRONT = 18   # conv0 w, gn w, gn b, conv1..6 w, feat-LN w b, proj w b, pos g v bias, enc-LN w b
+
+
+def front_params(enc) -> list:
+    """The trainable tensors of the front end of module.hubert.HubertModel, in HubertFrontTrainFn's order (base / GroupNorm extractor)."""
+    convs = enc.feature_extractor.conv_layers
+    assert enc.cfg.extractor_mode == "default" and not enc.cfg.conv_bias and not enc.cfg.layer_norm_first and len(convs) == 7
+    gn = getattr(convs[0], "2")
+    pc = getattr(enc.encoder.pos_conv, "0")
+    return ([getattr(convs[0], "0").weight, gn.weight, gn.bias] + [getattr(convs[i], "0").weight for i in range(1, 7)] +
+            [enc.layer_norm.weight, enc.layer_norm.bias, enc.post_extract_proj.weight, enc.post_extract_proj.bias,
+             pc.weight_g, pc.weight_v, pc.bias, enc.encoder.layer_norm.weight, enc.encoder.layer_norm.bias])
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+def _conv_w16(w):
+    """[out, in, k] -> bf16 [out, k*in] (K index = tap*C + c_in), the conv-as-GEMM operand."""
+    return w.detach().permute(0, 2, 1).reshape(w.shape[0], -1).to(BF).contiguous()
+
+
+def _fold_weight_norm(g, v):
+    v = v.detach().float()
+    n = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+    return g.detach().float() * v / n, n
+
+
+def _pos_operands(wfold, G, Kw):
+    """folded weight f32 [d, d/G, Kw] -> (forward operand, adjoint operand) bf16 [G, cg, Kw*cg], K index = tap*cg + c_in."""
+    d, cg, _ = wfold.shape
+    w4 = wfold.view(G, cg, cg, Kw)                                   # [g, out, in, tap]
+    fwd = w4.permute(0, 1, 3, 2).reshape(G, cg, Kw * cg).to(BF).contiguous()
+    adj = w4.permute(0, 2, 3, 1).reshape(G, cg, Kw * cg).to(BF).contiguous()      # roles of in / out swapped
+    return fwd, adj
+
+
+def posconv_wgrad(du, xp, valid_i32, B, Tp, D, G, Kw):
+    """dW of the grouped positional conv in the folded weight's layout: f32 [D, D/G, Kw] = sum_{b,t} du[b,t,out] * mask(xp)[b, t + tap - Kw/2, in]."""
+    cg = D // G
+    dev = du.device
+    Tq = -(-Tp // 64) * 64
+    Ktot = B * Tq
+    S = max(s for s in (16, 8, 4, 2, 1) if B % s == 0)
+    chunk = Ktot // S
+    xg = ops.posconv_pack(xp, valid_i32, B, Tp, D, G, Kw)              # [B, G, Tp + Kw, cg]
+    xvT = torch.empty(Kw * cg, Ktot, device=dev, dtype=BF)
+    duT = torch.empty(cg, Ktot, device=dev, dtype=BF)
+    part = torch.empty(S, Kw * cg, cg, device=dev, dtype=torch.float32)
+    out = torch.empty(D, cg, Kw, device=dev, dtype=torch.float32)
+    rows = Tp + Kw
+    for g in range(G):
+        ops.transpose_bf16(xg[g * rows * cg:], cg, G * rows * cg, Tp, Kw * cg, B, rows_padded=Tq, out=xvT, ld_out=Ktot, stride_out=Tq)
+        ops.transpose_bf16(du[:, g * cg:], D, Tp * D, Tp, cg, B, rows_padded=Tq, out=duT, ld_out=Ktot, stride_out=Tq)
+        ops.gemm_batched(xvT, Ktot, chunk, duT, chunk, S, part, cg, Kw * cg * cg, None, Kw * cg, cg, chunk, S, ldw=Ktot)
+        tot = part[0] if S == 1 else ops.colsum(part.view(S, Kw * cg * cg)).view(Kw * cg, cg)      # [(tap, in), out]
+        out[g * cg:(g + 1) * cg] = tot.view(Kw, cg, cg).permute(2, 1, 0)
+    return out
+
+
+class HubertFrontTrainFn(torch.autograd.Function):
+    """h0 bf16 [B*Tp, d] = LN(mask(x) + gelu(pos_conv(mask(x)))) with x = proj(LN(conv stack(wav))).
+    args: meta (conv_layers, T0, P0, Tp, d, G, Kw, grad_mult, train: compute parameter gradients), wav f32 [B, L], valid_i32 [B], N_FRONT tensors."""
+
+    @staticmethod
+    def forward(ctx, meta, wav, valid_i32, *params):
+        assert len(params) == N_FRONT
+        c0w, gnw, gnb = params[:3]
+        cws = params[3:9]
+        flw, flb, pw, pb, pg, pv, pbias, elw, elb = params[9:]
+        cl, T0, P0, Tp, d, G, Kw = meta["conv_layers"], meta["T0"], meta["P0"], meta["Tp"], meta["d"], meta["G"], meta["Kw"]
+        B = wav.shape[0]
+        dev = wav.device
+        C = cl[0][0]
+        x = ops.conv0(wav, _f32(c0w).reshape(C, -1), T0, P0, gn_gamma=_f32(gnw), gn_beta=_f32(gnb))
+        acts = [x]
+        rows = P0
+        for (dim, k, s), w in zip(cl[1:], cws):
+            rows //= s
+            y = torch.zeros(B * rows + 8, dim, device=dev, dtype=BF)
+            ops.gemm(x, _conv_w16(w), None, ACT_GELU, out=y[:B * rows], M=B * rows, K=k * C, lda=s * C)
+            acts.append(y)
+            x, C = y, dim
+        assert rows == Tp
+        M = B * Tp
+        feats = ops.layernorm(x[:M], _f32(flw), _f32(flb))
+        xp = ops.gemm(feats, pw.detach().to(BF).contiguous(), _f32(pb))
+        wfold, _ = _fold_weight_norm(pg, pv)
+        wg, _ = _pos_operands(wfold, G, Kw)
+        conv = ops.posconv_conv(xp, valid_i32, wg, B, Tp, d, G, Kw)
+        u, s_ = ops.posconv_finish_train(xp, valid_i32, conv, _f32(pbias), B, Tp, d, G)
+        h0 = ops.layernorm(s_, _f32(elw), _f32(elb), 1e-5)
+        ctx.meta = meta
+        ctx.valid = valid_i32
+        ctx.save_for_backward(wav, *acts, feats, xp, u, s_, *[p.detach() for p in params])
+        return h0
+
+    @staticmethod
+    def backward(ctx, dh0):
+        meta = ctx.meta
+        cl, T0, P0, Tp, d, G, Kw = meta["conv_layers"], meta["T0"], meta["P0"], meta["Tp"], meta["d"], meta["G"], meta["Kw"]
+        t = ctx.saved_tensors
+        wav, acts, (feats, xp, u, s_), params = t[0], t[1:8], t[8:12], t[12:]
+        c0w, gnw, gnb = params[:3]
+        cws = params[3:9]
+        flw, flb, pw, pb, pg, pv, pbias, elw, elb = params[9:]
+        B = wav.shape[0]
+        M = B * Tp
+        dev = wav.device
+        valid = ctx.valid
+        grads = [None] * N_FRONT
+        # ---- h0 = LN(s)
+        ds, grads[16], grads[17] = ops.layernorm_bwd_bf16(s_, dh0.to(BF).contiguous(), _f32(elw), 1e-5)
+        # ---- s = mask(xp) + gelu(u),  u = conv(mask(xp)) + bias
+        du = ops.gelu_bwd_bf16(u, ds)
+        grads[15] = ops.colsum_bf16(du)
+        wfold, norm = _fold_weight_norm(pg, pv)
+        _, wg_adj = _pos_operands(wfold, G, Kw)
+        full = ops.dev_ints([Tp] * B, torch.int32, dev)
+        convT = ops.posconv_conv(ops.reverse_rows_bf16(du, B, Tp, d), full, wg_adj, B, Tp, d, G, Kw)
+        dxp = ops.posconv_dgrad_finish(convT, ds, valid, B, Tp, d, G)
+        dwf = posconv_wgrad(du, xp, valid, B, Tp, d, G, Kw)              # gradient of the FOLDED weight
+        v = pv.detach().float()
+        dot = (dwf * v).sum(dim=(0, 1), keepdim=True)                     # weight-norm: w = g v / |v|  (norm over dims 0, 1 per tap)
+        gf = pg.detach().float()
+        grads[13] = (dot / norm).to(pg.dtype)
+        grads[14] = (gf / norm * dwf - gf * dot / norm.pow(3) * v).to(pv.dtype)
+        del convT, du, ds
+        # ---- xp = feats W^T + b ; feats = LN(x6)
+        dfeats = ops.gemm(dxp, pw.detach().t().to(BF).contiguous())
+        grads[11], grads[12] = wgrad(dxp, feats), ops.colsum_bf16(dxp)
+        x6 = acts[6][:M]
+        g, grads[9], grads[10] = ops.layernorm_bwd_bf16(x6, dfeats, _f32(flw), 1e-5)
+        mult = float(meta["grad_mult"])
+        if mult != 1.0:      # [3P fairseq] GradMultiply on the feature extractor's output
+            g = ops.axpy_bf16(torch.zeros_like(g), g, mult)
+        # ---- conv layers 6 .. 1
+        rows_out = Tp
+        for i in range(6, 0, -1):
+            dim, k, s = cl[i]
+            C = cl[i - 1][0]
+            xin = acts[i - 1]
+            Mi = B * rows_out
+            rows_in = rows_out * s
+            w16 = _conv_w16(cws[i - 1])
+            upre = ops.gemm(xin, w16, None, ACT_NONE, M=Mi, K=k * C, lda=s * C)        # pre-activation, recomputed
+            du_i = ops.gelu_bwd_bf16(upre, g)
+            del upre
+            xview = torch.as_strided(xin, (Mi, k * C), (s * C, 1))
+            grads[3 + i - 1] = wgrad(du_i, xview).view(dim, k, C).permute(0, 2, 1).contiguous()
+            wT = w16.t().contiguous()                                                    # [k*C, dim]
+            dx = torch.zeros(B * rows_in + 8, C, device=dev, dtype=BF)
+            ops.gemm(du_i, wT[:s * C], out=dx[:s * Mi].view(Mi, s * C))                  # taps 0 .. s-1 tile the input rows exactly
+            for j in range(s, k):                                                        # overlapping taps: accumulate in place
+                tgt = torch.as_strided(dx, (Mi, C), (s * C, 1), storage_offset=j * C)
+                ops.gemm(du_i, wT[j * C:(j + 1) * C], residual=tgt, out=tgt)
+            g = dx[:B * rows_in]
+            rows_out = rows_in
+            del du_i
+        assert rows_out == P0
+        # ---- conv layer 0 from the wave
+        C0 = cl[0][0]
+        dw0, dgn, dbn = ops.conv0_bwd(wav, _f32(c0w).reshape(C0, -1), _f32(gnw), _f32(gnb), g.contiguous(), T0, P0)
+        grads[0], grads[1], grads[2] = dw0.view_as(c0w), dgn, dbn
+        return (None, None, None, *grads)

@@ -141,7 +141,7 @@ def test_cls_pool_dz_matches_autograd():
         assert dz[b, n:].abs().max().item() == 0 if n < T else True
 
 
-def _finetune_pair(train_layers, reinit=False):
+def _finetune_pair(train_layers, reinit=False, everything=False):
     """Tiny P-base model with the listed encoder layers trainable + the oracle with the same weights."""
     from helpers import make_config
     from oracle.clip_ref import ClipRefConfig
@@ -153,7 +153,9 @@ def _finetune_pair(train_layers, reinit=False):
     href, cref = dataclasses.replace(HubertRefConfig.tiny(), encoder_layers=3), ClipRefConfig.tiny()
     cfg = make_config(d_model=128, branch_heads=4, hubert_config=HubertConfig(**dataclasses.asdict(href)), clip_config=ClipConfig(**dataclasses.asdict(cref)))
     cfg.audio_encoder.trainable = True
-    if reinit:
+    if everything:
+        pass                                                          # bare trainable: true -- no layer lists
+    elif reinit:
         cfg.audio_encoder.reinit_layers = list(train_layers)
     else:
         cfg.audio_encoder.unfreeze_layers = list(train_layers)
@@ -189,8 +191,8 @@ def test_trainable_flags_follow_the_reference():
     tp = model.getTrainableParams()
     assert sum(any(p is q for q in tp) for p in enc.encoder.parameters() if p.requires_grad) == 32
     from speechclip_amd.module import FairseqSpeechEncoder_Hubert
-    with pytest.raises(NotImplementedError):
-        FairseqSpeechEncoder_Hubert("hubert", trainable=True, hubert_config=enc.encoder.cfg)        # would train the conv stack too: not built
+    full = FairseqSpeechEncoder_Hubert("hubert", trainable=True, hubert_config=enc.encoder.cfg)     # bare trainable: everything trains (train_front.py)
+    assert full.train_front and full.train_layers == [0, 1, 2]
     with pytest.raises(AssertionError):
         FairseqSpeechEncoder_Hubert("hubert", trainable=False, unfreeze_layers=[1], hubert_config=enc.encoder.cfg)
 
@@ -249,6 +251,88 @@ def test_finetune_gradients_vs_oracle_autograd(train_layers):
     assert _cos(mine["audio_encoder.weightedsum_layer.weights"].grad, ref.ws_weights.grad) > 0.98
     # frozen parts have no gradient
     assert all(p.grad is None for k, p in mine.items() if k.startswith("audio_encoder.encoder.") and not any(f".layers.{i}." in k for i in train_layers))
+
+
+def test_full_encoder_training_gradients_vs_oracle_autograd():
+    """`audio_encoder.trainable: true` with no layer lists (speech_encoder_plus.py:399-401): loss.backward() reaches EVERY encoder tensor the forward
+    uses -- conv feature extractor (x feature_grad_mult 0.1), feature LayerNorm, post_extract_proj, positional conv (weight-norm g and v), encoder
+    LayerNorm, all transformer layers -- and matches the fp32 oracle's autograd on the same weights and batch."""
+    from oracle import hubert_ref as HR
+    from oracle import speechclip_ref as R
+    model, ref, batch = _finetune_pair([], everything=True)
+    model = model.cuda().eval()
+    assert model.audio_encoder.train_front
+    feats, _, _ = model({k: v.cuda() for k, v in batch.items()})
+    loss = model.compute_loss(feats)["loss"]
+    loss.backward()
+    for p in ref.parameters():
+        p.requires_grad_(False)
+    for k, p in ref.encoder.named_parameters():
+        p.requires_grad_(not k.startswith(("mask_emb", "final_proj", "label_embs_concat")))
+    for p in ref.parallel_branch.parameters():
+        p.requires_grad_(True)
+    ref.ws_weights.requires_grad_(True)
+    ref.encoder.feature_grad_mult = 0.1
+    wavs = [batch["wav"][b, :int(batch["wav_len"][b])] for b in range(4)]
+    padded, mask = HR.preprocess_input(wavs, ref.hubert_cfg.normalize)
+    with torch.enable_grad():
+        hidden = HR.hubert_forward.__wrapped__(ref.encoder, padded, mask)["layer_results"]
+        flen = HR.feat_lengths([len(w) for w in wavs], 320, hidden[-1].shape[1])
+        pa = R.l2_normalize(ref.parallel_branch(R.weighted_sum(hidden, ref.ws_weights, False), flen))
+        with torch.no_grad():
+            img = R.l2_normalize(ref.clip.encode_image(batch["image"]))
+        ref_loss = R.masked_contrastive_loss(pa, img, batch["id"], ref.inv_temperature)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 2e-2
+    mine = dict(model.named_parameters())
+    checked, worst = 0, (1.0, "")
+    for k, p in ref.encoder.named_parameters():
+        if not p.requires_grad:
+            assert mine["audio_encoder.encoder." + k].grad is None, k
+            continue
+        got = mine["audio_encoder.encoder." + k].grad
+        assert got is not None and p.grad is not None, k
+        if p.grad.norm().item() < 1e-7:
+            assert got.norm().item() < 1e-4, k
+            continue
+        c, ratio = _cos(got, p.grad), got.norm().item() / p.grad.norm().item()
+        worst = min(worst, (c, k))
+        assert c > 0.97 and abs(ratio - 1) < 0.12, (k, c, ratio)
+        checked += 1
+    print("full-encoder gradients checked:", checked, "worst cosine:", worst)
+    assert checked >= 18 + 3 * 12
+    assert _cos(mine["audio_encoder.weightedsum_layer.weights"].grad, ref.ws_weights.grad) > 0.98
+
+
+def test_short_full_encoder_run_lowers_the_loss_and_moves_the_conv_stack():
+    model, _, batch = _finetune_pair([], everything=True)
+    model = model.cuda().train()
+    batch = {k: v.cuda() for k, v in batch.items()}
+    model.config.audio_encoder.optim.args.lr = 3e-4
+    model.config.audio_encoder.scheduler.warmup = 1
+    (opt,), (sch,) = model.configure_optimizers()
+    conv3 = getattr(model.audio_encoder.encoder.feature_extractor.conv_layers[3], "0").weight
+    pos_v = getattr(model.audio_encoder.encoder.encoder.pos_conv, "0").weight_v
+    c0, v0 = conv3.detach().clone(), pos_v.detach().clone()
+    with torch.no_grad():
+        model.eval()
+        before = model(batch)[0]["parallel_audio_feat"].clone()
+        model.train()
+    losses = []
+    torch.manual_seed(0)
+    for step in range(20):
+        opt.zero_grad()
+        loss = model.training_step_end(model.training_step(batch, step))["loss"]
+        loss.backward()
+        opt.step()
+        sch["scheduler"].step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and np.mean(losses[-4:]) < 0.8 * np.mean(losses[:3]), losses
+    assert not torch.equal(c0, conv3.detach()) and not torch.equal(v0, pos_v.detach())
+    model.eval()
+    with torch.no_grad():
+        after = model(batch)[0]["parallel_audio_feat"]
+    assert (after - before).abs().max().item() > 1e-3           # the eval engine repacked the trained front-end weights (parameter epoch)
 
 
 def test_short_finetuning_run_moves_the_encoder_layer_and_the_eval_path_sees_it():

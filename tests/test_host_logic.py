@@ -518,8 +518,16 @@ def test_encoder_fine_tuning_flags_follow_the_reference():
     assert not torch.equal(l2b.fc1.weight, l2r.fc1.weight) and torch.equal(base.encoder.encoder.layers[1].fc1.weight, re.encoder.encoder.layers[1].fc1.weight)
     assert float(l2r.fc1.bias.abs().max()) == 0.0 and abs(float(l2r.fc1.weight.std()) - 0.02) < 2e-3
     assert len(base.trainable_params()) == 1 and not any(p.requires_grad for p in base.encoder.parameters())
+    # bare trainable=True (speech_encoder_plus.py:399-401): nothing is frozen; the extractor keeps the checkpoint's feature_grad_mult
+    full = FairseqSpeechEncoder_Hubert("hubert", trainable=True, feat_select_idx="weighted_sum", hubert_config=hc)
+    on = {k for k, p in full.encoder.named_parameters() if p.requires_grad}
+    assert full.train_front and full.train_layers == [0, 1, 2] and full.encoder.feature_grad_mult == 0.1
+    assert {"feature_extractor.conv_layers.0.0.weight", "feature_extractor.conv_layers.0.2.weight", "feature_extractor.conv_layers.6.0.weight", "layer_norm.bias",
+            "post_extract_proj.weight", "encoder.pos_conv.0.weight_g", "encoder.pos_conv.0.weight_v", "encoder.layer_norm.weight",
+            "encoder.layers.0.fc1.weight"} <= on and "mask_emb" not in on and len(on) == 18 + 3 * 16
+    large = HubertConfig(**dataclasses.asdict(HubertRefConfig.tiny(layer_norm_first=True, extractor_mode="layer_norm", conv_bias=True)))
     with pytest.raises(NotImplementedError):
-        FairseqSpeechEncoder_Hubert("hubert", trainable=True, hubert_config=hc)                      # would also train the conv stack: not built
+        FairseqSpeechEncoder_Hubert("hubert_large_ll60k", trainable=True, hubert_config=large)      # pre-LN / LayerNorm-extractor model: not built
     with pytest.raises(AssertionError):
         FairseqSpeechEncoder_Hubert("hubert", trainable=False, unfreeze_layers=[1], hubert_config=hc)
     with pytest.raises(AssertionError):
