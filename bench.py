@@ -65,7 +65,7 @@ def algorithmic_gflop_per_pair(L=160000, d=768, ffn=3072, layers=12, vit_w=768, 
 LARGE = dict(d=1024, ffn=4096, layers=24, vit_w=1024, vit_layers=24, patch=14, E=768)   # HuBERT-large + ViT-L/14 (BASELINE configs[4])
 
 
-def build_model(seed=7122, large=False, cascaded=False, vocab=8112, finetune_layers=()):
+def build_model(seed=7122, large=False, cascaded=False, vocab=8112, finetune_layers=(), finetune_all=False):
     from speechclip_amd.util.shipped_configs import make_config
     from speechclip_amd.model import KWClip_GeneralTransformer
     torch.manual_seed(seed)
@@ -85,7 +85,9 @@ def build_model(seed=7122, large=False, cascaded=False, vocab=8112, finetune_lay
                           temperature_trainable=True)
     else:
         cfg = make_config()
-    if finetune_layers:
+    if finetune_all:          # audio_encoder.trainable: true with no layer lists: the whole encoder trains (speech_encoder_plus.py:399-401)
+        cfg.audio_encoder.trainable = True
+    elif finetune_layers:
         cfg.audio_encoder.trainable = True
         cfg.audio_encoder.unfreeze_layers = [int(i) for i in finetune_layers]
     return KWClip_GeneralTransformer(cfg).eval()
@@ -295,6 +297,8 @@ def main():
                     "+ grad all-reduce + clip + Adam + LR schedule); not the headline metric, reported with config.mode = 'train'")
     ap.add_argument("--finetune-layers", type=int, nargs="*", default=[], help="with --train: also fine-tune these HuBERT transformer layers "
                     "(unfreeze_layers of the reference, speech_encoder_plus.py:431-446); informational, not a BASELINE config")
+    ap.add_argument("--finetune-all", action="store_true", help="with --train: audio_encoder.trainable: true -- conv extractor, positional conv and all "
+                    "transformer layers train too; informational")
     ap.add_argument("--vocab", type=int, default=8112, help="--model cascaded: sub-word table size (8112 = the shipped reduced vocabulary, "
                     "spchclp_c.yaml:94; 49408 = the full table)")
     ap.add_argument("--no-vendor-comparator", action="store_true", help="skip the hipBLASLt comparator run beside the headline")
@@ -331,7 +335,7 @@ def main():
     if args.batch is None:
         args.batch = 64 if large else 256
     casc = args.model == "cascaded"
-    model = build_model(large=large, cascaded=casc, vocab=args.vocab, finetune_layers=args.finetune_layers if args.train else [])
+    model = build_model(large=large, cascaded=casc, vocab=args.vocab, finetune_layers=args.finetune_layers if args.train else [], finetune_all=args.finetune_all and args.train)
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_pairs > 0 and world == 1 and not args.train and not large and not casc) else None
     model = model.to(dev)
     B, L = args.batch, args.audio_len
@@ -499,7 +503,7 @@ def main():
                           + " forward + InfoNCE, 10 s/16 kHz audio + 224^2 images",
                           "pairs_per_gpu": B, "global_batch": world * B, "audio_samples": L_eff, "frames": conv_lens(L_eff)[-1],
                           "parallelism": f"dp{world}" if world > 1 else "single", "weights": "random-init (no network)",
-                          "algorithmic_gflop_per_pair": round(total_gf, 2), "mode": ("train (tail: branch + layer-mix weights%s)" % (" + HuBERT layers %s" % args.finetune_layers if args.finetune_layers else "")) if args.train else "forward + loss"},
+                          "algorithmic_gflop_per_pair": round(total_gf, 2), "mode": ("train (tail: branch + layer-mix weights%s)" % (" + the whole HuBERT encoder" if args.finetune_all else " + HuBERT layers %s" % args.finetune_layers if args.finetune_layers else "")) if args.train else "forward + loss"},
                "e2e_tflops_per_gpu": round(total_gf * 1e9 * pairs_per_s / world / 1e12, 1),
                "e2e_frac_of_bf16_peak": round(total_gf * 1e9 * pairs_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
                "rccl_ranks_seen": int(seen.item()), "exchange_ms_per_step": exchange_ms,

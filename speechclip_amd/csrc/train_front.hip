@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ beta, const bf16_t* __restrict__ dy, float* __restrict__ part, int C, int T0,
                                                         int P, float eps) {
     __shared__ float red[4][64][12];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y, c = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the frame index below is wave-uniform,
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lane;                                            // so the ten wave samples of a frame are scalar loads
     const float* wv = wav + (int64_t)b * ld;
     float wk[C0_K];
 #pragma unroll
@@ -102,15 +102,20 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
     };
     float x[C0_K];
     float acc[12];
-    // (A) two-pass statistics (mean first, then centred second moment: the frames of a 10 s wave sum to ~3e4 terms)
-    acc[0] = 0.f;
-    for (int t = wave; t < T0; t += 4) acc[0] += conv_at(t, x);
-    block_sum(acc, 1);
-    const float mean = acc[0] / (float)T0;
-    acc[0] = 0.f;
-    for (int t = wave; t < T0; t += 4) { const float d = conv_at(t, x) - mean; acc[0] = fmaf(d, d, acc[0]); }
-    block_sum(acc, 1);
-    const float rstd = rsqrtf(acc[0] / (float)T0 + eps);
+    // (A) statistics in ONE sweep: sum and sum of squares in fp64 (the frames of a 10 s wave are ~3e4 terms; E[u^2] - E[u]^2 in fp32 would
+    // lose the variance of a channel with a DC offset)
+    double su = 0.0, sq = 0.0;
+    for (int t = wave; t < T0; t += 4) { const double v = (double)conv_at(t, x); su += v; sq += v * v; }
+    {
+        __shared__ double dred[4][64][2];
+        dred[wave][lane][0] = su; dred[wave][lane][1] = sq;
+        __syncthreads();
+        su = (dred[0][lane][0] + dred[1][lane][0]) + (dred[2][lane][0] + dred[3][lane][0]);
+        sq = (dred[0][lane][1] + dred[1][lane][1]) + (dred[2][lane][1] + dred[3][lane][1]);
+    }
+    const double mean_d = su / (double)T0;
+    const float mean = (float)mean_d;
+    const float rstd = rsqrtf((float)(sq / (double)T0 - mean_d * mean_d) + eps);
     const float gm = gamma[c], bt = beta[c];
     const bf16_t* dyb = dy + (int64_t)b * P * C + c;
     // (B)
