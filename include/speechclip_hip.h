@@ -121,6 +121,16 @@ int sc_wave_layernorm(const float* wav, float* out, const int32_t* lens, int B, 
 int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H,
                      int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, int causal, void* stream);
 
+/* Train-mode dropouts of the FROZEN encoder: Lightning's model.train() re-enables them while the reference trains the pooling heads
+ * (avssl/module/speech_encoder_plus.py:42 F.dropout after the positional conv, :87 dropout_input; [3P fairseq] TransformerSentenceEncoderLayer
+ * dropout1 / dropout2 / dropout3 and MultiheadAttention's dropout on the probabilities).  Masks are counter-based: element i of a tensor is kept iff
+ * hash(seed, i) >= drop_p * 2^32, and scaled by 1 / (1 - drop_p).
+ *   sc_attention_fwd_dropout: sc_attention_fwd with dropout on the attention probabilities (the softmax row sum keeps every probability).
+ *   sc_dropout_bf16: out = [residual +] dropout(x) over n bf16 elements (n % 4 == 0); in place allowed. */
+int sc_attention_fwd_dropout(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H, int T, int head_dim,
+                             int64_t ld_qkv, int64_t ld_out, float scale, int causal, float drop_p, uint32_t seed, void* stream);
+int sc_dropout_bf16(const void* x, const void* residual, void* out, int64_t n, float drop_p, uint32_t seed, void* stream);
+
 /* CLS-rows-only attention of the pooling heads (kwClip.py:1089-1099 parallel, :869-881 cascaded):
  * NQ learned query tokens attend to [NQ CLS tokens ; frames t < lens[b]].  cls_qkv: bf16 [NQ, 3*D]
  * (q|k|v of the CLS tokens); kv_x: bf16 rows (b*T+t) = [k | v] of the frames, stride ld_kv;

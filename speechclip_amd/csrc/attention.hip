@@ -41,11 +41,12 @@ __device__ __forceinline__ int swz_k(int row) { return SC_ATTN_KSWZ ? ((row >> 1
 
 __device__ unsigned long long* g_attn_trace = nullptr;   // debug: per-block phase cycles (sc_debug_set_attn_trace)
 
-template <int NW, bool TRACE>   // waves per block: NW x 32 query rows share one K/V ring (4: 128 rows, 8: 256 rows -- half the K/V traffic, 4 waves per SIMD)
+template <int NW, bool TRACE, bool DROP = false>   // DROP: attention-probability dropout (train-mode frozen encoder, sc_attention_fwd_dropout); waves per block: NW x 32 query rows share one K/V ring (4: 128 rows, 8: 256 rows -- half the K/V traffic, 4 waves per SIMD)
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
                                                        const int32_t* __restrict__ klens, int T, int64_t ld_qkv,
-                                                       int64_t ld_out, float scale_log2e, int causal, int B, int H, int nq, int n_ids, int ipb) {
+                                                       int64_t ld_out, float scale_log2e, int causal, int B, int H, int nq, int n_ids, int ipb,
+                                                       uint32_t drop_seed, uint32_t drop_thresh_, float drop_keep_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NSTAGE x (K 8 KiB + V 8 KiB)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -226,6 +227,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 #else
                 const f32x2_t p2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
 #endif
+                if (DROP) {
+                    // torch: attn = dropout(softmax(s)) -- the row sum keeps every probability, the P.V product sees the masked, rescaled ones.
+                    // element index = ((b*H + h)*T + query)*T + key; this lane's register r holds key kv0 + kb*32 + (r & 3) + 8*(r >> 2) + 4*g
+                    const uint32_t e0 = (uint32_t)(((int64_t)(b * H + h) * T + qrow_c) * T) + (uint32_t)(kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g);
+                    const float d0 = keep_elem(drop_seed, e0, drop_thresh_) ? p2[0] * drop_keep_scale : 0.f;
+                    const float d1 = keep_elem(drop_seed, e0 + 1, drop_thresh_) ? p2[1] * drop_keep_scale : 0.f;
+                    ppk[kb][r >> 1] = pack2bf(d0, d1);
+                } else
                 ppk[kb][r >> 1] = pack2bf(p2[0], p2[1]);       // P leaves the fp32 registers right here: 16 VGPRs instead of 32 through the PV phase
                 psum2 += p2;
             }
@@ -487,11 +496,13 @@ extern "C" void sc_debug_set_attn_trace(void* dev_buf) {     // per-block [8] u6
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &p, sizeof(p));
 }
 
-extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H,
-                                int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, int causal, void* stream) {
+static int attention_fwd_impl(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H, int T, int head_dim,
+                              int64_t ld_qkv, int64_t ld_out, float scale, int causal, float drop_p, uint32_t seed, void* stream) {
     SC_CHECK_ARG(head_dim == 64, "sc_attention_fwd: head_dim=%d unsupported (64 only; use sc_cls_attention_fwd for pooling heads)", head_dim);
     SC_CHECK_ARG(ld_qkv % 8 == 0 && ld_out % 4 == 0, "sc_attention_fwd: ld_qkv must be a multiple of 8, ld_out of 4");
     SC_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "sc_attention_fwd: misaligned pointers");
+    SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_attention_fwd_dropout: drop_p=%f must be in [0, 1)", (double)drop_p);
+    SC_CHECK_ARG(drop_p == 0.f || (int64_t)B * H * T * T < 0xffffffffLL, "sc_attention_fwd_dropout: B*H*T*T must fit 32 bits (mask element index)");
     if (B <= 0 || T <= 0) return 0;
     constexpr int lds = NSTAGE * STAGE_BYTES;
     // 8-wave blocks (256 query rows share the K/V ring) when there are at least 256 queries; SC_ATTN_NW=4 forces the 4-wave form
@@ -507,18 +518,34 @@ extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, voi
     ipb = ipb < 1 ? 1 : (ipb > 16 ? 16 : ipb);
     const int groups8 = (n_ids / 8 + ipb - 1) / ipb;           // n_ids is a multiple of 8
     dim3 grid((unsigned)(groups8 * 8));
-#define ATTN_LAUNCH(NW_, TR_)                                                                                                               \
+    const uint32_t th = drop_thresh(drop_p);
+    const float ks = 1.0f / (1.0f - drop_p);
+#define ATTN_LAUNCH(NW_, TR_, DR_)                                                                                                          \
     do {                                                                                                                                    \
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NW_, TR_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                 \
-        hipLaunchKernelGGL((attn_fwd_kernel<NW_, TR_>), grid, dim3(NW_ * 64), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, \
-                           (const bf16_t*)v, (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq, n_ids, ipb); \
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NW_, TR_, DR_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);            \
+        hipLaunchKernelGGL((attn_fwd_kernel<NW_, TR_, DR_>), grid, dim3(NW_ * 64), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, \
+                           (const bf16_t*)v, (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq, n_ids, ipb, \
+                           seed, th, ks);                                                                                                   \
     } while (0)
-    if (g_attn_trace_host) { if (nw == 8) ATTN_LAUNCH(8, true); else ATTN_LAUNCH(4, true); }
-    else if (nw == 8) ATTN_LAUNCH(8, false);
-    else ATTN_LAUNCH(4, false);
+    if (th) { if (nw == 8) ATTN_LAUNCH(8, false, true); else ATTN_LAUNCH(4, false, true); }
+    else if (g_attn_trace_host) { if (nw == 8) ATTN_LAUNCH(8, true, false); else ATTN_LAUNCH(4, true, false); }
+    else if (nw == 8) ATTN_LAUNCH(8, false, false);
+    else ATTN_LAUNCH(4, false, false);
 #undef ATTN_LAUNCH
     SC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H,
+                                int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, int causal, void* stream) {
+    return attention_fwd_impl(q, k, v, out, klens, B, H, T, head_dim, ld_qkv, ld_out, scale, causal, 0.f, 0u, stream);
+}
+
+// Train-mode attention of the FROZEN encoder: the same kernel with dropout on the attention probabilities (fairseq MultiheadAttention
+// dropout_module, attention_dropout of the checkpoint) -- Lightning's model.train() switches the frozen HuBERT's dropouts on too.
+extern "C" int sc_attention_fwd_dropout(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H, int T, int head_dim,
+                                        int64_t ld_qkv, int64_t ld_out, float scale, int causal, float drop_p, uint32_t seed, void* stream) {
+    return attention_fwd_impl(q, k, v, out, klens, B, H, T, head_dim, ld_qkv, ld_out, scale, causal, drop_p, seed, stream);
 }
 
 extern "C" int sc_cls_attention_fwd(const void* cls_qkv, const void* kv_x, int64_t ld_kv, const int32_t* lens, void* out, int B, int T,

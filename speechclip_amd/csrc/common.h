@@ -74,6 +74,14 @@ __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
     return x * (xc * g + 0.5f);
 }
 __device__ __forceinline__ float gelu_erf_precise(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+// Counter-based dropout masks: element idx of a tensor is kept iff hash(seed, idx) >= thresh (thresh = p * 2^32); the backward regenerates the
+// mask from (seed, idx) instead of storing it.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool keep_elem(uint32_t seed, uint32_t idx, uint32_t thresh) { return hash32(seed ^ hash32(idx + 0x9e3779b9U)) >= thresh; }
+static inline uint32_t drop_thresh(float pd) { return pd <= 0.f ? 0u : (uint32_t)fmin(4294967295.0, (double)pd * 4294967296.0); }
 // CLIP QuickGELU: x * sigmoid(1.702 x)
 __device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 

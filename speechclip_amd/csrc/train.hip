@@ -10,13 +10,7 @@
 
 namespace {
 
-__device__ __forceinline__ uint32_t hash32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
-// keep-mask of element idx for a given (seed, drop probability as a 32-bit threshold)
-__device__ __forceinline__ bool keep_elem(uint32_t seed, uint32_t idx, uint32_t thresh) { return hash32(seed ^ hash32(idx + 0x9e3779b9U)) >= thresh; }
-__host__ uint32_t drop_thresh(float pd) { return pd <= 0.f ? 0u : (uint32_t)fmin(4294967295.0, (double)pd * 4294967296.0); }
+// (hash32 / keep_elem / drop_thresh: common.h)
 
 // ------------------------------------------------------------------------------------------------ CLS pooling, training forward
 // as cls_pool_kernel (attention.hip) but fp32 outputs, the probabilities are kept for the backward and attention dropout is applied.

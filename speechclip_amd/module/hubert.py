@@ -43,6 +43,12 @@ class HubertConfig:
     conv_pos_groups: int = 16
     normalize: bool = False              # fairseq task.cfg.normalize (per-utterance wave layer-norm)
     feature_grad_mult: float = 0.1       # [3P fairseq hubert_base_librispeech: 0.1; hubert_large_librivox: 1.0]: scale of the gradient entering the conv extractor
+    # the checkpoint's dropouts [3P fairseq hubert_base_librispeech; hubert_large_librivox has 0 everywhere]: applied by the FROZEN encoder too while
+    # the module is in train mode (speech_encoder_plus.py:42, :87 and the layers' dropout modules)
+    dropout: float = 0.1
+    attention_dropout: float = 0.1
+    activation_dropout: float = 0.0
+    dropout_input: float = 0.1
     encoder_layerdrop: float = 0.05      # the checkpoint's own rate [3P fairseq hubert_base_librispeech: 0.05, hubert_large_librivox: 0.0]; used
                                          # only with audio_encoder.layer_drop: "original" (speech_encoder_plus.py:411-412)
 
@@ -53,7 +59,8 @@ class HubertConfig:
         if name == "hubert_large_ll60k":
             return HubertConfig(extractor_mode="layer_norm", conv_bias=True, encoder_layers=24, encoder_embed_dim=1024,
                                 encoder_ffn_embed_dim=4096, encoder_attention_heads=16, layer_norm_first=True, normalize=True,
-                                encoder_layerdrop=0.0, feature_grad_mult=1.0)
+                                encoder_layerdrop=0.0, feature_grad_mult=1.0, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+                                dropout_input=0.0)
         raise KeyError(name)
 
 
@@ -268,11 +275,19 @@ class HubertModel(nn.Module):
         return d % 256 == 0 and B * Tp >= 256 and self.cfg.encoder_ffn_embed_dim >= 256
 
     @torch.no_grad()
-    def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int], fold_ln: bool = False, stop_layer: int = None, drop_layers=()):
+    def dropout_rates(self):
+        c = self.cfg
+        return dict(features=float(c.dropout_input), hidden=float(c.dropout), attention=float(c.attention_dropout), activation=float(c.activation_dropout))
+
+    def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int], fold_ln: bool = False, stop_layer: int = None, drop_layers=(),
+                           dropout_seed: int = None):
         """wav: f32 [B, Lmax] device tensor (right zero-padded); lens: host ints.
         Returns (hidden [n_layers+1, B, Tp, d] (bf16 for post-LN, f32 for pre-LN), T, Tp, valid_frames); with `stop_layer` = L only
         hidden[0..L] are computed.  `drop_layers` (layerdrop, speech_encoder_plus.py:49-53): the listed layers are skipped and leave NO entry
         in the result -- hidden has 1 + (layers run) states, as the reference's `layer_results`.
+        `dropout_seed` (train mode of the FROZEN encoder, post-LN models): the checkpoint's dropouts are applied -- dropout_input on the projected
+        features, `dropout` after the positional conv + LayerNorm and after out_proj / fc2 (before the residual add), attention_dropout on the
+        probabilities, activation_dropout after the GELU; masks are counter-based, one stream per site derived from the seed.
         fold_ln (caller checked fold_ln_supported): returns ((h0 [M,d], ypre [n_layers, M, d], gamma2, beta2), T, Tp, valid) instead -- layer 0's
         normalised state and the PRE-LayerNorm outputs of the layers with the affines of their final LayerNorms (ops.weighted_sum_ln mixes them)."""
         cfg = self.cfg
@@ -316,6 +331,20 @@ class HubertModel(nn.Module):
         # ---- feature LayerNorm + projection
         feats = ops.layernorm(x[:M], *P["feat_ln"], out=self._buf("feat_ln", (M, C), bf, dev))
         xp = ops.gemm(feats, P["proj_w"], P["proj_b"], out=self._buf("proj", (M, d), bf, dev))
+        rates = self.dropout_rates() if dropout_seed is not None else None
+        if rates is not None and any(v > 0 for v in rates.values()):
+            if cfg.layer_norm_first:
+                raise NotImplementedError("train-mode dropout inside a pre-LN encoder is not built (the released large checkpoint has all rates 0)")
+            assert not fold_ln
+        else:
+            rates = None
+        site = [int(dropout_seed) & 0x7fffffff if dropout_seed is not None else 0]
+
+        def next_seed():       # one mask stream per dropout site, in forward order
+            site[0] = (site[0] * 1103515245 + 12345) & 0x7fffffff
+            return site[0]
+        if rates and rates["features"] > 0:
+            ops.dropout_bf16(xp, rates["features"], next_seed(), out=xp)                      # dropout_input (speech_encoder_plus.py:87)
         # ---- frame mask, positional conv (+ LN for post-LN models)
         valid = self.valid_frames(lens, lmax, T)
         valid_i32 = ops.dev_ints(valid, torch.int32, dev)
@@ -325,6 +354,8 @@ class HubertModel(nn.Module):
         hidden = self._buf("hidden0", (1, M, d), hid_dtype, dev) if fold_ln else self._buf("hidden", (nl + 1, M, d), hid_dtype, dev)
         g, bta = (None, None) if pre_ln else P["enc_ln"]
         ops.posconv(xp, valid_i32, P["pos_w"], P["pos_b"], g, bta, B, Tp, d, cfg.conv_pos_groups, cfg.conv_pos, out=hidden[0])
+        if rates and rates["hidden"] > 0:
+            ops.dropout_bf16(hidden[0], rates["hidden"], next_seed(), out=hidden[0])            # F.dropout before the layers (:42); layer_results[0] is the dropped state
         # ---- transformer layers
         H = cfg.encoder_attention_heads
         qkv = self._buf("qkv", (M, 3 * d), bf, dev)
@@ -377,7 +408,19 @@ class HubertModel(nn.Module):
                 continue
             h, h_out = hidden[kept], hidden[kept + 1]
             kept += 1
-            if not pre_ln:
+            if not pre_ln and rates:      # [3P fairseq] TransformerSentenceEncoderLayer in train mode: x = LN(x + dropout1(attn(x))); x = LN(x + dropout3(fc2(dropout2(act(fc1 x)))))
+                ops.gemm(h, L["wqkv"], L["bqkv"], out=qkv)
+                ops.attention_dropout(qkv, B, Tp, H, valid_i32, rates["attention"], next_seed(), out=att)
+                ops.gemm(att, L["wo"], L["bo"], out=tmp)
+                ops.dropout_bf16(tmp, rates["hidden"], next_seed(), residual=h, out=tmp)
+                ops.layernorm(tmp, *L["ln1"], out=tmp2)
+                ops.gemm(tmp2, L["w1"], L["b1"], ACT_GELU, out=ffn)
+                if rates["activation"] > 0:
+                    ops.dropout_bf16(ffn, rates["activation"], next_seed(), out=ffn)
+                ops.gemm(ffn, L["w2"], L["b2"], out=tmp)
+                ops.dropout_bf16(tmp, rates["hidden"], next_seed(), residual=tmp2, out=tmp)
+                ops.layernorm(tmp, *L["ln2"], out=h_out)
+            elif not pre_ln:
                 ops.gemm(h, L["wqkv"], L["bqkv"], out=qkv)
                 ops.attention(qkv, B, Tp, H, valid_i32, out=att)
                 ops.gemm(att, L["wo"], L["bo"], residual=h, out=tmp)

@@ -188,6 +188,12 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         draws = np.random.random(nl_)
         rate = float(self.encoder.encoder.layerdrop)
         drop = tuple(i for i in range(nl_) if self.training and not (draws[i] > rate))
+        # train mode of the module = train mode of the frozen encoder's dropouts too (Lightning's model.train(); speech_encoder_plus.py:42, :87 and
+        # the fairseq layers' dropout modules).  One seed per forward from torch's generator; SC_FROZEN_DROPOUT=0 keeps the eval arithmetic.
+        drop_seed = None
+        if self.training and os.environ.get("SC_FROZEN_DROPOUT", "1") != "0" and any(v > 0 for v in self.encoder.dropout_rates().values()) \
+                and not self.encoder.cfg.layer_norm_first:
+            drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         # Eval fast path: nobody asked for the hidden states themselves (only their mix), so the LayerNorms are folded into the GEMMs around
         # them and the layer mix rebuilds each state from its pre-norm rows (module/hubert.py: fold_ln).  The states are materialised when they
         # are returned, selected by index, or needed by the training tail's layer-mix gradient.
@@ -197,15 +203,15 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if drop and feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             # WeightedSumLayer.forward asserts one weight per hidden state (weighted_sum.py:36): the reference fails here too
             raise AssertionError(self.upstream_model_hiddenstates_len - len(drop))
-        if mix_only and not drop and self.encoder.fold_ln_supported(padded.shape[0], padded.shape[1]):
+        if mix_only and not drop and drop_seed is None and self.encoder.fold_ln_supported(padded.shape[0], padded.shape[1]):
             (h0, ypre, g2, b2), T, Tp, _valid = self.encoder.extract_all_layers(padded, lens, fold_ln=True)
             B_, d_ = padded.shape[0], h0.shape[-1]
             mixed = ops.weighted_sum_ln(h0, ypre, g2, b2, self.weightedsum_layer.weights.detach().float()).view(B_, Tp, d_)[:, :T]
             feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()
             return (mixed, feat_len)
         if self.train_layers and torch.is_grad_enabled():
-            return self._forward_finetune(padded, lens, feat_select_idx, return_hidden_states)
-        hidden, T, Tp, _valid = self.encoder.extract_all_layers(padded, lens, drop_layers=drop)      # [n, B, Tp, d]
+            return self._forward_finetune(padded, lens, feat_select_idx, return_hidden_states, drop_seed)
+        hidden, T, Tp, _valid = self.encoder.extract_all_layers(padded, lens, drop_layers=drop, dropout_seed=drop_seed)      # [n, B, Tp, d]
         # speech_encoder_plus.py:604-611: Python round() (banker's) of len / 320, clamped to T
         feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()   # escapes to the caller
         layers = lambda: tuple(hidden[i, :, :T] for i in range(hidden.shape[0]))  # noqa: E731
@@ -234,7 +240,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         return tuple(out)
 
 
-def _forward_finetune(self, padded, lens, feat_select_idx, return_hidden_states):
+def _forward_finetune(self, padded, lens, feat_select_idx, return_hidden_states, drop_seed=None):
     """Training forward with encoder layers L0.. as ONE autograd node (train_hubert.HubertLayersTrainFn): the frozen part below the lowest
     trainable layer runs on the eval path, the layer mix carries the gradient to the hidden states (WeightedSumTrainFn)."""
     from ..train_hubert import HubertLayersTrainFn, WeightedSumTrainFn, layer_params
@@ -254,7 +260,8 @@ def _forward_finetune(self, padded, lens, feat_select_idx, return_hidden_states)
         h_front = HubertFrontTrainFn.apply(fmeta, padded.contiguous(), ops.dev_ints(valid, torch.int32, dev), *front_params(enc))      # [B*Tp, d]
         hidden = None
     else:
-        hidden, T, Tp, valid = enc.extract_all_layers(padded, lens, stop_layer=L0)        # hidden[0 .. L0] are valid
+        # (the frozen layers below L0 get the train-mode dropouts; the autograd nodes of the TRAINED part run without them: DESIGN.md section 6)
+        hidden, T, Tp, valid = enc.extract_all_layers(padded, lens, stop_layer=L0, dropout_seed=drop_seed)        # hidden[0 .. L0] are valid
     M = B * Tp
     params = []
     for i in range(L0, nl):

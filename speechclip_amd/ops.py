@@ -234,6 +234,28 @@ def attention(qkv, B, T, H, klens_i32=None, out=None, scale=None, causal=False):
     return out
 
 
+def attention_dropout(qkv, B, T, H, klens_i32, drop_p, seed, out=None):
+    """ops.attention with dropout on the attention probabilities (train-mode frozen encoder); drop_p == 0 is the plain kernel."""
+    _need_cuda(qkv)
+    D = H * 64
+    assert qkv.dtype == bf16 and qkv.shape == (B * T, 3 * D) and qkv.is_contiguous()
+    if out is None:
+        out = torch.empty(B * T, D, device=qkv.device, dtype=bf16)
+    check(lib().sc_attention_fwd_dropout(qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2, ptr(out), ptr(klens_i32), B, H, T, 64,
+                                         3 * D, D, 0.125, 0, float(drop_p), int(seed) & 0xffffffff, stream()), "sc_attention_fwd_dropout")
+    return out
+
+
+def dropout_bf16(x, drop_p, seed, residual=None, out=None):
+    """out = [residual +] dropout(x) (bf16, counter-based mask from `seed`); out=x runs in place."""
+    _need_cuda(x)
+    assert x.dtype == bf16 and x.is_contiguous() and (residual is None or (residual.dtype == bf16 and residual.is_contiguous() and residual.shape == x.shape))
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().sc_dropout_bf16(ptr(x), ptr(residual), ptr(out), x.numel(), float(drop_p), int(seed) & 0xffffffff, stream()), "sc_dropout_bf16")
+    return out
+
+
 def attention_rows(qkv, B, L, H, hd, key_padding_mask=None, scale=None):
     """Full-row MHA for any head dim: qkv bf16 [B*L, 3*H*hd] packed (q|k|v); key_padding_mask bool/uint8 [B, L] (True = padding) or None.
     Returns bf16 [B*L, H*hd] (heads concatenated, before out_proj)."""
