@@ -338,6 +338,11 @@ int sc_conv0_bwd(const float* wav, int64_t ld, const float* w, const float* gamm
                  int P, float eps, void* stream);
 int sc_attn_softmax_bwd(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
                         int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch, float scale, void* stream);
+/* sc_attn_softmax_bwd for a forward that ran sc_attention_fwd_dropout with (drop_p, seed): P comes out masked and rescaled (dV = P^T dO sees the
+ * dropped probabilities), dP is masked before the softmax backward; batch z = utterance b, head h of H (the forward's mask index). */
+int sc_attn_softmax_bwd_dropout(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
+                                int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch, float scale, float drop_p,
+                                uint32_t seed, int H, int h, void* stream);
 int sc_gelu_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, void* stream);
 int64_t sc_layernorm_bwd_bf16_partials(int64_t rows);
 int sc_layernorm_bwd_bf16(const void* x, const void* dy, const float* gamma, void* dx, float* part, int64_t rows, int D, float eps, void* stream);

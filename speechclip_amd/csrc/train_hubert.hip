@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ S, const float* __restrict__ dP, int64_t ld, int64_t stride,
                                                                const bf16_t* __restrict__ dO, int64_t ld_do, const bf16_t* __restrict__ O, int64_t ld_o,
                                                                int64_t row_stride_z, const int32_t* __restrict__ klens, bf16_t* __restrict__ P,
-                                                               bf16_t* __restrict__ dS, int L, int Lp, float scale) {
+                                                               bf16_t* __restrict__ dS, int L, int Lp, float scale, uint32_t drop_seed,
+                                                               uint32_t drop_thresh_, float keep_scale, uint32_t elem_base, uint32_t elem_stride_z) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), z = blockIdx.y;
     if (i >= Lp) return;
@@ -65,7 +66,15 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
         float p = 0.f, ds = 0.f;
         if (j < klen) {
             p = __expf(srow[j] * scale - mx) * inv;
-            ds = p * (gprow[j] - dd) * scale;
+            float gp = gprow[j];
+            if (drop_thresh_) {      // attention dropout of the forward (sc_attention_fwd_dropout): the same mask, element = elem_base + z * stride + i * L + j.
+                // dP = m dP_dropped, P_dropped = m P (what dV = P_dropped^T dO multiplies); sum_k P_ik dP_ik = dO_i . O_i still holds
+                const float m = keep_elem(drop_seed, elem_base + (uint32_t)z * elem_stride_z + (uint32_t)i * (uint32_t)L + (uint32_t)j, drop_thresh_) ? keep_scale : 0.f;
+                gp *= m;
+                ds = p * (gp - dd) * scale;
+                p *= m;
+            } else
+            ds = p * (gp - dd) * scale;
         }
         prow[j] = f2bf(p);
         drow[j] = f2bf(ds);
@@ -184,13 +193,29 @@ extern "C" int sc_transpose_bf16(const void* in, int64_t ld_in, int64_t stride_i
     return 0;
 }
 
-extern "C" int sc_attn_softmax_bwd(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
-                                   int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch, float scale, void* stream) {
+static int attn_softmax_bwd_impl(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
+                                 int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch, float scale, float drop_p,
+                                 uint32_t seed, int H, int h, void* stream) {
     SC_CHECK_ARG(S && dP && dO && O && P && dS && L > 0 && Lp >= L && batch > 0 && batch <= 65535 && ld >= Lp, "sc_attn_softmax_bwd: bad arguments");
+    SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && H >= 1 && h >= 0 && h < H, "sc_attn_softmax_bwd_dropout: bad dropout arguments");
+    // forward element index = ((b*H + h)*L + i)*L + j with b = z
     hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((Lp + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, S, dP, ld, stride, (const bf16_t*)dO, ld_do,
-                       (const bf16_t*)O, ld_o, rows_per_batch, klens, (bf16_t*)P, (bf16_t*)dS, L, Lp, scale);
+                       (const bf16_t*)O, ld_o, rows_per_batch, klens, (bf16_t*)P, (bf16_t*)dS, L, Lp, scale, seed, drop_thresh(drop_p), 1.0f / (1.0f - drop_p),
+                       (uint32_t)h * (uint32_t)L * (uint32_t)L, (uint32_t)H * (uint32_t)L * (uint32_t)L);
     SC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sc_attn_softmax_bwd(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
+                                   int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch, float scale, void* stream) {
+    return attn_softmax_bwd_impl(S, dP, ld, stride, dO, ld_do, O, ld_o, rows_per_batch, klens, P, dS, L, Lp, batch, scale, 0.f, 0u, 1, 0, stream);
+}
+
+// the same with the forward's attention dropout (sc_attention_fwd_dropout, same seed): head h of H, batch z = utterance
+extern "C" int sc_attn_softmax_bwd_dropout(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O,
+                                           int64_t ld_o, int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch,
+                                           float scale, float drop_p, uint32_t seed, int H, int h, void* stream) {
+    return attn_softmax_bwd_impl(S, dP, ld, stride, dO, ld_do, O, ld_o, rows_per_batch, klens, P, dS, L, Lp, batch, scale, drop_p, seed, H, h, stream);
 }
 
 extern "C" int sc_gelu_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, void* stream) {

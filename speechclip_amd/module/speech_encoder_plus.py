@@ -257,16 +257,22 @@ def _forward_finetune(self, padded, lens, feat_select_idx, return_hidden_states,
         valid = enc.valid_frames(lens, padded.shape[1], T)
         fmeta = dict(conv_layers=[tuple(c) for c in cfg.conv_layers], T0=T0, P0=P0, Tp=Tp, d=d, G=cfg.conv_pos_groups, Kw=cfg.conv_pos,
                      grad_mult=float(enc.feature_grad_mult))
+        if drop_seed is not None:
+            r = enc.dropout_rates()
+            fmeta["drop"] = dict(features=r["features"], hidden=r["hidden"], seed=int(drop_seed))
         h_front = HubertFrontTrainFn.apply(fmeta, padded.contiguous(), ops.dev_ints(valid, torch.int32, dev), *front_params(enc))      # [B*Tp, d]
         hidden = None
     else:
-        # (the frozen layers below L0 get the train-mode dropouts; the autograd nodes of the TRAINED part run without them: DESIGN.md section 6)
+        # (train-mode dropouts: the frozen layers below L0 through the engine, the trained nodes through their own masks)
         hidden, T, Tp, valid = enc.extract_all_layers(padded, lens, stop_layer=L0, dropout_seed=drop_seed)        # hidden[0 .. L0] are valid
     M = B * Tp
     params = []
     for i in range(L0, nl):
         params += layer_params(enc.encoder.layers[i])
     meta = dict(B=B, Tp=Tp, H=cfg.encoder_attention_heads, eps=1e-5, train=[i in self.train_layers for i in range(L0, nl)])
+    if drop_seed is not None:
+        r = enc.dropout_rates()
+        meta["drop"] = dict(hidden=r["hidden"], attention=r["attention"], activation=r["activation"], seed=(int(drop_seed) * 2654435761 + 97) & 0x7fffffff)
     # (the engine's hidden buffer is a reused workspace: the autograd node keeps its own copy)
     h_in = h_front if self.train_front else hidden[L0].reshape(M, d).clone()
     hi = HubertLayersTrainFn.apply(meta, h_in, ops.dev_ints(valid, torch.int32, dev), *params)      # [nl - L0, M, d]

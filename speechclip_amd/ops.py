@@ -798,12 +798,18 @@ def transpose_bf16(src, ld_in, stride_in, rows, cols, batch, rows_padded=None, o
     return out
 
 
-def attn_softmax_bwd(S, dP, dO_head, ld_do, O_head, ld_o, rows_per_batch, klens_i32, L, scale):
-    """S, dP f32 [Z, Lp, Lp]; dO_head / O_head: views at the head's first column, rows of stride ld_*; -> (P, dS) bf16 [Z, Lp, Lp]."""
+def attn_softmax_bwd(S, dP, dO_head, ld_do, O_head, ld_o, rows_per_batch, klens_i32, L, scale, drop=None):
+    """S, dP f32 [Z, Lp, Lp]; dO_head / O_head: views at the head's first column, rows of stride ld_*; -> (P, dS) bf16 [Z, Lp, Lp].
+    drop = (p, seed, H, h): the forward ran attention_dropout with (p, seed); this is head h of H."""
     _need_cuda(S, dP)
     Z, Lp, _ = S.shape
     P = torch.empty(Z, Lp, Lp, device=S.device, dtype=bf16)
     dS = torch.empty_like(P)
+    if drop is not None and drop[0] > 0:
+        check(lib().sc_attn_softmax_bwd_dropout(ptr(S), ptr(dP), Lp, Lp * Lp, ptr(dO_head), ld_do, ptr(O_head), ld_o, rows_per_batch, ptr(klens_i32), ptr(P),
+                                                ptr(dS), L, Lp, Z, float(scale), float(drop[0]), int(drop[1]) & 0xffffffff, int(drop[2]), int(drop[3]),
+                                                stream()), "sc_attn_softmax_bwd_dropout")
+        return P, dS
     check(lib().sc_attn_softmax_bwd(ptr(S), ptr(dP), Lp, Lp * Lp, ptr(dO_head), ld_do, ptr(O_head), ld_o, rows_per_batch, ptr(klens_i32), ptr(P), ptr(dS),
                                     L, Lp, Z, float(scale), stream()), "sc_attn_softmax_bwd")
     return P, dS

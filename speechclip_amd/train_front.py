@@ -15,8 +15,8 @@ enters the feature extractor by `feature_grad_mult`, 0.1 in the released base ch
                                    overlapping-row view, dX = one GEMM per group of taps written straight into the channels-last input gradient
                                    (taps 0..s-1 tile it exactly; tap s.. accumulate through the residual epilogue, in place)
             conv layer 0           sc_conv0_bwd (GroupNorm + GELU + conv from the wave)
-The dropouts fairseq applies in train mode (features 0.1, after the positional conv) are not applied -- the same documented deviation as in the
-frozen towers.
+meta["drop"] = dict(features, hidden, seed) applies the two dropouts fairseq has on this stretch in train mode (dropout_input on the projected
+features, F.dropout on hidden state 0) with counter-based masks the backward regenerates.
 """
 import torch
 
@@ -113,11 +113,16 @@ class HubertFrontTrainFn(torch.autograd.Function):
         M = B * Tp
         feats = ops.layernorm(x[:M], _f32(flw), _f32(flb))
         xp = ops.gemm(feats, pw.detach().to(BF).contiguous(), _f32(pb))
+        drop = meta.get("drop")          # dict(features, hidden, seed): dropout_input on the projected features, F.dropout on hidden state 0
+        if drop is not None and drop["features"] > 0:
+            ops.dropout_bf16(xp, drop["features"], drop["seed"] ^ 0x2545F491, out=xp)
         wfold, _ = _fold_weight_norm(pg, pv)
         wg, _ = _pos_operands(wfold, G, Kw)
         conv = ops.posconv_conv(xp, valid_i32, wg, B, Tp, d, G, Kw)
         u, s_ = ops.posconv_finish_train(xp, valid_i32, conv, _f32(pbias), B, Tp, d, G)
         h0 = ops.layernorm(s_, _f32(elw), _f32(elb), 1e-5)
+        if drop is not None and drop["hidden"] > 0:
+            h0 = ops.dropout_bf16(h0, drop["hidden"], drop["seed"] ^ 0x61C88647)
         ctx.meta = meta
         ctx.valid = valid_i32
         ctx.save_for_backward(wav, *acts, feats, xp, u, s_, *[p.detach() for p in params])
@@ -137,8 +142,12 @@ class HubertFrontTrainFn(torch.autograd.Function):
         dev = wav.device
         valid = ctx.valid
         grads = [None] * N_FRONT
-        # ---- h0 = LN(s)
-        ds, grads[16], grads[17] = ops.layernorm_bwd_bf16(s_, dh0.to(BF).contiguous(), _f32(elw), 1e-5)
+        drop = meta.get("drop")
+        dh0 = dh0.to(BF).contiguous()
+        if drop is not None and drop["hidden"] > 0:
+            dh0 = ops.dropout_bf16(dh0, drop["hidden"], drop["seed"] ^ 0x61C88647)
+        # ---- h0 = [dropout] LN(s)
+        ds, grads[16], grads[17] = ops.layernorm_bwd_bf16(s_, dh0, _f32(elw), 1e-5)
         # ---- s = mask(xp) + gelu(u),  u = conv(mask(xp)) + bias
         du = ops.gelu_bwd_bf16(u, ds)
         grads[15] = ops.colsum_bf16(du)
@@ -154,7 +163,9 @@ class HubertFrontTrainFn(torch.autograd.Function):
         grads[13] = (dot / norm).to(pg.dtype)
         grads[14] = (gf / norm * dwf - gf * dot / norm.pow(3) * v).to(pv.dtype)
         del convT, du, ds
-        # ---- xp = feats W^T + b ; feats = LN(x6)
+        if drop is not None and drop["features"] > 0:
+            ops.dropout_bf16(dxp, drop["features"], drop["seed"] ^ 0x2545F491, out=dxp)      # saved xp is the dropped tensor; its gradient takes the same mask
+        # ---- xp = [dropout] (feats W^T + b) ; feats = LN(x6)
         dfeats = ops.gemm(dxp, pw.detach().t().to(BF).contiguous())
         grads[11], grads[12] = wgrad(dxp, feats), ops.colsum_bf16(dxp)
         x6 = acts[6][:M]

@@ -12,8 +12,9 @@ with fused epilogues, flash attention, LayerNorm) keeping what the backward need
   attention            S = Q K^T and dP = dO V^T recomputed per head (batched MFMA GEMMs), sc_attn_softmax_bwd -> P, dS, then dQ = dS K,
                        dK = dS^T Q, dV = P^T dO as batched GEMMs over transposed operands (key-padding mask = the forward's klens)
   LayerNorm / GELU     sc_layernorm_bwd_bf16 (+ partial column sums -> dgamma, dbeta), sc_gelu_bwd_bf16 (fc1's pre-activation is recomputed)
-Post-LN layers only (HuBERT-base; `layer_norm_first` models raise).  Dropout inside the trained layers is not applied (documented deviation:
-fairseq trains them with dropout 0.1); layerdrop must be 0 (every shipped config).
+Post-LN layers only (HuBERT-base; `layer_norm_first` models raise).  meta["drop"] = dict(hidden, attention, activation, seed) applies the
+checkpoint's dropouts inside the trained layers as fairseq does in train mode (dropout1 / dropout2 / dropout3, attention probabilities): the
+masks are counter-based, so the backward regenerates them from the per-site seeds instead of storing them.
 """
 from typing import List, Sequence
 
@@ -59,7 +60,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return ops.colsum(part.view(S, N * K)).view(N, K)
 
 
-def attention_bwd(qkv: torch.Tensor, att: torch.Tensor, datt: torch.Tensor, B: int, Tp: int, H: int, klens_i32: torch.Tensor) -> torch.Tensor:
+def attention_bwd(qkv: torch.Tensor, att: torch.Tensor, datt: torch.Tensor, B: int, Tp: int, H: int, klens_i32: torch.Tensor, drop=None) -> torch.Tensor:
     """qkv bf16 [>= B*Tp (+ Lp - Tp slack rows), 3*H*64] packed (q | k | v) as the forward produced it; att / datt bf16 [B*Tp, H*64] (attention output and its
     gradient) -> dqkv bf16 [B*Tp, 3*H*64]."""
     d = H * 64
@@ -76,7 +77,7 @@ def attention_bwd(qkv: torch.Tensor, att: torch.Tensor, datt: torch.Tensor, B: i
         do, o = datt[:, h * 64:], att[:, h * 64:]
         ops.gemm_batched(q, 3 * d, Tp * 3 * d, k, Tp * 3 * d, B, S, Lp, Lp * Lp, None, Tp, Lp, 64, B, ldw=3 * d)      # S = Q K^T   [Tp, Lp] per utterance
         ops.gemm_batched(do, d, Tp * d, v, Tp * 3 * d, B, dP, Lp, Lp * Lp, None, Tp, Lp, 64, B, ldw=3 * d)            # dP = dO V^T
-        P, dS = ops.attn_softmax_bwd(S, dP, do, d, o, d, Tp, klens_i32, Tp, scale)
+        P, dS = ops.attn_softmax_bwd(S, dP, do, d, o, d, Tp, klens_i32, Tp, scale, None if drop is None else (drop[0], drop[1], H, h))
         PT = ops.transpose_bf16(P, Lp, Lp * Lp, Lp, Lp, B)
         dST = ops.transpose_bf16(dS, Lp, Lp * Lp, Lp, Lp, B)
         kT = ops.transpose_bf16(k, 3 * d, Tp * 3 * d, Tp, 64, B, rows_padded=Lp)          # [B, 64, Lp]
@@ -102,21 +103,40 @@ class HubertLayersTrainFn(torch.autograd.Function):
         Lp = -(-Tp // 64) * 64
         hidden = torch.empty(n, M, d, device=dev, dtype=BF)
         saved = []
+        drop = meta.get("drop")
+        seeds = []
+        if drop is not None:
+            s0 = int(drop["seed"]) & 0x7fffffff
+            for _ in range(4 * n):
+                s0 = (s0 * 1103515245 + 12345) & 0x7fffffff
+                seeds.append(s0)
         h = h_in.detach()
         for li in range(n):
             qw, qb, kw, kb, vw, vb, ow, ob, g1, b1n, w1, b1, w2, b2, g2, b2n = params[li * PER_LAYER:(li + 1) * PER_LAYER]
             wqkv, bqkv = _w16(torch.cat([qw, kw, vw], 0)), _f32(torch.cat([qb, kb, vb], 0))
             qkv = torch.zeros(M + (Lp - Tp), 3 * d, device=dev, dtype=BF)          # slack rows: the backward's S / dP products read Lp keys per utterance
             ops.gemm(h, wqkv, bqkv, out=qkv[:M])
-            att = ops.attention(qkv[:M], B, Tp, H, valid_i32)
-            y1 = ops.gemm(att, _w16(ow), _f32(ob), residual=h)
-            x1 = ops.layernorm(y1, _f32(g1), _f32(b1n), eps)
-            hm = ops.gemm(x1, _w16(w1), _f32(b1), ACT_GELU)
-            y2 = ops.gemm(hm, _w16(w2), _f32(b2), residual=x1)
+            if drop is None:
+                att = ops.attention(qkv[:M], B, Tp, H, valid_i32)
+                y1 = ops.gemm(att, _w16(ow), _f32(ob), residual=h)
+                x1 = ops.layernorm(y1, _f32(g1), _f32(b1n), eps)
+                hm = ops.gemm(x1, _w16(w1), _f32(b1), ACT_GELU)
+                y2 = ops.gemm(hm, _w16(w2), _f32(b2), residual=x1)
+            else:       # x = LN(x + dropout1(attn(x)));  x = LN(x + dropout3(fc2(dropout2(gelu(fc1 x)))))
+                sa, s1, s2, s3 = seeds[4 * li:4 * li + 4]
+                att = ops.attention_dropout(qkv[:M], B, Tp, H, valid_i32, drop["attention"], sa)
+                y1 = ops.gemm(att, _w16(ow), _f32(ob))
+                ops.dropout_bf16(y1, drop["hidden"], s1, residual=h, out=y1)
+                x1 = ops.layernorm(y1, _f32(g1), _f32(b1n), eps)
+                hm = ops.gemm(x1, _w16(w1), _f32(b1), ACT_GELU)
+                if drop["activation"] > 0:
+                    ops.dropout_bf16(hm, drop["activation"], s2, out=hm)
+                y2 = ops.gemm(hm, _w16(w2), _f32(b2))
+                ops.dropout_bf16(y2, drop["hidden"], s3, residual=x1, out=y2)
             ops.layernorm(y2, _f32(g2), _f32(b2n), eps, out=hidden[li])
             saved += [h, qkv, att, y1, x1, hm, y2]
             h = hidden[li]
-        ctx.meta = dict(meta, n=n)
+        ctx.meta = dict(meta, n=n, seeds=seeds)
         ctx.valid = valid_i32
         ctx.save_for_backward(*saved, *[p.detach() for p in params])
         return hidden
@@ -135,22 +155,28 @@ class HubertLayersTrainFn(torch.autograd.Function):
             qw, qb, kw, kb, vw, vb, ow, ob, g1, b1n, w1, b1, w2, b2, g2, b2n = params[li * PER_LAYER:(li + 1) * PER_LAYER]
             want = bool(train[li])
             M, d = h.shape
+            drop = m.get("drop")
+            sa, s1, s2, s3 = m["seeds"][4 * li:4 * li + 4] if drop is not None else (0, 0, 0, 0)
             # x2 = LN2(y2)
-            dy2, dg2, db2n = ops.layernorm_bwd_bf16(y2, g, _f32(g2), eps, want)
-            # y2 = hm W2^T + b2 + x1
+            dy2r, dg2, db2n = ops.layernorm_bwd_bf16(y2, g, _f32(g2), eps, want)
+            # y2 = dropout3(hm W2^T + b2) + x1: the residual branch takes dy2r as it is, the fc2 branch the masked gradient
+            dy2 = dy2r if drop is None else ops.dropout_bf16(dy2r, drop["hidden"], s3)
             dhm = ops.gemm(dy2, _w16(w2.t()))                                  # [M, ffn] = dy2 W2
+            if drop is not None and drop["activation"] > 0:
+                ops.dropout_bf16(dhm, drop["activation"], s2, out=dhm)
             u = ops.gemm(x1, _w16(w1), _f32(b1))                               # fc1's pre-activation, recomputed (not kept by the forward)
             du = ops.gelu_bwd_bf16(u, dhm)
             del u, dhm
             # u = x1 W1^T + b1 ; x1 also feeds the residual of fc2
-            dx1 = ops.gemm(du, _w16(w1.t()), residual=dy2)                     # [M, d] = du W1 + dy2
+            dx1 = ops.gemm(du, _w16(w1.t()), residual=dy2r)                    # [M, d] = du W1 + dy2 (unmasked: the residual path)
             # x1 = LN1(y1)
-            dy1, dg1, db1n = ops.layernorm_bwd_bf16(y1, dx1, _f32(g1), eps, want)
-            # y1 = att Wo^T + bo + h
+            dy1r, dg1, db1n = ops.layernorm_bwd_bf16(y1, dx1, _f32(g1), eps, want)
+            # y1 = dropout1(att Wo^T + bo) + h
+            dy1 = dy1r if drop is None else ops.dropout_bf16(dy1r, drop["hidden"], s1)
             datt = ops.gemm(dy1, _w16(ow.t()))
-            dqkv = attention_bwd(qkv, att, datt, B, Tp, H, ctx.valid)
+            dqkv = attention_bwd(qkv, att, datt, B, Tp, H, ctx.valid, None if drop is None else (drop["attention"], sa))
             wqkv = torch.cat([qw, kw, vw], 0)
-            dh = ops.gemm(dqkv, _w16(wqkv.t()), residual=dy1)                  # [M, d] = dqkv Wqkv + dy1
+            dh = ops.gemm(dqkv, _w16(wqkv.t()), residual=dy1r)                 # [M, d] = dqkv Wqkv + dy1 (unmasked: the residual path)
             if want:
                 dwqkv = wgrad(dqkv, h)
                 dbqkv = ops.colsum_bf16(dqkv)

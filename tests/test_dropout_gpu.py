@@ -111,3 +111,114 @@ def test_frozen_encoder_applies_its_dropouts_in_train_mode_only(monkeypatch):
     assert all(torch.equal(a, b) for a, b in zip(off, e1))                  # the switch restores the eval arithmetic in train mode
     large = HubertConfig.from_name("hubert_large_ll60k")
     assert (large.dropout, large.attention_dropout, large.dropout_input) == (0.0, 0.0, 0.0)
+
+
+def _hash32(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def _keep(seed, idx, p):
+    """csrc/common.h keep_elem, restated: element idx survives iff hash32(seed ^ hash32(idx + 0x9e3779b9)) >= p * 2^32."""
+    idx = (np.asarray(idx, dtype=np.uint64) + np.uint64(0x9e3779b9)) & np.uint64(0xffffffff)
+    h = _hash32(np.uint64(seed & 0xffffffff) ^ _hash32(idx))
+    return torch.from_numpy((h >= np.uint64(int(p * 4294967296.0))).astype(np.float32))
+
+
+def test_trained_layer_with_dropout_matches_autograd_with_the_same_masks():
+    """One post-LN layer through train_hubert.HubertLayersTrainFn with meta["drop"]: forward and every gradient against an fp32 torch
+    re-statement of the fairseq layer (dropout1 / dropout3 / attention dropout) that uses the SAME counter-based masks, regenerated in numpy."""
+    from speechclip_amd import ops
+    from speechclip_amd.train_hubert import HubertLayersTrainFn
+    B, Tp, H, d, ffn = 2, 64, 2, 128, 256
+    M = B * Tp
+    lens = [64, 40]
+    g = torch.Generator().manual_seed(4)
+    P = [0.08 * torch.randn(d, d, generator=g), 0.02 * torch.randn(d, generator=g)] * 0
+    shapes = [(d, d), (d,), (d, d), (d,), (d, d), (d,), (d, d), (d,), (d,), (d,), (ffn, d), (ffn,), (d, ffn), (d,), (d,), (d,)]
+    params = []
+    for i, sh in enumerate(shapes):
+        t = 0.08 * torch.randn(*sh, generator=g) if len(sh) == 2 else 0.05 * torch.randn(*sh, generator=g)
+        if i in (8, 14):
+            t = 1.0 + t                                               # LayerNorm gains
+        params.append(t)
+    h_in = torch.randn(M, d, generator=g).to(BF)
+    dout = torch.randn(1, M, d, generator=g).to(BF)
+    for b, n in enumerate(lens):
+        dout[0, b * Tp + n:(b + 1) * Tp] = 0                         # nothing flows back from padded frames
+    p_h, p_a, seed = 0.1, 0.1, 987654
+    s0, seeds = seed & 0x7fffffff, []
+    for _ in range(4):
+        s0 = (s0 * 1103515245 + 12345) & 0x7fffffff
+        seeds.append(s0)
+    sa, s1, _, s3 = seeds
+    # ---- the HIP node
+    dev_p = [p.clone().cuda().requires_grad_(True) for p in params]
+    hin_d = h_in.clone().cuda().requires_grad_(True)
+    meta = dict(B=B, Tp=Tp, H=H, eps=1e-5, train=[True], drop=dict(hidden=p_h, attention=p_a, activation=0.0, seed=seed))
+    out = HubertLayersTrainFn.apply(meta, hin_d, torch.tensor(lens, dtype=torch.int32).cuda(), *dev_p)
+    out.backward(dout.cuda())
+    # ---- fp32 torch re-statement with the same masks
+    rp = [p.clone().requires_grad_(True) for p in params]
+    qw, qb, kw, kb, vw, vb, ow, ob, g1, b1n, w1, b1, w2, b2, g2, b2n = rp
+    x = h_in.float().clone().requires_grad_(True)
+    q = (x @ qw.t() + qb).view(B, Tp, H, 64).transpose(1, 2)
+    k = (x @ kw.t() + kb).view(B, Tp, H, 64).transpose(1, 2)
+    v = (x @ vw.t() + vb).view(B, Tp, H, 64).transpose(1, 2)
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    kmask = torch.arange(Tp)[None, :] >= torch.tensor(lens)[:, None]
+    pr = torch.softmax(s.masked_fill(kmask[:, None, None, :], float("-inf")), dim=-1)
+    am = _keep(sa, np.arange(B * H * Tp * Tp), p_a).view(B, H, Tp, Tp) / (1 - p_a)
+    att = ((pr * am) @ v).transpose(1, 2).reshape(M, d)
+    m1 = _keep(s1, np.arange(M * d), p_h).view(M, d) / (1 - p_h)
+    m3 = _keep(s3, np.arange(M * d), p_h).view(M, d) / (1 - p_h)
+    y1 = (att @ ow.t() + ob) * m1 + x
+    x1 = torch.nn.functional.layer_norm(y1, (d,), g1, b1n, 1e-5)
+    hm = torch.nn.functional.gelu(x1 @ w1.t() + b1)
+    y2 = (hm @ w2.t() + b2) * m3 + x1
+    ref = torch.nn.functional.layer_norm(y2, (d,), g2, b2n, 1e-5)
+    ref.backward(dout[0].float())
+    cosf = torch.nn.functional.cosine_similarity
+    for b, n in enumerate(lens):
+        rows = slice(b * Tp, b * Tp + n)
+        assert cosf(out[0, rows].float().cpu().reshape(1, -1), ref[rows].detach().reshape(1, -1)).item() > 0.999
+        assert cosf(hin_d.grad[rows].float().cpu().reshape(1, -1), x.grad[rows].reshape(1, -1)).item() > 0.995
+    names = "q_w q_b k_w k_b v_w v_b o_w o_b ln1_w ln1_b fc1_w fc1_b fc2_w fc2_b ln2_w ln2_b".split()
+    for nme, mine, r in zip(names, dev_p, rp):
+        if r.grad.norm().item() < 1e-5 * max(1.0, rp[0].grad.norm().item()):      # k_b: exactly zero in theory (softmax rows are shift invariant)
+            assert mine.grad.float().norm().item() < 1e-2 * dev_p[0].grad.float().norm().item(), nme
+            continue
+        c = cosf(mine.grad.float().cpu().reshape(1, -1), r.grad.reshape(1, -1)).item()
+        ratio = mine.grad.float().norm().item() / r.grad.norm().item()
+        assert c > 0.99 and abs(ratio - 1) < 0.06, (nme, c, ratio)
+    # and the masks really were applied: without them the output differs
+    meta0 = dict(B=B, Tp=Tp, H=H, eps=1e-5, train=[False])
+    with torch.no_grad():
+        plain = HubertLayersTrainFn.apply(meta0, h_in.cuda(), torch.tensor(lens, dtype=torch.int32).cuda(), *[p.cuda() for p in params])
+    assert cosf(plain[0, :64].float().reshape(1, -1), out[0, :64].detach().float().reshape(1, -1)).item() < 0.999
+
+
+def test_full_encoder_training_step_with_dropout_runs_and_is_seeded(monkeypatch):
+    from test_finetune_gpu import _finetune_pair
+    monkeypatch.setenv("SC_FROZEN_DROPOUT", "1")
+    model, _, batch = _finetune_pair([], everything=True)
+    model = model.cuda().train()
+    batch = {k: v.cuda() for k, v in batch.items()}
+
+    def grads(seed):
+        model.zero_grad()
+        torch.manual_seed(seed)
+        np.random.seed(0)
+        loss = model.training_step_end(model.training_step(batch, 0))["loss"]
+        loss.backward()
+        c = getattr(model.audio_encoder.encoder.feature_extractor.conv_layers[2], "0").weight.grad.clone()
+        return loss.item(), c
+    l1, g1 = grads(3)
+    l2, g2 = grads(3)
+    l3, g3 = grads(4)
+    assert l1 == l2 and torch.equal(g1, g2)                           # same torch seed -> same masks -> same step
+    assert l1 != l3 and not torch.equal(g1, g3)
+    assert np.isfinite(l1) and torch.isfinite(g1).all() and g1.abs().max().item() > 0
