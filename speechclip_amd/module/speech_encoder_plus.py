@@ -103,8 +103,6 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 p.requires_grad = not k.startswith(unused)
             self.encoder.feature_grad_mult = cfg.feature_grad_mult
         elif self.train_layers:
-            if cfg.layer_norm_first:
-                raise NotImplementedError("fine-tuning pre-LN (HuBERT-large) layers is not built; HuBERT-base layers are (train_hubert.py)")
             assert 0 <= self.train_layers[0] and self.train_layers[-1] < cfg.encoder_layers, self.train_layers
             for i in self.train_layers:
                 lyr = self.encoder.encoder.layers[i]
@@ -269,7 +267,8 @@ def _forward_finetune(self, padded, lens, feat_select_idx, return_hidden_states,
     params = []
     for i in range(L0, nl):
         params += layer_params(enc.encoder.layers[i])
-    meta = dict(B=B, Tp=Tp, H=cfg.encoder_attention_heads, eps=1e-5, train=[i in self.train_layers for i in range(L0, nl)])
+    meta = dict(B=B, Tp=Tp, H=cfg.encoder_attention_heads, eps=1e-5, train=[i in self.train_layers for i in range(L0, nl)],
+                pre_ln=bool(cfg.layer_norm_first))
     if drop_seed is not None:
         r = enc.dropout_rates()
         meta["drop"] = dict(hidden=r["hidden"], attention=r["attention"], activation=r["activation"], seed=(int(drop_seed) * 2654435761 + 97) & 0x7fffffff)

@@ -12,7 +12,8 @@ with fused epilogues, flash attention, LayerNorm) keeping what the backward need
   attention            S = Q K^T and dP = dO V^T recomputed per head (batched MFMA GEMMs), sc_attn_softmax_bwd -> P, dS, then dQ = dS K,
                        dK = dS^T Q, dV = P^T dO as batched GEMMs over transposed operands (key-padding mask = the forward's klens)
   LayerNorm / GELU     sc_layernorm_bwd_bf16 (+ partial column sums -> dgamma, dbeta), sc_gelu_bwd_bf16 (fc1's pre-activation is recomputed)
-Post-LN layers only (HuBERT-base; `layer_norm_first` models raise).  meta["drop"] = dict(hidden, attention, activation, seed) applies the
+Post-LN layers (HuBERT-base) and, with meta["pre_ln"], pre-LN layers on an fp32 residual stream (HuBERT-large, `unfreeze_layers` / `reinit_layers`
+only: its LayerNorm-extractor front end has no backward here).  meta["drop"] = dict(hidden, attention, activation, seed) applies the
 checkpoint's dropouts inside the trained layers as fairseq does in train mode (dropout1 / dropout2 / dropout3, attention probabilities): the
 masks are counter-based, so the backward regenerates them from the per-site seeds instead of storing them.
 """
@@ -101,6 +102,9 @@ class HubertLayersTrainFn(torch.autograd.Function):
         assert M == B * Tp and d == H * 64
         dev = h_in.device
         Lp = -(-Tp // 64) * 64
+        pre_ln = bool(meta.get("pre_ln", False))
+        if pre_ln:
+            return HubertLayersTrainFn._forward_pre_ln(ctx, meta, h_in, valid_i32, params)
         hidden = torch.empty(n, M, d, device=dev, dtype=BF)
         saved = []
         drop = meta.get("drop")
@@ -142,7 +146,85 @@ class HubertLayersTrainFn(torch.autograd.Function):
         return hidden
 
     @staticmethod
+    def _forward_pre_ln(ctx, meta, h_in, valid_i32, params):
+        """Pre-LN layers ([3P fairseq] layer_norm_first, HuBERT-large): x += attn(LN1 x); x += fc2(gelu(fc1(LN2 x))) on an fp32 residual stream.
+        h_in / hidden are f32; the saved copies of the stream (LayerNorm inputs of the backward) are bf16.  The large checkpoint's dropouts are 0."""
+        B, Tp, H, eps = meta["B"], meta["Tp"], meta["H"], meta["eps"]
+        assert meta.get("drop") is None or not any(v > 0 for k, v in meta["drop"].items() if k != "seed"), "dropout inside pre-LN layers is not built"
+        n = len(params) // PER_LAYER
+        M, d = h_in.shape
+        dev = h_in.device
+        Lp = -(-Tp // 64) * 64
+        hidden = torch.empty(n, M, d, device=dev, dtype=torch.float32)
+        saved = []
+        h = h_in.detach().float().contiguous()
+        for li in range(n):
+            qw, qb, kw, kb, vw, vb, ow, ob, g1, b1n, w1, b1, w2, b2, g2, b2n = params[li * PER_LAYER:(li + 1) * PER_LAYER]
+            wqkv, bqkv = _w16(torch.cat([qw, kw, vw], 0)), _f32(torch.cat([qb, kb, vb], 0))
+            t1 = ops.layernorm(h, _f32(g1), _f32(b1n), eps)                                   # bf16
+            qkv = torch.zeros(M + (Lp - Tp), 3 * d, device=dev, dtype=BF)
+            ops.gemm(t1, wqkv, bqkv, out=qkv[:M])
+            att = ops.attention(qkv[:M], B, Tp, H, valid_i32)
+            xmid = ops.gemm(att, _w16(ow), _f32(ob), residual=h, out_f32=True)
+            t2 = ops.layernorm(xmid, _f32(g2), _f32(b2n), eps)
+            hm = ops.gemm(t2, _w16(w1), _f32(b1), ACT_GELU)
+            ops.gemm(hm, _w16(w2), _f32(b2), residual=xmid, out=hidden[li], out_f32=True)
+            saved += [h.to(BF), qkv, att, xmid.to(BF), t1, hm, t2]
+            h = hidden[li]
+        ctx.meta = dict(meta, n=n, seeds=[])
+        ctx.valid = valid_i32
+        ctx.save_for_backward(*saved, *[p.detach() for p in params])
+        return hidden
+
+    @staticmethod
+    def _backward_pre_ln(ctx, dhidden):
+        m = ctx.meta
+        B, Tp, H, eps, n, train = m["B"], m["Tp"], m["H"], m["eps"], m["n"], m["train"]
+        tensors = ctx.saved_tensors
+        acts, params = tensors[:7 * n], tensors[7 * n:]
+        dhidden = dhidden.to(BF).contiguous()
+        grads = [None] * len(params)
+        g = dhidden[n - 1].clone()                                   # gradient of the residual stream after the top layer (bf16)
+        for li in range(n - 1, -1, -1):
+            h16, qkv, att, xmid16, t1, hm, t2 = acts[7 * li:7 * li + 7]
+            qw, qb, kw, kb, vw, vb, ow, ob, g1, b1n, w1, b1, w2, b2, g2, b2n = params[li * PER_LAYER:(li + 1) * PER_LAYER]
+            want = bool(train[li])
+            M, d = h16.shape
+            # out = xmid + fc2(gelu(fc1(t2))),  t2 = LN2(xmid)
+            dhm = ops.gemm(g, _w16(w2.t()))
+            u = ops.gemm(t2, _w16(w1), _f32(b1))
+            du = ops.gelu_bwd_bf16(u, dhm)
+            del u, dhm
+            dt2 = ops.gemm(du, _w16(w1.t()))
+            dxm, dg2, db2n = ops.layernorm_bwd_bf16(xmid16, dt2, _f32(g2), eps, want)
+            ops.axpy_bf16(dxm, g, 1.0)                                 # + the residual path
+            # xmid = h + out_proj(attn(qkv(t1))),  t1 = LN1(h)
+            datt = ops.gemm(dxm, _w16(ow.t()))
+            dqkv = attention_bwd(qkv, att, datt, B, Tp, H, ctx.valid)
+            wqkv = torch.cat([qw, kw, vw], 0)
+            dt1 = ops.gemm(dqkv, _w16(wqkv.t()))
+            dh, dg1, db1n = ops.layernorm_bwd_bf16(h16, dt1, _f32(g1), eps, want)
+            ops.axpy_bf16(dh, dxm, 1.0)
+            if want:
+                dwqkv = wgrad(dqkv, t1)
+                dbqkv = ops.colsum_bf16(dqkv)
+                base = li * PER_LAYER
+                grads[base + 0], grads[base + 2], grads[base + 4] = dwqkv[:d], dwqkv[d:2 * d], dwqkv[2 * d:]
+                grads[base + 1], grads[base + 3], grads[base + 5] = dbqkv[:d], dbqkv[d:2 * d], dbqkv[2 * d:]
+                grads[base + 6], grads[base + 7] = wgrad(dxm, att), ops.colsum_bf16(dxm)
+                grads[base + 8], grads[base + 9] = dg1, db1n
+                grads[base + 10], grads[base + 11] = wgrad(du, t2), ops.colsum_bf16(du)
+                grads[base + 12], grads[base + 13] = wgrad(g, hm), ops.colsum_bf16(g)
+                grads[base + 14], grads[base + 15] = dg2, db2n
+            g = dh
+            if li > 0:
+                ops.axpy_bf16(g, dhidden[li - 1], 1.0)
+        return (None, g.float() if ctx.needs_input_grad[1] else None, None, *grads)
+
+    @staticmethod
     def backward(ctx, dhidden):
+        if ctx.meta.get("pre_ln"):
+            return HubertLayersTrainFn._backward_pre_ln(ctx, dhidden)
         m = ctx.meta
         B, Tp, H, eps, n, train = m["B"], m["Tp"], m["H"], m["eps"], m["n"], m["train"]
         tensors = ctx.saved_tensors
@@ -200,18 +282,21 @@ class WeightedSumTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hidden, weights, normalize):
-        if normalize:
-            raise NotImplementedError("fine-tuning with normalize_hiddenstates (pre-LN large models) is not supported")
-        ctx.save_for_backward(weights.detach())
+        ctx.normalize = bool(normalize)
+        ctx.save_for_backward(weights.detach(), hidden.detach().to(BF) if normalize else weights.detach())
         n, M, D = hidden.shape
-        return ops.weighted_sum(hidden.detach(), weights.detach().float(), False)
+        return ops.weighted_sum(hidden.detach().contiguous(), weights.detach().float(), bool(normalize))
 
     @staticmethod
     def backward(ctx, dmixed):
-        (w,) = ctx.saved_tensors
+        w, h16 = ctx.saved_tensors
         sm = torch.softmax(w.float(), 0).tolist()
         dm = dmixed.to(BF).contiguous()
         out = torch.zeros(len(sm), *dm.shape, device=dm.device, dtype=BF)
         for l, a in enumerate(sm):
             ops.axpy_bf16(out[l], dm, a)
+        if ctx.normalize:      # F.layer_norm(hidden_l) without affine in front of the mix (weighted_sum.py:41-42): its backward per state
+            ones = torch.ones(dm.shape[-1], device=dm.device, dtype=torch.float32)
+            for l in range(len(sm)):
+                out[l] = ops.layernorm_bwd_bf16(h16[l].contiguous(), out[l].contiguous(), ones, 1e-5, False)[0]
         return out, None, None

@@ -141,7 +141,7 @@ def test_cls_pool_dz_matches_autograd():
         assert dz[b, n:].abs().max().item() == 0 if n < T else True
 
 
-def _finetune_pair(train_layers, reinit=False, everything=False):
+def _finetune_pair(train_layers, reinit=False, everything=False, large=False):
     """Tiny P-base model with the listed encoder layers trainable + the oracle with the same weights."""
     from helpers import make_config
     from oracle.clip_ref import ClipRefConfig
@@ -150,8 +150,13 @@ def _finetune_pair(train_layers, reinit=False, everything=False):
     from speechclip_amd.model import KWClip_GeneralTransformer
     from speechclip_amd.module.clip_model import ClipConfig
     from speechclip_amd.module.hubert import HubertConfig
-    href, cref = dataclasses.replace(HubertRefConfig.tiny(), encoder_layers=3), ClipRefConfig.tiny()
-    cfg = make_config(d_model=128, branch_heads=4, hubert_config=HubertConfig(**dataclasses.asdict(href)), clip_config=ClipConfig(**dataclasses.asdict(cref)))
+    tiny = HubertRefConfig.tiny(layer_norm_first=True, extractor_mode="layer_norm", conv_bias=True) if large else HubertRefConfig.tiny()
+    href, cref = dataclasses.replace(tiny, encoder_layers=3), ClipRefConfig.tiny()
+    hc = HubertConfig(**dataclasses.asdict(href))
+    if large:       # the released large checkpoint: no dropouts, feature_grad_mult 1
+        hc = dataclasses.replace(hc, dropout=0.0, attention_dropout=0.0, dropout_input=0.0, encoder_layerdrop=0.0, feature_grad_mult=1.0)
+    cfg = make_config(d_model=128, branch_heads=4, hubert_config=hc, clip_config=ClipConfig(**dataclasses.asdict(cref)),
+                      hubert_name="hubert_large_ll60k" if large else "hubert", normalize_hiddenstates=large)
     cfg.audio_encoder.trainable = True
     if everything:
         pass                                                          # bare trainable: true -- no layer lists
@@ -167,7 +172,7 @@ def _finetune_pair(train_layers, reinit=False, everything=False):
         for m in model.audio_encoder.encoder.modules():
             if isinstance(m, torch.nn.LayerNorm):
                 m.weight.add_(0.2 * torch.randn(m.weight.shape, generator=g)); m.bias.add_(0.1 * torch.randn(m.bias.shape, generator=g))
-    ref = SpeechClipRef(href, cref, parallel=True, branch_heads=4)
+    ref = SpeechClipRef(href, cref, parallel=True, branch_heads=4, normalize_hiddenstates=large)
     sd = model.state_dict()
     ref.encoder.load_state_dict({k[len("audio_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("audio_encoder.encoder.")})
     ref.clip.load_state_dict({k[len("clip.model."):]: v for k, v in sd.items() if k.startswith("clip.model.")})
@@ -250,6 +255,56 @@ def test_finetune_gradients_vs_oracle_autograd(train_layers):
             assert _cos(got, p.grad) > 0.98, k
     assert _cos(mine["audio_encoder.weightedsum_layer.weights"].grad, ref.ws_weights.grad) > 0.98
     # frozen parts have no gradient
+    assert all(p.grad is None for k, p in mine.items() if k.startswith("audio_encoder.encoder.") and not any(f".layers.{i}." in k for i in train_layers))
+
+
+@pytest.mark.parametrize("train_layers", [[2], [1, 2]])
+def test_finetune_pre_ln_layers_vs_oracle_autograd(train_layers):
+    """HuBERT-large style encoder (pre-LN layers on an fp32 residual stream, LayerNorm extractor, wave normalisation, normalize_hiddenstates in
+    front of the mix): `unfreeze_layers` gradients vs the oracle's autograd."""
+    from oracle import hubert_ref as HR
+    from oracle import speechclip_ref as R
+    model, ref, batch = _finetune_pair(train_layers, large=True)
+    model = model.cuda().eval()
+    feats, _, _ = model({k: v.cuda() for k, v in batch.items()})
+    loss = model.compute_loss(feats)["loss"]
+    loss.backward()
+    for p in ref.parameters():
+        p.requires_grad_(False)
+    lys = ref.encoder.encoder.layers
+    for i in train_layers:
+        for p in lys[i].parameters():
+            p.requires_grad_(True)
+    for p in ref.parallel_branch.parameters():
+        p.requires_grad_(True)
+    ref.ws_weights.requires_grad_(True)
+    wavs = [batch["wav"][b, :int(batch["wav_len"][b])] for b in range(4)]
+    padded, mask = HR.preprocess_input(wavs, ref.hubert_cfg.normalize)
+    with torch.enable_grad():
+        hidden = HR.hubert_forward.__wrapped__(ref.encoder, padded, mask)["layer_results"]
+        flen = HR.feat_lengths([len(w) for w in wavs], 320, hidden[-1].shape[1])
+        pa = R.l2_normalize(ref.parallel_branch(R.weighted_sum(hidden, ref.ws_weights, True), flen))
+        with torch.no_grad():
+            img = R.l2_normalize(ref.clip.encode_image(batch["image"]))
+        ref_loss = R.masked_contrastive_loss(pa, img, batch["id"], ref.inv_temperature)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 2e-2
+    mine = dict(model.named_parameters())
+    checked, worst = 0, (1.0, "")
+    for i in train_layers:
+        for k, p in lys[i].named_parameters():
+            got = mine[f"audio_encoder.encoder.encoder.layers.{i}.{k}"].grad
+            assert got is not None, (i, k)
+            if p.grad.norm().item() < 1e-7:
+                assert got.norm().item() < 1e-4, (i, k)
+                continue
+            c, ratio = _cos(got, p.grad), got.norm().item() / p.grad.norm().item()
+            worst = min(worst, (c, f"{i}.{k}"))
+            assert c > 0.97 and abs(ratio - 1) < 0.12, (i, k, c, ratio)
+            checked += 1
+    print("pre-LN gradients checked:", checked, "worst cosine:", worst)
+    assert checked >= 12 * len(train_layers)
+    assert _cos(mine["audio_encoder.weightedsum_layer.weights"].grad, ref.ws_weights.grad) > 0.97
     assert all(p.grad is None for k, p in mine.items() if k.startswith("audio_encoder.encoder.") and not any(f".layers.{i}." in k for i in train_layers))
 
 
