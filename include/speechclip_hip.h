@@ -336,6 +336,9 @@ int sc_posconv_dgrad_finish(const void* convT, const void* ds, const int32_t* va
 int sc_reverse_rows_bf16(const void* in, void* out, int B, int T, int D, void* stream);
 int sc_conv0_bwd(const float* wav, int64_t ld, const float* w, const float* gamma, const float* beta, const void* dy, float* part, int B, int C, int T0,
                  int P, float eps, void* stream);
+/* conv layer 0 of the LayerNorm extractor (HuBERT-large: conv + bias -> LayerNorm(C) -> GELU; the LayerNorm / GELU backward runs on the row kernels):
+ * du bf16 [B, P, C] = gradient of the conv output -> part f32 [B, C, 12] = per-utterance (dw[0..9], dbias, 0). */
+int sc_conv0_wgrad(const float* wav, int64_t ld, const void* du, float* part, int B, int C, int T0, int P, void* stream);
 int sc_attn_softmax_bwd(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
                         int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch, float scale, void* stream);
 /* sc_attn_softmax_bwd for a forward that ran sc_attention_fwd_dropout with (drop_p, seed): P comes out masked and rescaled (dV = P^T dO sees the

@@ -70,6 +70,7 @@ def _declare(L):
         "sc_posconv_dgrad_finish": ([P, P, P, P, I, I, I, I, P], c_int),
         "sc_reverse_rows_bf16": ([P, P, I, I, I, P], c_int),
         "sc_conv0_bwd": ([P, L64, P, P, P, P, P, I, I, I, I, F, P], c_int),
+        "sc_conv0_wgrad": ([P, L64, P, P, I, I, I, I, P], c_int),
         "sc_topk_rows_f32": ([P, L64, L64, I, I, P, P, P], c_int),
         "sc_cls_pool_fwd": ([P, L64, P, P, P, P, P, I, I, I, I, I, P], c_int),
         "sc_conv0_stats_workspace_bytes": ([I], c_int64),

@@ -156,7 +156,44 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
     }
 }
 
+// conv layer 0 of the LayerNorm extractor (HuBERT-large: Conv1d(1 -> C, k 10, s 5, bias) -> LayerNorm(C) -> GELU): the LayerNorm / GELU part of the
+// backward runs on the row kernels, which leaves dw[c, j] = sum_t du[t, c] wav[5 t + j] and dbias[c] = sum_t du[t, c] per utterance.
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ wav, int64_t ld, const bf16_t* __restrict__ du, float* __restrict__ part,
+                                                          int C, int T0, int P) {
+    __shared__ float red[4][64][12];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lane;
+    const float* wv = wav + (int64_t)b * ld;
+    const bf16_t* dub = du + (int64_t)b * P * C + c;
+    float acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = 0.f;
+    for (int t = wave; t < T0; t += 4) {
+        const float g = bf2f(dub[(int64_t)t * C]);
+#pragma unroll
+        for (int j = 0; j < C0_K; ++j) acc[j] = fmaf(g, wv[t * C0_S + j], acc[j]);
+        acc[10] += g;
+    }
+    for (int i = 0; i < 11; ++i) red[wave][lane][i] = acc[i];
+    __syncthreads();
+    if (wave == 0) {
+        float* o = part + ((int64_t)b * C + c) * 12;
+        for (int i = 0; i < 11; ++i) o[i] = (red[0][lane][i] + red[1][lane][i]) + (red[2][lane][i] + red[3][lane][i]);
+        o[11] = 0.f;
+    }
+}
+
 }  // namespace
+
+extern "C" int sc_conv0_wgrad(const float* wav, int64_t ld, const void* du, float* part, int B, int C, int T0, int P, void* stream) {
+    SC_CHECK_ARG(wav && du && part, "sc_conv0_wgrad: null operand");
+    SC_CHECK_ARG(C % 64 == 0 && B <= 65535, "sc_conv0_wgrad: C must be a multiple of 64, B <= 65535");
+    SC_CHECK_ARG(T0 >= 1 && P >= T0 && ld >= (int64_t)(T0 - 1) * C0_S + C0_K, "sc_conv0_wgrad: T0=%d P=%d ld=%lld inconsistent", T0, P, (long long)ld);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, wav, ld, (const bf16_t*)du, part, C, T0, P);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int sc_posconv_finish_train(const void* x, const int32_t* valid, const void* conv, const float* bias, void* u, void* s, int B, int Tp, int D, int G,
                                        void* stream) {

@@ -94,11 +94,14 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # the checkpoint's feature_grad_mult [3P fairseq forward_features]), layer_norm, post_extract_proj, the positional conv and all layers train
         self.train_front = bool(trainable) and not self.train_layers
         if self.train_front:
-            if cfg.layer_norm_first or cfg.extractor_mode != "default" or cfg.conv_bias:
-                raise NotImplementedError("trainable=True is built for the GroupNorm / post-LN architecture (HuBERT-base); the LayerNorm-extractor, "
-                                          "pre-LN large model is not (train_front.py, train_hubert.py)")
+            base_arch = not cfg.layer_norm_first and cfg.extractor_mode == "default" and not cfg.conv_bias
+            large_arch = cfg.layer_norm_first and cfg.extractor_mode == "layer_norm" and cfg.conv_bias
+            if not (base_arch or large_arch):
+                raise NotImplementedError("trainable=True is built for the two released architectures: GroupNorm extractor + post-LN layers (base) and "
+                                          "LayerNorm extractor with conv biases + pre-LN layers (large); not for other combinations")
             self.train_layers = list(range(cfg.encoder_layers))
-            unused = ("mask_emb", "final_proj", "label_embs_concat")      # never reached by customHubertForward: torch's Adam skips their None gradients
+            # never reached by customHubertForward: torch's Adam skips their None gradients (pre-LN: encoder.layer_norm only touches the final x)
+            unused = ("mask_emb", "final_proj", "label_embs_concat") + (("encoder.layer_norm",) if large_arch else ())
             for k, p in self.encoder.named_parameters():
                 p.requires_grad = not k.startswith(unused)
             self.encoder.feature_grad_mult = cfg.feature_grad_mult
@@ -249,16 +252,20 @@ def _forward_finetune(self, padded, lens, feat_select_idx, return_hidden_states,
     dev = padded.device
     L0, nl = self.train_layers[0], cfg.encoder_layers
     B, d = padded.shape[0], cfg.encoder_embed_dim
-    if self.train_front:          # the wave -> hidden state 0 as an autograd node too (train_front.HubertFrontTrainFn)
-        from ..train_front import HubertFrontTrainFn, front_params
+    if self.train_front:          # the wave -> hidden state 0 as an autograd node too (train_front.HubertFront[LN]TrainFn)
+        from ..train_front import HubertFrontLNTrainFn, HubertFrontTrainFn, front_params, front_params_ln
         T0, T, P0, Tp = enc.frame_geometry(padded.shape[1])
         valid = enc.valid_frames(lens, padded.shape[1], T)
         fmeta = dict(conv_layers=[tuple(c) for c in cfg.conv_layers], T0=T0, P0=P0, Tp=Tp, d=d, G=cfg.conv_pos_groups, Kw=cfg.conv_pos,
-                     grad_mult=float(enc.feature_grad_mult))
-        if drop_seed is not None:
-            r = enc.dropout_rates()
-            fmeta["drop"] = dict(features=r["features"], hidden=r["hidden"], seed=int(drop_seed))
-        h_front = HubertFrontTrainFn.apply(fmeta, padded.contiguous(), ops.dev_ints(valid, torch.int32, dev), *front_params(enc))      # [B*Tp, d]
+                     grad_mult=float(enc.feature_grad_mult), normalize=bool(cfg.normalize))
+        valid_dev = ops.dev_ints(valid, torch.int32, dev)
+        if cfg.layer_norm_first:
+            h_front = HubertFrontLNTrainFn.apply(fmeta, padded.contiguous(), ops.dev_ints(lens, torch.int32, dev), valid_dev, *front_params_ln(enc))
+        else:
+            if drop_seed is not None:
+                r = enc.dropout_rates()
+                fmeta["drop"] = dict(features=r["features"], hidden=r["hidden"], seed=int(drop_seed))
+            h_front = HubertFrontTrainFn.apply(fmeta, padded.contiguous(), valid_dev, *front_params(enc))      # [B*Tp, d]
         hidden = None
     else:
         # (train-mode dropouts: the frozen layers below L0 through the engine, the trained nodes through their own masks)

@@ -920,3 +920,14 @@ def conv0_bwd(wav, w, gamma, beta, dy, T0, P, eps=1e-5):
     check(lib().sc_conv0_bwd(ptr(wav), L, ptr(w), ptr(gamma), ptr(beta), ptr(dy), ptr(part), B, C, T0, P, eps, stream()), "sc_conv0_bwd")
     tot = colsum(part).view(C, 12)
     return tot[:, :10].contiguous(), tot[:, 10].contiguous(), tot[:, 11].contiguous()
+
+
+def conv0_wgrad(wav, du, C, T0, P):
+    """wav f32 [B, L]; du bf16 [B*P (+ slack), C] = gradient of conv layer 0's (pre-norm) output -> (dw f32 [C, 10], dbias f32 [C])."""
+    _need_cuda(wav, du)
+    B, L = wav.shape
+    assert wav.dtype == torch.float32 and wav.is_contiguous() and du.dtype == bf16 and du.is_contiguous()
+    part = torch.empty(B, C * 12, device=wav.device, dtype=torch.float32)
+    check(lib().sc_conv0_wgrad(ptr(wav), L, ptr(du), ptr(part), B, C, T0, P, stream()), "sc_conv0_wgrad")
+    tot = colsum(part).view(C, 12)
+    return tot[:, :10].contiguous(), tot[:, 10].contiguous()

@@ -86,6 +86,40 @@ def posconv_wgrad(du, xp, valid_i32, B, Tp, D, G, Kw):
     return out
 
 
+def conv_layer_backward(xin, w, du_i, B, rows_out, dim, k, s, C):
+    """Conv-as-GEMM layer, gradient du_i bf16 [B*rows_out, dim] of its (pre-activation) output -> (dW f32 [dim, C, k], dX bf16 [B*rows_in + 8, C])."""
+    Mi = B * rows_out
+    rows_in = rows_out * s
+    w16 = _conv_w16(w)
+    xview = torch.as_strided(xin, (Mi, k * C), (s * C, 1))
+    dW = wgrad(du_i, xview).view(dim, k, C).permute(0, 2, 1).contiguous()
+    wT = w16.t().contiguous()                                                    # [k*C, dim]
+    dx = torch.zeros(B * rows_in + 8, C, device=xin.device, dtype=BF)
+    ops.gemm(du_i, wT[:s * C], out=dx[:s * Mi].view(Mi, s * C))                  # taps 0 .. s-1 tile the input rows exactly
+    for j in range(s, k):                                                        # overlapping taps: accumulate in place
+        tgt = torch.as_strided(dx, (Mi, C), (s * C, 1), storage_offset=j * C)
+        ops.gemm(du_i, wT[j * C:(j + 1) * C], residual=tgt, out=tgt)
+    return dW, dx
+
+
+def posconv_tail_backward(ds, u, xp, valid, pg, pv, B, Tp, d, G, Kw):
+    """s = mask(xp) + gelu(u), u = grouped_conv(mask(xp)) + bias, weight-normalised weight (g, v): gradient ds of s ->
+    (dxp bf16 [B*Tp, d], dg, dv, dbias)."""
+    dev = ds.device
+    du = ops.gelu_bwd_bf16(u, ds)
+    dbias = ops.colsum_bf16(du)
+    wfold, norm = _fold_weight_norm(pg, pv)
+    _, wg_adj = _pos_operands(wfold, G, Kw)
+    full = ops.dev_ints([Tp] * B, torch.int32, dev)
+    convT = ops.posconv_conv(ops.reverse_rows_bf16(du, B, Tp, d), full, wg_adj, B, Tp, d, G, Kw)
+    dxp = ops.posconv_dgrad_finish(convT, ds, valid, B, Tp, d, G)
+    dwf = posconv_wgrad(du, xp, valid, B, Tp, d, G, Kw)              # gradient of the FOLDED weight
+    v = pv.detach().float()
+    dot = (dwf * v).sum(dim=(0, 1), keepdim=True)                     # weight-norm: w = g v / |v|  (norm over dims 0, 1 per tap)
+    gf = pg.detach().float()
+    return dxp, (dot / norm).to(pg.dtype), (gf / norm * dwf - gf * dot / norm.pow(3) * v).to(pv.dtype), dbias
+
+
 class HubertFrontTrainFn(torch.autograd.Function):
     """h0 bf16 [B*Tp, d] = LN(mask(x) + gelu(pos_conv(mask(x)))) with x = proj(LN(conv stack(wav))).
     args: meta (conv_layers, T0, P0, Tp, d, G, Kw, grad_mult, train: compute parameter gradients), wav f32 [B, L], valid_i32 [B], N_FRONT tensors."""
@@ -149,20 +183,8 @@ class HubertFrontTrainFn(torch.autograd.Function):
         # ---- h0 = [dropout] LN(s)
         ds, grads[16], grads[17] = ops.layernorm_bwd_bf16(s_, dh0, _f32(elw), 1e-5)
         # ---- s = mask(xp) + gelu(u),  u = conv(mask(xp)) + bias
-        du = ops.gelu_bwd_bf16(u, ds)
-        grads[15] = ops.colsum_bf16(du)
-        wfold, norm = _fold_weight_norm(pg, pv)
-        _, wg_adj = _pos_operands(wfold, G, Kw)
-        full = ops.dev_ints([Tp] * B, torch.int32, dev)
-        convT = ops.posconv_conv(ops.reverse_rows_bf16(du, B, Tp, d), full, wg_adj, B, Tp, d, G, Kw)
-        dxp = ops.posconv_dgrad_finish(convT, ds, valid, B, Tp, d, G)
-        dwf = posconv_wgrad(du, xp, valid, B, Tp, d, G, Kw)              # gradient of the FOLDED weight
-        v = pv.detach().float()
-        dot = (dwf * v).sum(dim=(0, 1), keepdim=True)                     # weight-norm: w = g v / |v|  (norm over dims 0, 1 per tap)
-        gf = pg.detach().float()
-        grads[13] = (dot / norm).to(pg.dtype)
-        grads[14] = (gf / norm * dwf - gf * dot / norm.pow(3) * v).to(pv.dtype)
-        del convT, du, ds
+        dxp, grads[13], grads[14], grads[15] = posconv_tail_backward(ds, u, xp, valid, pg, pv, B, Tp, d, G, Kw)
+        del ds
         if drop is not None and drop["features"] > 0:
             ops.dropout_bf16(dxp, drop["features"], drop["seed"] ^ 0x2545F491, out=dxp)      # saved xp is the dropped tensor; its gradient takes the same mask
         # ---- xp = [dropout] (feats W^T + b) ; feats = LN(x6)
@@ -185,14 +207,7 @@ class HubertFrontTrainFn(torch.autograd.Function):
             upre = ops.gemm(xin, w16, None, ACT_NONE, M=Mi, K=k * C, lda=s * C)        # pre-activation, recomputed
             du_i = ops.gelu_bwd_bf16(upre, g)
             del upre
-            xview = torch.as_strided(xin, (Mi, k * C), (s * C, 1))
-            grads[3 + i - 1] = wgrad(du_i, xview).view(dim, k, C).permute(0, 2, 1).contiguous()
-            wT = w16.t().contiguous()                                                    # [k*C, dim]
-            dx = torch.zeros(B * rows_in + 8, C, device=dev, dtype=BF)
-            ops.gemm(du_i, wT[:s * C], out=dx[:s * Mi].view(Mi, s * C))                  # taps 0 .. s-1 tile the input rows exactly
-            for j in range(s, k):                                                        # overlapping taps: accumulate in place
-                tgt = torch.as_strided(dx, (Mi, C), (s * C, 1), storage_offset=j * C)
-                ops.gemm(du_i, wT[j * C:(j + 1) * C], residual=tgt, out=tgt)
+            grads[3 + i - 1], dx = conv_layer_backward(xin, cws[i - 1], du_i, B, rows_out, dim, k, s, C)
             g = dx[:B * rows_in]
             rows_out = rows_in
             del du_i
@@ -202,3 +217,107 @@ class HubertFrontTrainFn(torch.autograd.Function):
         dw0, dgn, dbn = ops.conv0_bwd(wav, _f32(c0w).reshape(C0, -1), _f32(gnw), _f32(gnb), g.contiguous(), T0, P0)
         grads[0], grads[1], grads[2] = dw0.view_as(c0w), dgn, dbn
         return (None, None, None, *grads)
+
+
+N_FRONT_LN = 35   # 7 x (conv w, conv b, ln w, ln b), feat-LN w b, proj w b, pos g v bias
+
+
+def front_params_ln(enc) -> list:
+    """Front-end tensors of a LayerNorm-extractor / pre-LN model (HuBERT-large) in HubertFrontLNTrainFn's order.  `encoder.layer_norm` is not among
+    them: with layer_norm_first the reference applies it to the encoder's final `x` only, which the hidden states never see (speech_encoder_plus.py:101)."""
+    convs = enc.feature_extractor.conv_layers
+    assert enc.cfg.extractor_mode == "layer_norm" and enc.cfg.conv_bias and enc.cfg.layer_norm_first and len(convs) == 7
+    out = []
+    for blk in convs:
+        c, ln = getattr(blk, "0"), getattr(getattr(blk, "2"), "1")
+        out += [c.weight, c.bias, ln.weight, ln.bias]
+    pc = getattr(enc.encoder.pos_conv, "0")
+    return out + [enc.layer_norm.weight, enc.layer_norm.bias, enc.post_extract_proj.weight, enc.post_extract_proj.bias, pc.weight_g, pc.weight_v, pc.bias]
+
+
+class HubertFrontLNTrainFn(torch.autograd.Function):
+    """The same node for the LayerNorm extractor + pre-LN encoder (HuBERT-large): every conv layer is conv + bias -> LayerNorm(C) -> GELU, the wave is
+    layer-normalised per utterance first (no parameters), and hidden state 0 = mask(x) + gelu(pos_conv(mask(x))) WITHOUT a LayerNorm, in fp32.
+    The large checkpoint has no dropouts and feature_grad_mult = 1."""
+
+    @staticmethod
+    def forward(ctx, meta, wav, lens_i32, valid_i32, *params):
+        assert len(params) == N_FRONT_LN
+        cl, T0, P0, Tp, d, G, Kw = meta["conv_layers"], meta["T0"], meta["P0"], meta["Tp"], meta["d"], meta["G"], meta["Kw"]
+        assert meta.get("drop") is None, "the LayerNorm-extractor model has no dropouts"
+        B = wav.shape[0]
+        dev = wav.device
+        if meta["normalize"]:
+            wav = ops.wave_layernorm(wav.contiguous(), lens_i32)
+        C = cl[0][0]
+        w0, b0, g0, be0 = params[:4]
+        u = ops.conv0(wav, _f32(w0).reshape(C, -1), T0, P0, bias=_f32(b0))                  # conv + bias; rows >= T0 are zeros
+        pre, acts = [u], []
+        x = torch.zeros_like(u)
+        ops.layernorm(u[:B * P0], _f32(g0), _f32(be0), gelu=True, out=x[:B * P0])
+        acts.append(x)
+        rows = P0
+        for li, (dim, k, s) in enumerate(cl[1:], start=1):
+            w, b, g, be = params[4 * li:4 * li + 4]
+            rows //= s
+            u = torch.zeros(B * rows + 8, dim, device=dev, dtype=BF)
+            ops.gemm(x, _conv_w16(w), _f32(b), ACT_NONE, out=u[:B * rows], M=B * rows, K=k * C, lda=s * C)
+            y = torch.zeros_like(u)
+            ops.layernorm(u[:B * rows], _f32(g), _f32(be), gelu=True, out=y[:B * rows])
+            pre.append(u)
+            acts.append(y)
+            x, C = y, dim
+        assert rows == Tp
+        M = B * Tp
+        flw, flb, pw, pb, pg, pv, pbias = params[28:]
+        feats = ops.layernorm(x[:M], _f32(flw), _f32(flb))
+        xp = ops.gemm(feats, pw.detach().to(BF).contiguous(), _f32(pb))
+        wfold, _ = _fold_weight_norm(pg, pv)
+        wg, _ = _pos_operands(wfold, G, Kw)
+        conv = ops.posconv_conv(xp, valid_i32, wg, B, Tp, d, G, Kw)
+        upos, s_ = ops.posconv_finish_train(xp, valid_i32, conv, _f32(pbias), B, Tp, d, G)
+        ctx.meta = meta
+        ctx.valid = valid_i32
+        ctx.save_for_backward(wav, *pre, *acts, feats, xp, upos, *[p.detach() for p in params])
+        return s_.float()                                                                     # hidden state 0 of a pre-LN model lives on the fp32 stream
+
+    @staticmethod
+    def backward(ctx, dh0):
+        meta = ctx.meta
+        cl, T0, P0, Tp, d, G, Kw = meta["conv_layers"], meta["T0"], meta["P0"], meta["Tp"], meta["d"], meta["G"], meta["Kw"]
+        t = ctx.saved_tensors
+        wav, pre, acts, (feats, xp, upos), params = t[0], t[1:8], t[8:15], t[15:18], t[18:]
+        flw, flb, pw, pb, pg, pv, pbias = params[28:]
+        B = wav.shape[0]
+        M = B * Tp
+        grads = [None] * N_FRONT_LN
+        ds = dh0.to(BF).contiguous()
+        dxp, grads[32], grads[33], grads[34] = posconv_tail_backward(ds, upos, xp, ctx.valid, pg, pv, B, Tp, d, G, Kw)
+        dfeats = ops.gemm(dxp, pw.detach().t().to(BF).contiguous())
+        grads[30], grads[31] = wgrad(dxp, feats), ops.colsum_bf16(dxp)
+        g, grads[28], grads[29] = ops.layernorm_bwd_bf16(acts[6][:M], dfeats, _f32(flw), 1e-5)
+        mult = float(meta["grad_mult"])
+        if mult != 1.0:
+            g = ops.axpy_bf16(torch.zeros_like(g), g, mult)
+        rows_out = Tp
+        for li in range(6, -1, -1):
+            dim, k, s = cl[li]
+            w, b, gam, bet = params[4 * li:4 * li + 4]
+            rows = rows_out
+            u = pre[li][:B * rows]
+            z = ops.layernorm(u, _f32(gam), _f32(bet))                                        # the GELU's argument, recomputed
+            dz = ops.gelu_bwd_bf16(z, g.contiguous())
+            del z
+            du, grads[4 * li + 2], grads[4 * li + 3] = ops.layernorm_bwd_bf16(u, dz, _f32(gam), 1e-5)
+            del dz
+            if li == 0:
+                C0 = cl[0][0]
+                dw0, db0 = ops.conv0_wgrad(wav, du.contiguous(), C0, T0, P0)
+                grads[0], grads[1] = dw0.view_as(w), db0
+                break
+            C = cl[li - 1][0]
+            grads[4 * li + 1] = ops.colsum_bf16(du)
+            grads[4 * li], dx = conv_layer_backward(acts[li - 1], w, du, B, rows_out, dim, k, s, C)
+            rows_out = rows_out * s
+            g = dx[:B * rows_out]
+        return (None, None, None, None, *grads)

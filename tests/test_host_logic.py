@@ -526,8 +526,12 @@ def test_encoder_fine_tuning_flags_follow_the_reference():
             "post_extract_proj.weight", "encoder.pos_conv.0.weight_g", "encoder.pos_conv.0.weight_v", "encoder.layer_norm.weight",
             "encoder.layers.0.fc1.weight"} <= on and "mask_emb" not in on and len(on) == 18 + 3 * 16
     large = HubertConfig(**dataclasses.asdict(HubertRefConfig.tiny(layer_norm_first=True, extractor_mode="layer_norm", conv_bias=True)))
+    fl = FairseqSpeechEncoder_Hubert("hubert_large_ll60k", trainable=True, hubert_config=large)      # the large architecture trains end to end too
+    onl = {k for k, p in fl.encoder.named_parameters() if p.requires_grad}
+    assert fl.train_front and "encoder.layer_norm.weight" not in onl and "feature_extractor.conv_layers.3.2.1.weight" in onl and "feature_extractor.conv_layers.0.0.bias" in onl
+    odd = HubertConfig(**dataclasses.asdict(HubertRefConfig.tiny(layer_norm_first=True)))               # pre-LN layers on a GroupNorm extractor: no released model
     with pytest.raises(NotImplementedError):
-        FairseqSpeechEncoder_Hubert("hubert_large_ll60k", trainable=True, hubert_config=large)      # pre-LN / LayerNorm-extractor model: not built
+        FairseqSpeechEncoder_Hubert("hubert", trainable=True, hubert_config=odd)
     with pytest.raises(AssertionError):
         FairseqSpeechEncoder_Hubert("hubert", trainable=False, unfreeze_layers=[1], hubert_config=hc)
     with pytest.raises(AssertionError):
