@@ -37,17 +37,24 @@ class SimpleVectorQuantizer(nn.Module):
             self.temp_type = "fixed"
             self.register_buffer("curr_temp", torch.FloatTensor([ast.literal_eval(temp.replace("fixed=", ""))]))
             self._fixed_temp = float(ast.literal_eval(temp.replace("fixed=", "")))   # host copy: reading the buffer would sync the stream every step
-        else:
-            raise NotImplementedError("scheduled VQ temperature is a training-time feature (SURVEY.md section 8f)")
+        else:      # "(max, min, decay)": scheduled (my_vector_quantizer.py:45-52); nothing in the reference calls set_num_updates, so it stays at max
+            self.temp_type = "scheduled"
+            t3 = ast.literal_eval(temp) if isinstance(temp, str) else tuple(temp)
+            assert len(t3) == 3, f"{t3}, {len(t3)}"
+            self.max_temp, self.min_temp, self.temp_decay = t3
+            self.curr_temp = self.max_temp
         self.groundTruthPerplexity = None
         if self.temp_type == "fixed":   # a checkpoint may carry another value in the buffer: refresh the host copy once, at load time
             self.register_load_state_dict_post_hook(lambda mod, keys: setattr(mod, "_fixed_temp", float(mod.curr_temp.detach().cpu().item())))
 
     def set_num_updates(self, num_updates):
-        pass
+        if self.temp_type == "scheduled":       # my_vector_quantizer.py:58-62
+            self.curr_temp = max(self.max_temp * self.temp_decay ** num_updates, self.min_temp)
 
     def temperature_value(self) -> float:
-        return self._fixed_temp if self.temp_type == "fixed" else float(self.curr_temp.item())
+        if self.temp_type == "fixed":
+            return self._fixed_temp
+        return float(self.curr_temp) if self.temp_type == "scheduled" else float(self.curr_temp.item())
 
     def forward(self, x, prob_msk=[0, 2, 3], produce_targets=True):
         # train mode: same statistics and hard targets; the straight-through gradient (softmax(x / temp), :133-141) is applied where the

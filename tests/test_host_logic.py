@@ -536,3 +536,21 @@ def test_encoder_fine_tuning_flags_follow_the_reference():
         FairseqSpeechEncoder_Hubert("hubert", trainable=False, unfreeze_layers=[1], hubert_config=hc)
     with pytest.raises(AssertionError):
         FairseqSpeechEncoder_Hubert("hubert", trainable=True, unfreeze_layers=[1], reinit_layers=[2], hubert_config=hc)
+
+
+def test_vq_temperature_forms_follow_the_reference():
+    """my_vector_quantizer.py:28-62: "fixed=x" (buffer), "learnable=x" (parameter), "(max, min, decay)" (scheduled: starts at max, decays with
+    set_num_updates, floored at min -- which nothing in the reference ever calls)."""
+    from speechclip_amd.module.speechclip_c_modules.vector_quantizers import SimpleVectorQuantizer as VQ
+    f = VQ("fixed=0.1")
+    assert f.temp_type == "fixed" and abs(f.temperature_value() - 0.1) < 1e-7 and "curr_temp" in dict(f.named_buffers())
+    l = VQ("learnable=0.5")
+    assert l.temp_type == "learnable" and isinstance(l.curr_temp, torch.nn.Parameter)
+    s = VQ("(2.0, 0.5, 0.9)")
+    assert s.temp_type == "scheduled" and s.temperature_value() == 2.0
+    s.set_num_updates(3)
+    assert abs(s.temperature_value() - 2.0 * 0.9 ** 3) < 1e-12
+    s.set_num_updates(1000)
+    assert s.temperature_value() == 0.5
+    f.set_num_updates(5)
+    assert abs(f.temperature_value() - 0.1) < 1e-7
