@@ -287,7 +287,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         asm volatile("" :: "v"(o[0][0]), "v"(o[1][0]));
         if (TRACE) stamp(tr_pv);
         wait_stage(j + 2 < nkv);
+#if !(defined(SC_ATTN_NOBAR) && SC_ATTN_NOBAR)     // timing probe (garbage results): no per-tile barrier -- what the waves' lock-step costs
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         stamp(tr_bar);
     };
