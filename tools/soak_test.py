@@ -29,3 +29,20 @@ for i in range(150):
     if i%50==49:
         torch.cuda.synchronize(); t1=time.perf_counter(); times.append((t1-t)/50*1e3); t=t1; ls.append(float(l))
 print("train ms/step per 50-step window:", [round(x,2) for x in times], "losses", [round(x,4) for x in ls], "alloc delta MB", (torch.cuda.memory_allocated()-m0)/1e6, "reserved delta MB", (torch.cuda.memory_reserved()-r0)/1e6)
+# ---- full-encoder fine-tuning (audio_encoder.trainable: true, with the train-mode dropouts): 40 steps at B = 64
+del model, opt
+torch.cuda.empty_cache()
+ft = bench.build_model(finetune_all=True).cuda().train()
+Bf = 64
+fb = {k: (v[:Bf] if torch.is_tensor(v) else v) for k, v in batch.items()}
+(opt,), (sch,) = ft.configure_optimizers()
+def trf():
+    opt.zero_grad(); loss = ft.training_step_end(ft.training_step(fb, 0))["loss"]; loss.backward(); opt.step(); sch["scheduler"].step(); return loss.detach()
+for _ in range(2): trf()
+torch.cuda.synchronize(); m0 = torch.cuda.memory_allocated(); r0 = torch.cuda.memory_reserved(); t = time.perf_counter(); times = []; ls = []
+for i in range(40):
+    l = trf()
+    if i % 20 == 19:
+        torch.cuda.synchronize(); t1 = time.perf_counter(); times.append((t1 - t) / 20 * 1e3); t = t1; ls.append(float(l))
+print("full-encoder train ms/step per 20-step window (B=64):", [round(x, 2) for x in times], "losses", [round(x, 4) for x in ls], "alloc delta MB",
+      (torch.cuda.memory_allocated() - m0) / 1e6, "reserved delta MB", (torch.cuda.memory_reserved() - r0) / 1e6)
