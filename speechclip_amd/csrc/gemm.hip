@@ -302,7 +302,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int64_t lda64 = 64 * p.lda, ldw64 = 64 * p.ldw;
     const int lane_a = (tid >> 3) * (int)p.lda + (((tid & 7) ^ ((tid >> 3) & 7)) << 3);   // row (tid>>3), swizzled k-chunk
     const int lane_w = (tid >> 3) * (int)p.ldw + (((tid & 7) ^ ((tid >> 3) & 7)) << 3);
+#if SC_GEMM_BUFDMA
     const int lane_a_b = lane_a * 2, lane_w_b = lane_w * 2;       // byte offsets of this lane inside a 64-row group (buffer form)
+#endif
     auto tile_m0 = [&](int t) -> int64_t { const int64_t m = (int64_t)t * 256; return m + 256 <= p.M ? m : p.M - 256; };
     auto tile_n0 = [&](int t) -> int { const int n = t * 256; return n + 256 <= p.N ? n : p.N - 256; };
     // ABL 8 (timing probe, garbage results): every tile reads its A rows from the first 2048 rows -- distinct lines per k-step, but L2-resident:
