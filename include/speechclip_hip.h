@@ -62,6 +62,11 @@ int sc_gemm_last_path(void);   /* instrumentation: 1 if the last sc_gemm_bf16 ca
 int sc_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw,
                          int64_t strideW, int w_mod, void* C, int64_t ldc, int64_t strideC,
                          const float* bias, int64_t M, int N, int K, int batch, int flags, void* stream);
+/* Two-level batch of the same products: z = zo*inner + zi reads A at zo*strideA + zi*strideA2, W at zo*strideW + zi*strideW2, writes C at
+ * zo*strideC + zi*strideC2 (elements; no bias) -- the (utterance, head) pairs of the attention backward in ONE launch per product
+ * (speechclip_amd/train_hubert.py: autograd of the [3P fairseq] MultiheadAttention inside a fine-tuned layer, speech_encoder_plus.py:52). */
+int sc_gemm_bf16_batched2(const void* A, int64_t lda, int64_t strideA, int64_t strideA2, const void* W, int64_t ldw, int64_t strideW, int64_t strideW2,
+                          void* C, int64_t ldc, int64_t strideC, int64_t strideC2, int64_t M, int N, int K, int outer, int inner, int flags, void* stream);
 
 /* ---- LayerNorm (wave-per-row, D <= 1024) -----------------------------------------------------
  * out[r,:] = [gelu]( (x[r,:] - mean) * rstd * gamma + beta ), gamma/beta may be NULL (no affine).
@@ -346,6 +351,10 @@ int sc_attn_softmax_bwd(const float* S, const float* dP, int64_t ld, int64_t str
 int sc_attn_softmax_bwd_dropout(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
                                 int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch, float scale, float drop_p,
                                 uint32_t seed, int H, int h, void* stream);
+/* the same for ALL heads in one launch: S / dP / P / dS are [B*H, Lp, ld] images (z = b*H + h), dO / O the [rows, H*64] matrices; drop_p = 0: plain */
+int sc_attn_softmax_bwd_heads(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
+                              int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int B, int H, float scale, float drop_p,
+                              uint32_t seed, void* stream);
 int sc_gelu_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, void* stream);
 int64_t sc_layernorm_bwd_bf16_partials(int64_t rows);
 int sc_layernorm_bwd_bf16(const void* x, const void* dy, const float* gamma, void* dx, float* part, int64_t rows, int D, float eps, void* stream);

@@ -20,6 +20,8 @@ struct GemmParams {
     const bf16_t* A; int64_t lda; int64_t strideA;
     const bf16_t* W; int64_t ldw; int64_t strideW; int w_mod;
     void* C; int64_t ldc; int64_t strideC;
+    // two-level batches (sc_gemm_bf16_batched2): z = zo * inner + zi; operand offset = zo * stride + zi * stride2 (inner = 0: one level)
+    int inner; int64_t strideA2, strideW2, strideC2;
     const float* bias;
     const void* residual; int64_t ldr;
     int64_t M; int N; int K;
@@ -87,8 +89,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
     const int z = blockIdx.y;
 
-    const bf16_t* A = p.A + (int64_t)z * p.strideA;
-    const bf16_t* W = p.W + (int64_t)(z % p.w_mod) * p.strideW;
+    const int zo = p.inner > 0 ? z / p.inner : z, zi = p.inner > 0 ? z - zo * p.inner : 0;
+    const bf16_t* A = p.A + (int64_t)zo * p.strideA + (int64_t)zi * p.strideA2;
+    const bf16_t* W = p.inner > 0 ? p.W + (int64_t)zo * p.strideW + (int64_t)zi * p.strideW2 : p.W + (int64_t)(z % p.w_mod) * p.strideW;
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
 
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
     // epilogue: lane holds C[m = .. + (lane & 15)][n = .. + 4*(lane>>4) + r], r = 0..3
     const float* bias = p.bias ? p.bias + (int64_t)(z % p.w_mod) * p.N : nullptr;
-    char* Cb = (char*)p.C + (int64_t)z * p.strideC * (p.out_f32 ? 4 : 2);
+    char* Cb = (char*)p.C + ((int64_t)zo * p.strideC + (int64_t)zi * p.strideC2) * (p.out_f32 ? 4 : 2);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int64_t m = m0 + wm * WM + i * 16 + frow;
@@ -916,6 +919,25 @@ extern "C" int sc_gemm_bf16_ln(const void* A, int64_t lda, const void* W, int64_
     if (mode == 2) return launch256_one<0, false, SC_ACT_NONE, true, false, 2>(p, grid, s);
     if (act == SC_ACT_GELU) return launch256_one<0, false, SC_ACT_GELU, false, false, 1>(p, grid, s);
     return launch256_one<0, false, SC_ACT_NONE, false, false, 1>(p, grid, s);
+}
+
+// Two-level batch: product z = zo * inner + zi (zo < outer) reads A at zo*strideA + zi*strideA2, W at zo*strideW + zi*strideW2 and writes C at
+// zo*strideC + zi*strideC2 (elements) -- e.g. (utterance, head) pairs of packed q|k|v rows: outer stride = rows per utterance, inner stride = 64.
+extern "C" int sc_gemm_bf16_batched2(const void* A, int64_t lda, int64_t strideA, int64_t strideA2, const void* W, int64_t ldw, int64_t strideW,
+                                     int64_t strideW2, void* C, int64_t ldc, int64_t strideC, int64_t strideC2, int64_t M, int N, int K, int outer,
+                                     int inner, int flags, void* stream) {
+    GemmParams p{};
+    SC_CHECK_ARG(outer > 0 && inner > 0 && (int64_t)outer * inner <= 65535, "sc_gemm_bf16_batched2: outer*inner=%lld must be in [1, 65535]",
+                 (long long)outer * inner);
+    p.A = (const bf16_t*)A; p.lda = lda; p.strideA = strideA; p.strideA2 = strideA2;
+    p.W = (const bf16_t*)W; p.ldw = ldw; p.strideW = strideW; p.strideW2 = strideW2; p.w_mod = 1;
+    p.C = C; p.ldc = ldc; p.strideC = strideC; p.strideC2 = strideC2; p.inner = inner;
+    p.bias = nullptr; p.residual = nullptr; p.ldr = 0;
+    p.M = M; p.N = N; p.K = K;
+    p.act = flags & SC_GEMM_ACT_MASK; p.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0;
+    SC_CHECK_ARG((strideA % 8 == 0) && (strideA2 % 8 == 0) && (strideW % 8 == 0) && (strideW2 % 8 == 0) && (strideC % 4 == 0) && (strideC2 % 4 == 0),
+                 "sc_gemm_bf16_batched2: operand strides must keep 16-byte alignment");
+    return gemm_dispatch(p, outer * inner, (hipStream_t)stream);
 }
 
 extern "C" int sc_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw,

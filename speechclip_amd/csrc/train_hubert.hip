@@ -39,13 +39,15 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
                                                                const bf16_t* __restrict__ dO, int64_t ld_do, const bf16_t* __restrict__ O, int64_t ld_o,
                                                                int64_t row_stride_z, const int32_t* __restrict__ klens, bf16_t* __restrict__ P,
                                                                bf16_t* __restrict__ dS, int L, int Lp, float scale, uint32_t drop_seed,
-                                                               uint32_t drop_thresh_, float keep_scale, uint32_t elem_base, uint32_t elem_stride_z) {
+                                                               uint32_t drop_thresh_, float keep_scale, uint32_t elem_base, uint32_t elem_stride_z, int heads) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), z = blockIdx.y;
     if (i >= Lp) return;
     bf16_t* prow = P + (int64_t)z * stride + (int64_t)i * ld;
     bf16_t* drow = dS + (int64_t)z * stride + (int64_t)i * ld;
-    const int klen = klens ? klens[z] : L;
+    // heads > 0: z = b * heads + h over ALL heads (dO / O point at column 0, rows of utterance b, head h at column h * 64); else z = utterance
+    const int zb = heads > 0 ? z / heads : z, zh = heads > 0 ? z - zb * heads : 0;
+    const int klen = klens ? klens[zb] : L;
     if (i >= L) {                                                       // padding rows of the [Lp, Lp] images: zeros (they are K-dim padding of the TN products)
         for (int j = lane; j < Lp; j += 64) { prow[j] = 0; drow[j] = 0; }
         return;
@@ -53,8 +55,8 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
     const float* srow = S + (int64_t)z * stride + (int64_t)i * ld;
     const float* gprow = dP + (int64_t)z * stride + (int64_t)i * ld;
     // D_i = dO_i . O_i over the 64 head dims (one per lane)
-    const int64_t r = (int64_t)z * row_stride_z + i;
-    const float dd = wave_sum(bf2f(dO[r * ld_do + lane]) * bf2f(O[r * ld_o + lane]));
+    const int64_t r = (int64_t)zb * row_stride_z + i;
+    const float dd = wave_sum(bf2f(dO[r * ld_do + zh * 64 + lane]) * bf2f(O[r * ld_o + zh * 64 + lane]));
     float mx = -INFINITY;
     for (int j = lane; j < klen; j += 64) mx = fmaxf(mx, srow[j] * scale);
     mx = wave_max(mx);
@@ -195,13 +197,14 @@ extern "C" int sc_transpose_bf16(const void* in, int64_t ld_in, int64_t stride_i
 
 static int attn_softmax_bwd_impl(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
                                  int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch, float scale, float drop_p,
-                                 uint32_t seed, int H, int h, void* stream) {
+                                 uint32_t seed, int H, int h, void* stream, int all_heads = 0) {
     SC_CHECK_ARG(S && dP && dO && O && P && dS && L > 0 && Lp >= L && batch > 0 && batch <= 65535 && ld >= Lp, "sc_attn_softmax_bwd: bad arguments");
     SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && H >= 1 && h >= 0 && h < H, "sc_attn_softmax_bwd_dropout: bad dropout arguments");
     // forward element index = ((b*H + h)*L + i)*L + j with b = z
     hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((Lp + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, S, dP, ld, stride, (const bf16_t*)dO, ld_do,
                        (const bf16_t*)O, ld_o, rows_per_batch, klens, (bf16_t*)P, (bf16_t*)dS, L, Lp, scale, seed, drop_thresh(drop_p), 1.0f / (1.0f - drop_p),
-                       (uint32_t)h * (uint32_t)L * (uint32_t)L, (uint32_t)H * (uint32_t)L * (uint32_t)L);
+                       all_heads ? 0u : (uint32_t)h * (uint32_t)L * (uint32_t)L, (all_heads ? 1u : (uint32_t)H) * (uint32_t)L * (uint32_t)L,
+                       all_heads ? H : 0);
     SC_CHECK_LAUNCH();
     return 0;
 }
@@ -216,6 +219,14 @@ extern "C" int sc_attn_softmax_bwd_dropout(const float* S, const float* dP, int6
                                            int64_t ld_o, int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int batch,
                                            float scale, float drop_p, uint32_t seed, int H, int h, void* stream) {
     return attn_softmax_bwd_impl(S, dP, ld, stride, dO, ld_do, O, ld_o, rows_per_batch, klens, P, dS, L, Lp, batch, scale, drop_p, seed, H, h, stream);
+}
+
+// all heads in one launch: batch = B * H images (z = b*H + h), dO / O = the [rows, H*64] matrices themselves, klens per utterance; drop_p = 0: no dropout
+extern "C" int sc_attn_softmax_bwd_heads(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O,
+                                         int64_t ld_o, int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int B, int H,
+                                         float scale, float drop_p, uint32_t seed, void* stream) {
+    SC_CHECK_ARG(B > 0 && H > 0 && (int64_t)B * H <= 65535, "sc_attn_softmax_bwd_heads: B*H must be in [1, 65535]");
+    return attn_softmax_bwd_impl(S, dP, ld, stride, dO, ld_do, O, ld_o, rows_per_batch, klens, P, dS, L, Lp, B * H, scale, drop_p, seed, H, 0, stream, 1);
 }
 
 extern "C" int sc_gelu_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, void* stream) {

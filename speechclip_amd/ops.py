@@ -931,3 +931,25 @@ def conv0_wgrad(wav, du, C, T0, P):
     check(lib().sc_conv0_wgrad(ptr(wav), L, ptr(du), ptr(part), B, C, T0, P, stream()), "sc_conv0_wgrad")
     tot = colsum(part).view(C, 12)
     return tot[:, :10].contiguous(), tot[:, 10].contiguous()
+
+
+def gemm_batched2(a, lda, stride_a, stride_a2, w, ldw, stride_w, stride_w2, out, ldc, stride_c, stride_c2, M, N, K, outer, inner):
+    """outer x inner products out_z[M,N] = a_z[M,K] w_z[N,K]^T, z = (zo, zi): operand at base + zo*stride + zi*stride2 (elements); out dtype f32 => fp32."""
+    _need_cuda(a, w, out)
+    flags = GEMM_OUT_F32 if out.dtype == torch.float32 else 0
+    check(lib().sc_gemm_bf16_batched2(ptr(a), lda, stride_a, stride_a2, ptr(w), ldw, stride_w, stride_w2, ptr(out), ldc, stride_c, stride_c2, M, N, K,
+                                      outer, inner, flags, stream()), "sc_gemm_bf16_batched2")
+    return out
+
+
+def attn_softmax_bwd_heads(S, dP, dO, O, rows_per_batch, klens_i32, L, scale, B, H, drop=None):
+    """All heads at once: S, dP f32 [B*H, Lp, Lp]; dO / O bf16 [rows, H*64]; -> (P, dS) bf16 [B*H, Lp, Lp].  drop = (p, seed) of the forward."""
+    _need_cuda(S, dP)
+    Z, Lp, _ = S.shape
+    assert Z == B * H and dO.stride(1) == 1 and O.stride(1) == 1
+    P = torch.empty(Z, Lp, Lp, device=S.device, dtype=bf16)
+    dS = torch.empty_like(P)
+    p_, seed = (float(drop[0]), int(drop[1]) & 0xffffffff) if drop is not None else (0.0, 0)
+    check(lib().sc_attn_softmax_bwd_heads(ptr(S), ptr(dP), Lp, Lp * Lp, ptr(dO), dO.stride(0), ptr(O), O.stride(0), rows_per_batch, ptr(klens_i32), ptr(P),
+                                          ptr(dS), L, Lp, B, H, float(scale), p_, seed, stream()), "sc_attn_softmax_bwd_heads")
+    return P, dS

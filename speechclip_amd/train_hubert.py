@@ -63,30 +63,37 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 
 def attention_bwd(qkv: torch.Tensor, att: torch.Tensor, datt: torch.Tensor, B: int, Tp: int, H: int, klens_i32: torch.Tensor, drop=None) -> torch.Tensor:
     """qkv bf16 [>= B*Tp (+ Lp - Tp slack rows), 3*H*64] packed (q | k | v) as the forward produced it; att / datt bf16 [B*Tp, H*64] (attention output and its
-    gradient) -> dqkv bf16 [B*Tp, 3*H*64]."""
+    gradient) -> dqkv bf16 [B*Tp, 3*H*64].  Every product covers all (utterance, head) pairs in ONE two-level batched launch; drop = (p, seed) of a
+    forward that ran attention_dropout."""
     d = H * 64
     M = B * Tp
     Lp = -(-Tp // 64) * 64
     assert qkv.shape[0] >= M + (Lp - Tp) and qkv.shape[1] == 3 * d and qkv.is_contiguous() and att.is_contiguous() and datt.is_contiguous()
     dev = qkv.device
+    Z = B * H
     dqkv = torch.empty(M, 3 * d, device=dev, dtype=BF)
-    S = torch.empty(B, Lp, Lp, device=dev, dtype=torch.float32)
-    dP = torch.empty(B, Lp, Lp, device=dev, dtype=torch.float32)
-    scale = 0.125
-    for h in range(H):
-        q, k, v = qkv[:, h * 64:], qkv[:, d + h * 64:], qkv[:, 2 * d + h * 64:]
-        do, o = datt[:, h * 64:], att[:, h * 64:]
-        ops.gemm_batched(q, 3 * d, Tp * 3 * d, k, Tp * 3 * d, B, S, Lp, Lp * Lp, None, Tp, Lp, 64, B, ldw=3 * d)      # S = Q K^T   [Tp, Lp] per utterance
-        ops.gemm_batched(do, d, Tp * d, v, Tp * 3 * d, B, dP, Lp, Lp * Lp, None, Tp, Lp, 64, B, ldw=3 * d)            # dP = dO V^T
-        P, dS = ops.attn_softmax_bwd(S, dP, do, d, o, d, Tp, klens_i32, Tp, scale, None if drop is None else (drop[0], drop[1], H, h))
-        PT = ops.transpose_bf16(P, Lp, Lp * Lp, Lp, Lp, B)
-        dST = ops.transpose_bf16(dS, Lp, Lp * Lp, Lp, Lp, B)
-        kT = ops.transpose_bf16(k, 3 * d, Tp * 3 * d, Tp, 64, B, rows_padded=Lp)          # [B, 64, Lp]
-        qT = ops.transpose_bf16(q, 3 * d, Tp * 3 * d, Tp, 64, B, rows_padded=Lp)
-        doT = ops.transpose_bf16(do, d, Tp * d, Tp, 64, B, rows_padded=Lp)
-        ops.gemm_batched(dS, Lp, Lp * Lp, kT, 64 * Lp, B, dqkv[:, h * 64:], 3 * d, Tp * 3 * d, None, Tp, 64, Lp, B, ldw=Lp)            # dQ = dS K
-        ops.gemm_batched(dST, Lp, Lp * Lp, qT, 64 * Lp, B, dqkv[:, d + h * 64:], 3 * d, Tp * 3 * d, None, Tp, 64, Lp, B, ldw=Lp)       # dK = dS^T Q
-        ops.gemm_batched(PT, Lp, Lp * Lp, doT, 64 * Lp, B, dqkv[:, 2 * d + h * 64:], 3 * d, Tp * 3 * d, None, Tp, 64, Lp, B, ldw=Lp)   # dV = P^T dO
+    S = torch.empty(Z, Lp, Lp, device=dev, dtype=torch.float32)
+    dP = torch.empty(Z, Lp, Lp, device=dev, dtype=torch.float32)
+    q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
+    img, rq, ro = Lp * Lp, Tp * 3 * d, Tp * d
+    ops.gemm_batched2(q, 3 * d, rq, 64, k, 3 * d, rq, 64, S, Lp, H * img, img, Tp, Lp, 64, B, H)                 # S = Q K^T   [Tp, Lp] per (b, h)
+    ops.gemm_batched2(datt, d, ro, 64, v, 3 * d, rq, 64, dP, Lp, H * img, img, Tp, Lp, 64, B, H)                 # dP = dO V^T
+    P, dS = ops.attn_softmax_bwd_heads(S, dP, datt, att, Tp, klens_i32, Tp, 0.125, B, H, drop)
+    del S, dP
+    PT = ops.transpose_bf16(P, Lp, img, Lp, Lp, Z)
+    dST = ops.transpose_bf16(dS, Lp, img, Lp, Lp, Z)
+    del P
+    kT = torch.empty(Z, 64, Lp, device=dev, dtype=BF)
+    qT, doT = torch.empty_like(kT), torch.empty_like(kT)
+    for h in range(H):                                                  # [Tp, 64] blocks of the packed rows -> [64, Lp] per (b, h)
+        o = h * 64 * Lp
+        ops.transpose_bf16(k[:, h * 64:], 3 * d, rq, Tp, 64, B, rows_padded=Lp, out=kT.view(-1)[o:], ld_out=Lp, stride_out=H * 64 * Lp)
+        ops.transpose_bf16(q[:, h * 64:], 3 * d, rq, Tp, 64, B, rows_padded=Lp, out=qT.view(-1)[o:], ld_out=Lp, stride_out=H * 64 * Lp)
+        ops.transpose_bf16(datt[:, h * 64:], d, ro, Tp, 64, B, rows_padded=Lp, out=doT.view(-1)[o:], ld_out=Lp, stride_out=H * 64 * Lp)
+    t = 64 * Lp
+    ops.gemm_batched2(dS, Lp, H * img, img, kT, Lp, H * t, t, dqkv, 3 * d, rq, 64, Tp, 64, Lp, B, H)                      # dQ = dS K
+    ops.gemm_batched2(dST, Lp, H * img, img, qT, Lp, H * t, t, dqkv[:, d:], 3 * d, rq, 64, Tp, 64, Lp, B, H)              # dK = dS^T Q
+    ops.gemm_batched2(PT, Lp, H * img, img, doT, Lp, H * t, t, dqkv[:, 2 * d:], 3 * d, rq, 64, Tp, 64, Lp, B, H)          # dV = P^T dO
     return dqkv
 
 
@@ -256,7 +263,7 @@ class HubertLayersTrainFn(torch.autograd.Function):
             # y1 = dropout1(att Wo^T + bo) + h
             dy1 = dy1r if drop is None else ops.dropout_bf16(dy1r, drop["hidden"], s1)
             datt = ops.gemm(dy1, _w16(ow.t()))
-            dqkv = attention_bwd(qkv, att, datt, B, Tp, H, ctx.valid, None if drop is None else (drop["attention"], sa))
+            dqkv = attention_bwd(qkv, att, datt, B, Tp, H, ctx.valid, None if drop is None or drop["attention"] <= 0 else (drop["attention"], sa))
             wqkv = torch.cat([qw, kw, vw], 0)
             dh = ops.gemm(dqkv, _w16(wqkv.t()), residual=dy1r)                 # [M, d] = dqkv Wqkv + dy1 (unmasked: the residual path)
             if want:
