@@ -136,14 +136,83 @@ __global__ __launch_bounds__(256) void ln_bwd_bf16_kernel(const bf16_t* __restri
     }
 }
 
+// The same for D % 256 == 0 (512 / 768 / 1024): a lane owns 4 consecutive elements of every 256-element group (8-byte loads and stores instead of
+// 2-byte ones) -- the scalar form above moved 0.56 TB/s on [82 k, 768], this one is HBM-bound.
+__global__ __launch_bounds__(256) void ln_bwd_bf16_vec_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ gamma,
+                                                              bf16_t* __restrict__ dx, float* __restrict__ part, int64_t rows, int D, float eps,
+                                                              int rows_per_block) {
+    __shared__ float sg[4][1024], sb[4][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int ng = D / 256;                                            // <= 4
+    float ag[4][4], ab[4][4], g[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ag[m][j] = 0.f; ab[m][j] = 0.f; g[m][j] = (m < ng) ? gamma[m * 256 + lane * 4 + j] : 0.f; }
+    for (int64_t row = row_begin + w; row < row_begin + rows_per_block && row < rows; row += 4) {
+        float xv[4][4], gv[4][4];
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) if (m < ng) {
+            const uint2 u = *(const uint2*)(x + row * D + m * 256 + lane * 4);
+            xv[m][0] = lo2f(u.x); xv[m][1] = hi2f(u.x); xv[m][2] = lo2f(u.y); xv[m][3] = hi2f(u.y);
+            s += (xv[m][0] + xv[m][1]) + (xv[m][2] + xv[m][3]);
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) if (m < ng)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = xv[m][j] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) if (m < ng) {
+            const uint2 u = *(const uint2*)(dy + row * D + m * 256 + lane * 4);
+            const float dv[4] = {lo2f(u.x), hi2f(u.x), lo2f(u.y), hi2f(u.y)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xv[m][j] - mean) * rstd;
+                gv[m][j] = dv[j] * g[m][j];
+                s1 += gv[m][j]; s2 += gv[m][j] * xh;
+                ag[m][j] += dv[j] * xh; ab[m][j] += dv[j];
+                xv[m][j] = xh;
+            }
+        }
+        s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) if (m < ng) {
+            uint2 o;
+            o.x = pack2bf(rstd * (gv[m][0] - s1 - xv[m][0] * s2), rstd * (gv[m][1] - s1 - xv[m][1] * s2));
+            o.y = pack2bf(rstd * (gv[m][2] - s1 - xv[m][2] * s2), rstd * (gv[m][3] - s1 - xv[m][3] * s2));
+            *(uint2*)(dx + row * D + m * 256 + lane * 4) = o;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) if (m < ng)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sg[w][m * 256 + lane * 4 + j] = ag[m][j]; sb[w][m * 256 + lane * 4 + j] = ab[m][j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        part[((int64_t)blockIdx.x * 2 + 0) * D + c] = (sg[0][c] + sg[1][c]) + (sg[2][c] + sg[3][c]);
+        part[((int64_t)blockIdx.x * 2 + 1) * D + c] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_bf16_stage1_kernel(const bf16_t* __restrict__ x, int64_t ld, int64_t rows, int cols, float* __restrict__ part,
                                                                  int rows_per_block) {
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= cols) return;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    float s = 0.f;
-    for (int64_t r = r0; r < r0 + rows_per_block && r < rows; ++r) s += bf2f(x[r * ld + c]);
-    part[(int64_t)blockIdx.x * cols + c] = s;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {                                       // four independent loads in flight per thread
+        s0 += bf2f(x[r * ld + c]); s1 += bf2f(x[(r + 1) * ld + c]); s2 += bf2f(x[(r + 2) * ld + c]); s3 += bf2f(x[(r + 3) * ld + c]);
+    }
+    for (; r < r1; ++r) s0 += bf2f(x[r * ld + c]);
+    part[(int64_t)blockIdx.x * cols + c] = (s0 + s1) + (s2 + s3);
 }
 __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -239,14 +308,18 @@ extern "C" int sc_gelu_bwd_bf16(const void* u, const void* dh, void* du, int64_t
 }
 
 extern "C" int64_t sc_layernorm_bwd_bf16_partials(int64_t rows) {   // number of partial rows the kernel writes: part is f32 [partials, 2, D]
-    const int64_t rpb = rows >= 65536 ? 128 : (rows >= 4096 ? 32 : 4);
+    const int64_t rpb = rows >= 4096 ? 32 : 4;
     return (rows + rpb - 1) / rpb;
 }
 
 extern "C" int sc_layernorm_bwd_bf16(const void* x, const void* dy, const float* gamma, void* dx, float* part, int64_t rows, int D, float eps, void* stream) {
     SC_CHECK_ARG(D > 0 && D <= 1024 && D % 64 == 0, "sc_layernorm_bwd_bf16: D=%d must be a multiple of 64, <= 1024", D);
     if (rows <= 0) return 0;
-    const int rpb = rows >= 65536 ? 128 : (rows >= 4096 ? 32 : 4);
+    const int rpb = rows >= 4096 ? 32 : 4;
+    if (D % 256 == 0)
+        hipLaunchKernelGGL(ln_bwd_bf16_vec_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (const bf16_t*)dy, gamma, (bf16_t*)dx, part, rows, D, eps, rpb);
+    else
     hipLaunchKernelGGL(ln_bwd_bf16_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, gamma,
                        (bf16_t*)dx, part, rows, D, eps, rpb);
     SC_CHECK_LAUNCH();
@@ -254,13 +327,13 @@ extern "C" int sc_layernorm_bwd_bf16(const void* x, const void* dy, const float*
 }
 
 extern "C" int64_t sc_colsum_bf16_workspace_bytes(int64_t rows, int cols) {
-    const int64_t rpb = rows >= 65536 ? 512 : 64;
+    const int64_t rpb = rows >= 65536 ? 128 : 64;
     return ((rows + rpb - 1) / rpb) * (int64_t)cols * 4;
 }
 
 extern "C" int sc_colsum_bf16(const void* x, int64_t ld, int64_t rows, int cols, float* ws, float* out, int accumulate, void* stream) {
     if (rows <= 0 || cols <= 0) return 0;
-    const int rpb = rows >= 65536 ? 512 : 64;
+    const int rpb = rows >= 65536 ? 128 : 64;
     const int nparts = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(colsum_bf16_stage1_kernel, dim3(nparts, (cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows, cols, ws, rpb);
     hipLaunchKernelGGL(colsum_stage2_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, nparts, cols, out, accumulate);

@@ -47,7 +47,7 @@ def test_gelu_bwd_colsum_axpy_bf16():
     torch.testing.assert_close(y.float(), y0.float() + 0.37 * x.reshape(-1)[:4096].float().cuda(), atol=2e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("rows,D", [(301, 768), (70000, 128), (7, 64)])
+@pytest.mark.parametrize("rows,D", [(301, 768), (70000, 128), (7, 64), (70000, 512), (5000, 1024), (33, 256)])
 def test_layernorm_bwd_bf16_vs_autograd(rows, D):
     from speechclip_amd import ops
     g = _g(rows)
