@@ -29,6 +29,16 @@ def test_transpose_bf16_strided_batched_padded(R, C, Rp, Z):
     out = ops.transpose_bf16(src, ld, R * ld, R, C, Z, rows_padded=Rp)
     assert out.shape == (Z, C, Rp)
     assert torch.equal(out[:, :, :R], src[:, :, :C].transpose(1, 2)) and bool((out[:, :, R:] == 0).all())
+    if C >= 8:          # a view that starts 2 elements in (4-byte aligned only): the scalar form must take over, same result
+        sub = src.view(-1)[2:]
+        o2 = ops.transpose_bf16(sub, ld, R * ld, R, C - 4, Z, rows_padded=Rp)
+        assert torch.equal(o2[:, :, :R], src[:, :, 2:C - 2].transpose(1, 2))
+    # an overlapping-row (sliding-window) view: ld_in < cols
+    if R >= 8:
+        flat = src[0].reshape(-1)[: (R + 16) * 8].contiguous()
+        ov = ops.transpose_bf16(flat, 8, 0, R, 64, 1, rows_padded=Rp)[0]                 # row r = flat[8 r : 8 r + 64]
+        ref = torch.stack([flat[8 * r: 8 * r + 64] for r in range(R)], 1)
+        assert torch.equal(ov[:, :R], ref)
 
 
 def test_gelu_bwd_colsum_axpy_bf16():
