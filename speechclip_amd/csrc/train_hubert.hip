@@ -115,11 +115,23 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
 }
 
 __global__ __launch_bounds__(256) void gelu_bwd_bf16_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ dh, bf16_t* __restrict__ du, int64_t n) {
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
-    if (i >= n) return;
-    const uint32_t uu = *(const uint32_t*)(u + i), gg = *(const uint32_t*)(dh + i);
     auto d = [](float x) { return 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x); };
-    *(uint32_t*)(du + i) = pack2bf(lo2f(gg) * d(lo2f(uu)), hi2f(gg) * d(hi2f(uu)));
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;      // 16 bytes per lane; the tail (n % 8, n even) goes pair by pair
+    if (i >= n) return;
+    if (i + 8 <= n) {
+        const uint4 uu = *(const uint4*)(u + i), gg = *(const uint4*)(dh + i);
+        uint4 o;
+        o.x = pack2bf(lo2f(gg.x) * d(lo2f(uu.x)), hi2f(gg.x) * d(hi2f(uu.x)));
+        o.y = pack2bf(lo2f(gg.y) * d(lo2f(uu.y)), hi2f(gg.y) * d(hi2f(uu.y)));
+        o.z = pack2bf(lo2f(gg.z) * d(lo2f(uu.z)), hi2f(gg.z) * d(hi2f(uu.z)));
+        o.w = pack2bf(lo2f(gg.w) * d(lo2f(uu.w)), hi2f(gg.w) * d(hi2f(uu.w)));
+        *(uint4*)(du + i) = o;
+        return;
+    }
+    for (int64_t j = i; j < n; j += 2) {
+        const uint32_t uu = *(const uint32_t*)(u + j), gg = *(const uint32_t*)(dh + j);
+        *(uint32_t*)(du + j) = pack2bf(lo2f(gg) * d(lo2f(uu)), hi2f(gg) * d(hi2f(uu)));
+    }
 }
 
 // LayerNorm backward, bf16 rows: dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)); per-chunk partial sums of dy xhat (dgamma) and dy (dbeta).
@@ -340,7 +352,8 @@ extern "C" int sc_attn_softmax_bwd_heads(const float* S, const float* dP, int64_
 extern "C" int sc_gelu_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, void* stream) {
     SC_CHECK_ARG(n % 2 == 0, "sc_gelu_bwd_bf16: n=%lld must be even", (long long)n);
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(gelu_bwd_bf16_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)u, (const bf16_t*)dh,
+    SC_CHECK_ARG((((uintptr_t)u | (uintptr_t)dh | (uintptr_t)du) & 15) == 0, "sc_gelu_bwd_bf16: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(gelu_bwd_bf16_kernel, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)u, (const bf16_t*)dh,
                        (bf16_t*)du, n);
     SC_CHECK_LAUNCH();
     return 0;

@@ -49,6 +49,8 @@ def test_gelu_bwd_colsum_axpy_bf16():
     uf = u.float().requires_grad_(True)
     F.gelu(uf).backward(dh.float())
     torch.testing.assert_close(ops.gelu_bwd_bf16(u.cuda(), dh.cuda()).float().cpu(), uf.grad, atol=2e-2, rtol=2e-2)
+    ut, dt = u.reshape(-1)[:4102].contiguous(), dh.reshape(-1)[:4102].contiguous()          # 4102 = 8 * 512 + 6: the pairwise tail
+    torch.testing.assert_close(ops.gelu_bwd_bf16(ut.cuda(), dt.cuda()).float().cpu(), uf.grad.reshape(-1)[:4102], atol=2e-2, rtol=2e-2)
     x = torch.randn(70000, 96, generator=g).to(BF)
     torch.testing.assert_close(ops.colsum_bf16(x.cuda()).cpu(), x.float().sum(0), atol=0.05, rtol=1e-3)
     y = torch.randn(4096, generator=g).to(BF).cuda()
