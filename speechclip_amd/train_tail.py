@@ -50,6 +50,15 @@ def _mfma_f32(a: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     return ops.gemm(ops.split_hilo(a), w2, out_f32=True)
 
 
+def _hidden_rows(hid, B, Tp, D):
+    """hidden [n, B, Tp', D] -> contiguous [n, B*Tp, D] rows matching the frames view's row count.  With B == 1 the frames view has no batch stride
+    to read the padded length Tp' from and uses Tp = T; the padding rows of the states are cut off then (a small copy, B == 1 only)."""
+    if hid.shape[2] != Tp:
+        assert B == 1 and hid.shape[2] > Tp, (tuple(hid.shape), B, Tp)
+        hid = hid[:, :, :Tp].contiguous()
+    return hid.reshape(hid.shape[0], B * Tp, D)
+
+
 class ParallelBranchTrainFn(torch.autograd.Function):
     """out f32 [B, E (or D)] = linear_proj(norm(layer([CLS; mix(hidden)]))[:, 0]).
 
@@ -155,7 +164,7 @@ class ParallelBranchTrainFn(torch.autograd.Function):
         ops.colsum(datt, out=dbin[2 * D:])
         ops.sgemm_batched(B, D, hd, datt, D, hd, Wv, D, hd * D, dzbar, R * D, D, H)                               # dzbar_h = datt_h Wv_h
         hid = ctx.hidden
-        hid2 = hid.reshape(hid.shape[0], B * Tp, D) if (has_mix and hid is not None) else None
+        hid2 = _hidden_rows(hid, B, Tp, D) if (has_mix and hid is not None) else None
         dx16 = None
         if ctx.needs_input_grad[2]:      # the frames themselves carry a gradient (fine-tuned encoder layers: train_hubert.py)
             du, dck, dalpha, ds_ws, pp_ws = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)),
@@ -254,7 +263,7 @@ class CascadedPoolTrainFn(torch.autograd.Function):
         ops.colsum(datt, out=dbin[2 * D:])
         ops.sgemm_batched(B * NQ, D, hd, datt, D, hd, Wv, D, hd * D, dzbar, H * D, D, H)                          # dzbar_h = datt_h Wv_h
         hid = ctx.hidden
-        hid2 = hid.reshape(hid.shape[0], B * Tp, D) if (ctx.has_mix and hid is not None) else None
+        hid2 = _hidden_rows(hid, B, Tp, D) if (ctx.has_mix and hid is not None) else None
         dx16 = None
         if ctx.needs_input_grad[2]:      # fine-tuned encoder layers below: the frames carry a gradient (train_hubert.py)
             du, dck, dalpha, ds_ws, pp_ws = ops.cls_pool_bwd(rows, c, hid2, p, dzbar, U, lens_i, B, Tp, NQ, R, D, normalize=bool(m.get("normalize", False)),

@@ -478,3 +478,21 @@ def test_cascaded_branch_passes_the_frame_gradient_down_too(tmp_path):
         sch["scheduler"].step()
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and np.mean(losses[-4:]) < np.mean(losses[:3]), losses
+
+
+@pytest.mark.parametrize("everything", [False, True])
+def test_single_utterance_batch_goes_through_the_training_path(everything):
+    """B = 1: the pooling head's frames view has no batch stride to read the padded frame count from (it uses T), while the hidden states keep
+    their padded rows -- the layer-mix gradient has to reconcile the two (a reshape used to fail here).  One pair has zero InfoNCE loss; the
+    step must still run end to end and leave finite (zero) gradients."""
+    model, _, batch = _finetune_pair([] if everything else [2], everything=everything)
+    model = model.cuda().train()
+    one = {k: v[:1].cuda() for k, v in batch.items()}
+    one["wav"] = one["wav"][:, :6777]
+    one["wav_len"] = torch.tensor([6777]).cuda()
+    loss = model.training_step_end(model.training_step(one, 0))["loss"]
+    loss.backward()
+    assert abs(loss.item()) < 1e-5
+    g = model.audio_encoder.weightedsum_layer.weights.grad
+    assert g is not None and torch.isfinite(g).all()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
