@@ -135,6 +135,10 @@ int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, con
 int sc_attention_fwd_dropout(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H, int T, int head_dim,
                              int64_t ld_qkv, int64_t ld_out, float scale, int causal, float drop_p, uint32_t seed, void* stream);
 int sc_dropout_bf16(const void* x, const void* residual, void* out, int64_t n, float drop_p, uint32_t seed, void* stream);
+/* out = LayerNorm(residual + dropout(x)), bf16 [rows, D]: the post-LN sites of a [3P fairseq] TransformerSentenceEncoderLayer in train mode in ONE pass
+ * (same mask as sc_dropout_bf16: element index = row*D + column).  Returns 1 when D is not covered (768 is): run sc_dropout_bf16 + sc_layernorm_fwd. */
+int sc_dropout_add_layernorm_bf16(const void* x, const void* residual, const float* gamma, const float* beta, void* out, int64_t rows, int D, float eps,
+                                  float drop_p, uint32_t seed, void* stream);
 
 /* CLS-rows-only attention of the pooling heads (kwClip.py:1089-1099 parallel, :869-881 cascaded):
  * NQ learned query tokens attend to [NQ CLS tokens ; frames t < lens[b]].  cls_qkv: bf16 [NQ, 3*D]

@@ -65,6 +65,7 @@ def _declare(L):
         "sc_attention_fwd": ([P, P, P, P, P, I, I, I, I, L64, L64, F, I, P], c_int),
         "sc_attention_fwd_dropout": ([P, P, P, P, P, I, I, I, I, L64, L64, F, I, F, U32, P], c_int),
         "sc_dropout_bf16": ([P, P, P, L64, F, U32, P], c_int),
+        "sc_dropout_add_layernorm_bf16": ([P, P, P, P, P, L64, I, F, F, U32, P], c_int),
         "sc_cls_attention_fwd": ([P, P, L64, P, P, I, I, I, I, I, F, P], c_int),
         "sc_attention_rows_fwd": ([P, P, P, P, P, I, I, I, I, L64, L64, F, P], c_int),
         "sc_attention_probs_fwd": ([P, P, P, P, I, I, I, I, I, L64, F, P], c_int),

@@ -98,8 +98,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 
 // Fast path for the hot shape (D = 768, bf16 -> bf16, affine): a wave owns TWO consecutive rows = 192 chunks of 16 B = exactly 3 chunks
 // per lane (16-byte loads/stores; chunk c = lane + 64*i belongs to row c / 96).  4 x this per step is 25 LayerNorms over [128000, 768].
+// DROPRES: the row that is normalised is residual + dropout(x) (train-mode frozen encoder: x = LN(x + dropout(branch)), one pass instead of two;
+// same counter-based mask as sc_dropout_bf16 -- element index = row * 768 + column).
+template <bool DROPRES>
 __global__ __launch_bounds__(256) void layernorm768_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           bf16_t* __restrict__ out, int64_t rows, float eps) {
+                                                           bf16_t* __restrict__ out, int64_t rows, float eps, const bf16_t* __restrict__ residual,
+                                                           uint32_t drop_seed, uint32_t drop_thresh_, float keep_scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
     if (row0 >= rows) return;
@@ -115,6 +119,14 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const bf16_t* __restr
         if (!rsel[i] || two) u = *(const uint4*)(x + (row0 + rsel[i]) * 768 + col[i]);
         v[i][0] = lo2f(u.x); v[i][1] = hi2f(u.x); v[i][2] = lo2f(u.y); v[i][3] = hi2f(u.y);
         v[i][4] = lo2f(u.z); v[i][5] = hi2f(u.z); v[i][6] = lo2f(u.w); v[i][7] = hi2f(u.w);
+        if (DROPRES) {
+            uint4 r = make_uint4(0, 0, 0, 0);
+            if (!rsel[i] || two) r = *(const uint4*)(residual + (row0 + rsel[i]) * 768 + col[i]);
+            const float rv[8] = {lo2f(r.x), hi2f(r.x), lo2f(r.y), hi2f(r.y), lo2f(r.z), hi2f(r.z), lo2f(r.w), hi2f(r.w)};
+            const uint32_t e0 = (uint32_t)((row0 + rsel[i]) * 768 + col[i]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[i][k] = rv[k] + (keep_elem(drop_seed, e0 + k, drop_thresh_) ? v[i][k] * keep_scale : 0.f);
+        }
     }
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -365,7 +377,8 @@ extern "C" int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, co
     hipStream_t s = (hipStream_t)stream;
     const int gelu = (flags & SC_LN_GELU) ? 1 : 0;
     if (D == 768 && flags == 0 && gamma && ld_in == 768 && ld_out == 768 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
-        hipLaunchKernelGGL(layernorm768_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, rows, eps);
+        hipLaunchKernelGGL((layernorm768_kernel<false>), dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, rows, eps,
+                           (const bf16_t*)nullptr, 0u, 0u, 1.0f);
         SC_CHECK_LAUNCH();
         return 0;
     }
@@ -381,6 +394,20 @@ extern "C" int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, co
     else if (in32) hipLaunchKernelGGL((layernorm_kernel<true, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
     else if (out32) hipLaunchKernelGGL((layernorm_kernel<false, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
     else hipLaunchKernelGGL((layernorm_kernel<false, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+// out = LayerNorm(residual + dropout(x)) for bf16 [rows, 768] (the two post-LN sites of a HuBERT-base layer in train mode); returns 1 for any other
+// width (the caller then runs sc_dropout_bf16 + sc_layernorm_fwd).
+extern "C" int sc_dropout_add_layernorm_bf16(const void* x, const void* residual, const float* gamma, const float* beta, void* out, int64_t rows, int D,
+                                             float eps, float drop_p, uint32_t seed, void* stream) {
+    SC_CHECK_ARG(x && residual && gamma && beta && out, "sc_dropout_add_layernorm_bf16: null operand");
+    SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_dropout_add_layernorm_bf16: drop_p=%f must be in [0, 1)", (double)drop_p);
+    if (D != 768 || ((((uintptr_t)x | (uintptr_t)residual | (uintptr_t)out) & 15) != 0) || rows * 768 >= 0xffffffffLL) return 1;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL((layernorm768_kernel<true>), dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)out,
+                       rows, eps, (const bf16_t*)residual, seed, drop_thresh(drop_p), 1.0f / (1.0f - drop_p));
     SC_CHECK_LAUNCH();
     return 0;
 }

@@ -412,14 +412,12 @@ class HubertModel(nn.Module):
                 ops.gemm(h, L["wqkv"], L["bqkv"], out=qkv)
                 ops.attention_dropout(qkv, B, Tp, H, valid_i32, rates["attention"], next_seed(), out=att)
                 ops.gemm(att, L["wo"], L["bo"], out=tmp)
-                ops.dropout_bf16(tmp, rates["hidden"], next_seed(), residual=h, out=tmp)
-                ops.layernorm(tmp, *L["ln1"], out=tmp2)
+                ops.dropout_add_layernorm(tmp, h, *L["ln1"], rates["hidden"], next_seed(), out=tmp2)
                 ops.gemm(tmp2, L["w1"], L["b1"], ACT_GELU, out=ffn)
                 if rates["activation"] > 0:
                     ops.dropout_bf16(ffn, rates["activation"], next_seed(), out=ffn)
                 ops.gemm(ffn, L["w2"], L["b2"], out=tmp)
-                ops.dropout_bf16(tmp, rates["hidden"], next_seed(), residual=tmp2, out=tmp)
-                ops.layernorm(tmp, *L["ln2"], out=h_out)
+                ops.dropout_add_layernorm(tmp, tmp2, *L["ln2"], rates["hidden"], next_seed(), out=h_out)
             elif not pre_ln:
                 ops.gemm(h, L["wqkv"], L["bqkv"], out=qkv)
                 ops.attention(qkv, B, Tp, H, valid_i32, out=att)

@@ -256,6 +256,21 @@ def dropout_bf16(x, drop_p, seed, residual=None, out=None):
     return out
 
 
+def dropout_add_layernorm(x, residual, gamma, beta, drop_p, seed, eps=1e-5, out=None):
+    """out = LayerNorm(residual + dropout(x)) for bf16 [rows, D]: one fused pass for D = 768, else sc_dropout_bf16 (into x, in place) + layernorm."""
+    _need_cuda(x, residual)
+    assert x.dtype == bf16 and residual.dtype == bf16 and x.is_contiguous() and residual.is_contiguous() and x.shape == residual.shape and x.dim() == 2
+    if out is None:
+        out = torch.empty_like(x)
+    rc = lib().sc_dropout_add_layernorm_bf16(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(out), x.shape[0], x.shape[1], eps, float(drop_p),
+                                             int(seed) & 0xffffffff, stream())
+    if rc == 1:
+        dropout_bf16(x, drop_p, seed, residual=residual, out=x)
+        return layernorm(x, gamma, beta, eps, out=out)
+    check(rc, "sc_dropout_add_layernorm_bf16")
+    return out
+
+
 def attention_rows(qkv, B, L, H, hd, key_padding_mask=None, scale=None):
     """Full-row MHA for any head dim: qkv bf16 [B*L, 3*H*hd] packed (q|k|v); key_padding_mask bool/uint8 [B, L] (True = padding) or None.
     Returns bf16 [B*L, H*hd] (heads concatenated, before out_proj)."""

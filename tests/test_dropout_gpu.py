@@ -222,3 +222,24 @@ def test_full_encoder_training_step_with_dropout_runs_and_is_seeded(monkeypatch)
     assert l1 == l2 and torch.equal(g1, g2)                           # same torch seed -> same masks -> same step
     assert l1 != l3 and not torch.equal(g1, g3)
     assert np.isfinite(l1) and torch.isfinite(g1).all() and g1.abs().max().item() > 0
+
+
+def test_fused_dropout_residual_layernorm_matches_the_two_step_form():
+    """sc_dropout_add_layernorm_bf16 (D = 768): LayerNorm(residual + dropout(x)) in one pass, same mask as sc_dropout_bf16 (re-stated in numpy)."""
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(12)
+    rows, D, p, seed = 517, 768, 0.1, 4242
+    x = torch.randn(rows, D, generator=g).to(BF)
+    res = torch.randn(rows, D, generator=g).to(BF)
+    gamma, beta = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    out = ops.dropout_add_layernorm(x.clone().cuda(), res.cuda(), gamma.cuda(), beta.cuda(), p, seed).float().cpu()
+    m = _keep(seed, np.arange(rows * D), p).view(rows, D) / (1 - p)
+    ref = torch.nn.functional.layer_norm(res.float() + x.float() * m, (D,), gamma, beta, 1e-5)
+    assert (out - ref).abs().max().item() < 3e-2 and torch.nn.functional.cosine_similarity(out.reshape(1, -1), ref.reshape(1, -1)).item() > 0.9999
+    two = ops.layernorm(ops.dropout_bf16(x.cuda(), p, seed, residual=res.cuda()), gamma.cuda(), beta.cuda()).float().cpu()
+    assert (out - two).abs().max().item() < 6e-2                                  # the two-step form rounds the sum to bf16 first
+    # other widths fall back to the two-step form with the same result as calling it by hand
+    x2, r2 = x[:, :128].contiguous(), res[:, :128].contiguous()
+    fb = ops.dropout_add_layernorm(x2.clone().cuda(), r2.cuda(), gamma[:128].cuda().contiguous(), beta[:128].cuda().contiguous(), p, seed)
+    hand = ops.layernorm(ops.dropout_bf16(x2.cuda(), p, seed, residual=r2.cuda()), gamma[:128].cuda().contiguous(), beta[:128].cuda().contiguous())
+    assert torch.equal(fb, hand)
