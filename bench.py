@@ -436,6 +436,11 @@ def main():
     mal = int(getattr(model.audio_encoder, "max_audio_len", -1))
     L_eff = min(L, mal) if (args.train and mal > 0) else L
     total_gf, gemm_gf = algorithmic_gflop_per_pair(L_eff, **(LARGE if large else {}))
+    mode_str = "forward + loss"
+    if args.train:
+        what = " + the whole HuBERT encoder" if args.finetune_all else (" + HuBERT layers %s" % args.finetune_layers if args.finetune_layers else "")
+        drops = "off (SC_FROZEN_DROPOUT=0)" if os.environ.get("SC_FROZEN_DROPOUT", "1") == "0" else "on"
+        mode_str = "train (tail: branch + layer-mix weights%s; encoder in train mode, its checkpoint dropouts %s)" % (what, drops)
     if rank == 0:
         roof = None
         if prof:
@@ -503,7 +508,7 @@ def main():
                           + " forward + InfoNCE, 10 s/16 kHz audio + 224^2 images",
                           "pairs_per_gpu": B, "global_batch": world * B, "audio_samples": L_eff, "frames": conv_lens(L_eff)[-1],
                           "parallelism": f"dp{world}" if world > 1 else "single", "weights": "random-init (no network)",
-                          "algorithmic_gflop_per_pair": round(total_gf, 2), "mode": ("train (tail: branch + layer-mix weights%s; encoder in train mode: its checkpoint dropouts " + ("off (SC_FROZEN_DROPOUT=0)" if os.environ.get("SC_FROZEN_DROPOUT", "1") == "0" else "on") + ")") % (" + the whole HuBERT encoder" if args.finetune_all else " + HuBERT layers %s" % args.finetune_layers if args.finetune_layers else "")) if args.train else "forward + loss"},
+                          "algorithmic_gflop_per_pair": round(total_gf, 2), "mode": mode_str},
                "e2e_tflops_per_gpu": round(total_gf * 1e9 * pairs_per_s / world / 1e12, 1),
                "e2e_frac_of_bf16_peak": round(total_gf * 1e9 * pairs_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
                "rccl_ranks_seen": int(seen.item()), "exchange_ms_per_step": exchange_ms,
