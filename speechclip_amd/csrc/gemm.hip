@@ -22,6 +22,7 @@ struct GemmParams {
     void* C; int64_t ldc; int64_t strideC;
     // two-level batches (sc_gemm_bf16_batched2): z = zo * inner + zi; operand offset = zo * stride + zi * stride2 (inner = 0: one level)
     int inner; int64_t strideA2, strideW2, strideC2;
+    int nbatch;                    // gemm256 BATCH variant: independent products z < nbatch (A + z strideA, W + (z % w_mod) strideW, C + z strideC)
     const float* bias;
     const void* residual; int64_t ldr;
     int64_t M; int N; int K;
@@ -228,7 +229,9 @@ __device__ __forceinline__ void stage256(const StageAddr& sa, int lane_a, int la
 // EPI: 0 plain; 1 the A operand is a pre-LayerNorm tensor (LN folded: W pre-scaled by gamma, per-row (mean, rstd) applied to the accumulator);
 // 2 the residual operand is a pre-LayerNorm tensor (reconstructed per element from its row statistics) and the per-row partial statistics of
 // the output are emitted for the NEXT LayerNorm.  bf16 vector path only (the dispatcher checks the shape rules).
-template <int ABL, bool TRACE, int ACT, bool RES, bool RING3, int EPI = 0>
+// BATCH: the persistent tile list runs over nbatch independent products of the same shape (the split-K partial products of a weight gradient:
+// speechclip_amd/train_hubert.py::wgrad); every tile carries its product index, the operands move by a per-product stride.  Plain epilogue only.
+template <int ABL, bool TRACE, int ACT, bool RES, bool RING3, int EPI = 0, bool BATCH = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -272,9 +275,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     // Persistent: one block per CU walks the tile list (a new 512-thread / 144 KiB block per tile costs several us of
     // dispatch + an exposed prologue).  XCD-aware order: block b runs on XCD b % 8 and takes a contiguous chunk of the
     // tile space, M-panel-major, so the N-tiles of one A panel are L2 hits on the same XCD.
-    const int nwg = p.tiles_m * p.tiles_n;
+    const int per_product = p.tiles_m * p.tiles_n;
+    const int nwg = per_product * (BATCH ? p.nbatch : 1);
     const int G = gridDim.x;
-    auto tile_of = [&](int it, int& tm, int& tn) -> bool {   // it-th tile of this block
+    auto tile_of = [&](int it, int& tm, int& tn, int& tz) -> bool {   // it-th tile of this block (tz: product index, BATCH only)
         const int bid = blockIdx.x;
         const int xcd = bid & 7, slot_in_xcd = bid >> 3;
         const int nb_xcd = (G - xcd + 7) >> 3;                  // blocks living on this XCD
@@ -284,6 +288,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const int idx = it * nb_xcd + slot_in_xcd;
         if (idx >= cnt) return false;
         int v = begin + idx;
+        tz = 0;
+        if (BATCH) { tz = v / per_product; v -= tz * per_product; }
         // Column bands: the order walks all M-panels of a band of `band` N-tiles before moving to the next band, so the 32 blocks of
         // an XCD work on (32 / band) M-panels x band N-tiles at a time: the band's slice of W (band x 256 x K) stays resident in the
         // XCD's 4 MiB L2 while A streams through once per band.  With all of N in flight (qkv: 9 tiles = 3.5 MiB of W, fc1: 12 = 4.7 MiB)
@@ -313,8 +319,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     // ABL 8 (timing probe, garbage results): every tile reads its A rows from the first 2048 rows -- distinct lines per k-step, but L2-resident:
     // what the first-touch (MALL / HBM) latency of the A panels costs the loop
     auto a_row0 = [&](int t) -> int64_t { const int64_t m = tile_m0(t); return ABL == 8 ? (m & 2047) : m; };
-    int tm, tn;
-    bool have = tile_of(0, tm, tn);
+    int tm, tn, tz;
+    bool have = tile_of(0, tm, tn, tz);
     StageAddr sa{nullptr, nullptr};
 #if SC_GEMM_BUFDMA
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
@@ -353,7 +359,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     };
     if (have) {
         rot = p.rot ? tm % nk : 0;
-        set_tile(A + a_row0(tm) * p.lda, W + (int64_t)tile_n0(tn) * p.ldw);
+        set_tile(A + (BATCH ? (int64_t)tz * p.strideA : 0) + a_row0(tm) * p.lda,
+                 W + (BATCH ? (int64_t)(tz % p.w_mod) * p.strideW : 0) + (int64_t)tile_n0(tn) * p.ldw);
 #pragma unroll
         for (int q = 0; q < NPRO; ++q) issue_q(q);
     }
@@ -510,12 +517,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         // ---- next tile's first two stages fly during this tile's epilogue (the slots are free after this barrier:
         //      the epilogue uses its own 18 KiB image region)
         if (TRACE) { unsigned long long t = __builtin_readcyclecounter(); t_loop += t - t_begin; t_begin = t; }
-        int ntm, ntn;
-        const bool nhave = tile_of(it + 1, ntm, ntn);
+        int ntm, ntn, ntz;
+        const bool nhave = tile_of(it + 1, ntm, ntn, ntz);
+        const int64_t c_off = BATCH ? (int64_t)tz * p.strideC : 0;      // this tile's product (its epilogue runs below, after the next tile is set up)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int nrot = (nhave && p.rot) ? ntm % nk : 0;
-        if (nhave) set_tile(A + a_row0(ntm) * p.lda, W + (int64_t)tile_n0(ntn) * p.ldw);
+        if (nhave) set_tile(A + (BATCH ? (int64_t)ntz * p.strideA : 0) + a_row0(ntm) * p.lda,
+                            W + (BATCH ? (int64_t)(ntz % p.w_mod) * p.strideW : 0) + (int64_t)tile_n0(ntn) * p.ldw);
         rot = nrot;   // the k-loop of THIS tile is over; from here on kofs() addresses the next tile
         const int emode = (RES ? p.epi_mode_res : p.epi_mode) & 0xff;
         if (nhave && emode == 0) {
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             // 24-36 B/clk/CU when a quad covers 64 contiguous bytes (tools/probes/store_probe.hip).  So the 16 x 4 (row x chunk)
             // lane matrix is transposed through the LDS crossbar (ds_bpermute, no LDS memory): lane L ends up with row L >> 2,
             // 16-byte chunk L & 3 of the 32-column half, and a store instruction writes 16 rows x 64 contiguous bytes.
-            bf16_t* Cb = (bf16_t*)p.C;
+            bf16_t* Cb = (bf16_t*)p.C + c_off;
             const int srow = lane >> 2, schunk = lane & 3;
             const int src_fk = ((schunk & 1) << 1) | (schunk >> 1);                          // lane row that holds this chunk after the swap
             const int bperm = (src_fk * 16 + srow) << 2;
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             // fp32 outputs (the ViT / pre-LN residual streams): same quad rule as above.  Lane (frow, fk) holds 4 consecutive fp32 =
             // 16 bytes of row frow; the 4 lanes (frow, 0..3) together own one 64-byte segment, so lane L fetches (crossbar) the
             // value of lane (L >> 2) + 16 (L & 3): a store instruction then writes 16 rows x 64 contiguous bytes per 16-column block.
-            float* Cf = (float*)p.C;
+            float* Cf = (float*)p.C + c_off;
             const int srow = lane >> 2, schunk = lane & 3;
             const int bperm = (srow + 16 * schunk) << 2;
             const int64_t mrow0 = m0 + wm * 128 + srow;
@@ -694,7 +703,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 }
             }
         } else {
-            char* Cb = (char*)p.C;
+            char* Cb = (char*)p.C + c_off * (p.out_f32 ? 4 : 2);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int64_t m = m0 + wm * 128 + i * 16 + frow;
@@ -748,6 +757,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         have = nhave;
         tm = ntm;
         tn = ntn;
+        tz = ntz;
         if (TRACE && tid == 0) {
             unsigned long long t = __builtin_readcyclecounter();
             unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
@@ -758,15 +768,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     }
 }
 
-template <int ABL, bool TRACE, int ACT, bool RES, bool RING3, int EPI = 0>
+template <int ABL, bool TRACE, int ACT, bool RES, bool RING3, int EPI = 0, bool BATCH = false>
 int launch256_one(const GemmParams& p, int grid, hipStream_t s) {
     constexpr int lds = RING3 ? 5 * 256 * 128 : 2 * SLOT_BYTES;   // 160 KiB (A x3 + W x2) or 128 KiB ([A|W] x2)
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<ABL, TRACE, ACT, RES, RING3, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<ABL, TRACE, ACT, RES, RING3, EPI, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<ABL, TRACE, ACT, RES, RING3, EPI>), dim3(grid), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((gemm256_kernel<ABL, TRACE, ACT, RES, RING3, EPI, BATCH>), dim3(grid), dim3(512), lds, s, p);
     SC_CHECK_LAUNCH();
     return 0;
 }
@@ -838,6 +848,19 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
             p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (p.N + 255) / 256;
             if (p.band < 0) p.band = p.tiles_n >= 16 ? 4 : 0;   // measured: 8192^3 +20 %; N <= 3072 (the step's shapes) neutral
             return launch256(p, s);
+        }
+    }
+    if (batch > 1 && p.inner == 0 && !p.bias && !p.residual && p.act == SC_ACT_NONE && p.N >= 256 && p.M >= 256) {
+        // independent same-shape products (split-K partials of a weight gradient) on the 256-tile kernel: one persistent tile list over all of them
+        static const bool no_b256 = getenv("SC_GEMM_NOBATCH256") != nullptr;
+        const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * (int64_t)batch;
+        if (!no_b256 && t256 >= 100 && t256 < 0x7fffffff) {
+            p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (p.N + 255) / 256;
+            p.nbatch = batch; p.band = 0; p.rot = 1; p.epi_mode = 2; p.epi_mode_res = 3; p.kpair = 0;
+            static int n_cu = 0;
+            if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+            const int grid = (int)(t256 < n_cu ? t256 : n_cu);
+            return launch256_one<0, false, SC_ACT_NONE, false, true, 0, true>(p, grid, s);
         }
     }
     if (p.N <= 64) {

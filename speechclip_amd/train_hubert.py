@@ -48,7 +48,10 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     GEMM into per-split fp32 partials, column-summed."""
     M, N = dy.shape
     K = x.shape[1]
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    if N >= 256 and K >= 256:      # the split products run as ONE persistent tile list on the 256-tile kernel (gemm256 BATCH): aim at ~2 tiles per CU
+        tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    else:
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
     S = max(1, min(32, 512 // tiles, M // 2048 if M >= 4096 else 1))
     chunk = -(-M // (64 * S)) * 64
     Mp = chunk * S
