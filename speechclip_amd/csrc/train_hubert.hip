@@ -260,8 +260,15 @@ __global__ __launch_bounds__(256) void colsum_bf16_stage1_kernel(const bf16_t* _
 __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * cols + c];
+    // few blocks (cols / 256), many partial rows: keep eight loads in flight per thread (fixed summation order: deterministic)
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int p = 0;
+    for (; p + 8 <= nparts; p += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += part[(int64_t)(p + j) * cols + c];
+    }
+    for (; p < nparts; ++p) a[0] += part[(int64_t)p * cols + c];
+    const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     out[c] = accumulate ? out[c] + s : s;
 }
 
