@@ -86,6 +86,14 @@ def posconv_wgrad(du, xp, valid_i32, B, Tp, D, G, Kw):
     return out
 
 
+def _rows_with_slack(n_rows, cols, dev):
+    """[n_rows + 8, cols] bf16 whose 8 slack rows are zero (the conv-as-GEMM views over-read / the overlapping tap accumulates into them); the body is
+    written in full by the producing GEMM, so it is not filled first."""
+    t = torch.empty(n_rows + 8, cols, device=dev, dtype=BF)
+    t[n_rows:].zero_()
+    return t
+
+
 def conv_layer_backward(xin, w, du_i, B, rows_out, dim, k, s, C):
     """Conv-as-GEMM layer, gradient du_i bf16 [B*rows_out, dim] of its (pre-activation) output -> (dW f32 [dim, C, k], dX bf16 [B*rows_in + 8, C])."""
     Mi = B * rows_out
@@ -94,7 +102,7 @@ def conv_layer_backward(xin, w, du_i, B, rows_out, dim, k, s, C):
     xview = torch.as_strided(xin, (Mi, k * C), (s * C, 1))
     dW = wgrad(du_i, xview).view(dim, k, C).permute(0, 2, 1).contiguous()
     wT = w16.t().contiguous()                                                    # [k*C, dim]
-    dx = torch.zeros(B * rows_in + 8, C, device=xin.device, dtype=BF)
+    dx = _rows_with_slack(B * rows_in, C, xin.device)
     ops.gemm(du_i, wT[:s * C], out=dx[:s * Mi].view(Mi, s * C))                  # taps 0 .. s-1 tile the input rows exactly
     for j in range(s, k):                                                        # overlapping taps: accumulate in place
         tgt = torch.as_strided(dx, (Mi, C), (s * C, 1), storage_offset=j * C)
@@ -139,7 +147,7 @@ class HubertFrontTrainFn(torch.autograd.Function):
         rows = P0
         for (dim, k, s), w in zip(cl[1:], cws):
             rows //= s
-            y = torch.zeros(B * rows + 8, dim, device=dev, dtype=BF)
+            y = _rows_with_slack(B * rows, dim, dev)
             ops.gemm(x, _conv_w16(w), None, ACT_GELU, out=y[:B * rows], M=B * rows, K=k * C, lda=s * C)
             acts.append(y)
             x, C = y, dim
@@ -260,9 +268,9 @@ class HubertFrontLNTrainFn(torch.autograd.Function):
         for li, (dim, k, s) in enumerate(cl[1:], start=1):
             w, b, g, be = params[4 * li:4 * li + 4]
             rows //= s
-            u = torch.zeros(B * rows + 8, dim, device=dev, dtype=BF)
+            u = _rows_with_slack(B * rows, dim, dev)
             ops.gemm(x, _conv_w16(w), _f32(b), ACT_NONE, out=u[:B * rows], M=B * rows, K=k * C, lda=s * C)
-            y = torch.zeros_like(u)
+            y = _rows_with_slack(B * rows, dim, dev)
             ops.layernorm(u[:B * rows], _f32(g), _f32(be), gelu=True, out=y[:B * rows])
             pre.append(u)
             acts.append(y)

@@ -128,7 +128,8 @@ class HubertLayersTrainFn(torch.autograd.Function):
         for li in range(n):
             qw, qb, kw, kb, vw, vb, ow, ob, g1, b1n, w1, b1, w2, b2, g2, b2n = params[li * PER_LAYER:(li + 1) * PER_LAYER]
             wqkv, bqkv = _w16(torch.cat([qw, kw, vw], 0)), _f32(torch.cat([qb, kb, vb], 0))
-            qkv = torch.zeros(M + (Lp - Tp), 3 * d, device=dev, dtype=BF)          # slack rows: the backward's S / dP products read Lp keys per utterance
+            qkv = torch.empty(M + (Lp - Tp), 3 * d, device=dev, dtype=BF)
+            qkv[M:].zero_()          # slack rows: the backward's S / dP products read Lp keys per utterance
             ops.gemm(h, wqkv, bqkv, out=qkv[:M])
             if drop is None:
                 att = ops.attention(qkv[:M], B, Tp, H, valid_i32)
@@ -172,7 +173,8 @@ class HubertLayersTrainFn(torch.autograd.Function):
             qw, qb, kw, kb, vw, vb, ow, ob, g1, b1n, w1, b1, w2, b2, g2, b2n = params[li * PER_LAYER:(li + 1) * PER_LAYER]
             wqkv, bqkv = _w16(torch.cat([qw, kw, vw], 0)), _f32(torch.cat([qb, kb, vb], 0))
             t1 = ops.layernorm(h, _f32(g1), _f32(b1n), eps)                                   # bf16
-            qkv = torch.zeros(M + (Lp - Tp), 3 * d, device=dev, dtype=BF)
+            qkv = torch.empty(M + (Lp - Tp), 3 * d, device=dev, dtype=BF)
+            qkv[M:].zero_()
             ops.gemm(t1, wqkv, bqkv, out=qkv[:M])
             att = ops.attention(qkv[:M], B, Tp, H, valid_i32)
             xmid = ops.gemm(att, _w16(ow), _f32(ob), residual=h, out_f32=True)
