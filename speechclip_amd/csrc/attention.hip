@@ -80,6 +80,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 
     const int qrow = qblk * (NW * 32) + wave * 32 + ql;
     const int qrow_c = qrow < T ? qrow : T - 1;
+    const uint32_t drop_row = DROP ? (uint32_t)((b * H + h) * T + qrow_c) : 0u, drop_pairs = (uint32_t)((T + 1) >> 1);
 
     // Q fragments: B operand of S^T (col = query, k-slots = 8 dims)
     bf16x8_t qf[4];
@@ -229,10 +230,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 #endif
                 if (DROP) {
                     // torch: attn = dropout(softmax(s)) -- the row sum keeps every probability, the P.V product sees the masked, rescaled ones.
-                    // element index = ((b*H + h)*T + query)*T + key; this lane's register r holds key kv0 + kb*32 + (r & 3) + 8*(r >> 2) + 4*g
-                    const uint32_t e0 = (uint32_t)(((int64_t)(b * H + h) * T + qrow_c) * T) + (uint32_t)(kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g);
-                    const float d0 = keep_elem(drop_seed, e0, drop_thresh_) ? p2[0] * drop_keep_scale : 0.f;
-                    const float d1 = keep_elem(drop_seed, e0 + 1, drop_thresh_) ? p2[1] * drop_keep_scale : 0.f;
+                    // this lane's registers r, r + 1 hold the adjacent keys kv0 + kb*32 + (r & 3) + 8*(r >> 2) + 4*g (even) and + 1: one hash per pair
+                    const uint32_t key = (uint32_t)(kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g);
+                    const uint32_t hbits = hash_pair(drop_seed, drop_row * drop_pairs + (key >> 1));
+                    const float d0 = (hbits & 0xffffu) >= drop_thresh_ ? p2[0] * drop_keep_scale : 0.f;
+                    const float d1 = (hbits >> 16) >= drop_thresh_ ? p2[1] * drop_keep_scale : 0.f;
                     ppk[kb][r >> 1] = pack2bf(d0, d1);
                 } else
                 ppk[kb][r >> 1] = pack2bf(p2[0], p2[1]);       // P leaves the fp32 registers right here: 16 VGPRs instead of 32 through the PV phase
@@ -520,7 +522,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
     ipb = ipb < 1 ? 1 : (ipb > 16 ? 16 : ipb);
     const int groups8 = (n_ids / 8 + ipb - 1) / ipb;           // n_ids is a multiple of 8
     dim3 grid((unsigned)(groups8 * 8));
-    const uint32_t th = drop_thresh(drop_p);
+    const uint32_t th = drop_thresh16(drop_p);         // 16 random bits per probability: see hash_pair (common.h)
     const float ks = 1.0f / (1.0f - drop_p);
 #define ATTN_LAUNCH(NW_, TR_, DR_)                                                                                                          \
     do {                                                                                                                                    \

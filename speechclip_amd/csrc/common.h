@@ -82,6 +82,10 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
 }
 __device__ __forceinline__ bool keep_elem(uint32_t seed, uint32_t idx, uint32_t thresh) { return hash32(seed ^ hash32(idx + 0x9e3779b9U)) >= thresh; }
 static inline uint32_t drop_thresh(float pd) { return pd <= 0.f ? 0u : (uint32_t)fmin(4294967295.0, (double)pd * 4294967296.0); }
+// Attention-probability dropout: the flash kernel is VALU-bound, so ONE hash serves a PAIR of adjacent keys of a query row (16 random bits each):
+// pair index = row_id * ceil(L / 2) + (key >> 1), row_id = (b*H + h)*L + query; key parity picks the half.  thresh16 = p * 2^16.
+__device__ __forceinline__ uint32_t hash_pair(uint32_t seed, uint32_t pair_idx) { return hash32(pair_idx * 0x9E3779B1u + seed); }
+static inline uint32_t drop_thresh16(float pd) { return pd <= 0.f ? 0u : (uint32_t)fmin(65535.0, (double)pd * 65536.0); }
 // CLIP QuickGELU: x * sigmoid(1.702 x)
 __device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 

@@ -100,9 +100,10 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
         if (j < klen) {
             p = __expf(srow[j] * scale - mx) * inv;
             float gp = gprow[j];
-            if (drop_thresh_) {      // attention dropout of the forward (sc_attention_fwd_dropout): the same mask, element = elem_base + z * stride + i * L + j.
-                // dP = m dP_dropped, P_dropped = m P (what dV = P_dropped^T dO multiplies); sum_k P_ik dP_ik = dO_i . O_i still holds
-                const float m = keep_elem(drop_seed, elem_base + (uint32_t)z * elem_stride_z + (uint32_t)i * (uint32_t)L + (uint32_t)j, drop_thresh_) ? keep_scale : 0.f;
+            if (drop_thresh_) {      // attention dropout of the forward (sc_attention_fwd_dropout): the same mask -- one hash per pair of adjacent keys,
+                // 16 bits each (common.h hash_pair).  dP = m dP_dropped, P_dropped = m P (what dV = P_dropped^T dO multiplies); sum_k P_ik dP_ik = dO_i . O_i still holds
+                const uint32_t hb = hash_pair(drop_seed, (elem_base + (uint32_t)z * elem_stride_z + (uint32_t)i) * (uint32_t)((L + 1) >> 1) + ((uint32_t)j >> 1));
+                const float m = ((j & 1) ? (hb >> 16) : (hb & 0xffffu)) >= drop_thresh_ ? keep_scale : 0.f;
                 gp *= m;
                 ds = p * (gp - dd) * scale;
                 p *= m;
@@ -329,8 +330,8 @@ static int attn_softmax_bwd_impl(const float* S, const float* dP, int64_t ld, in
     SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && H >= 1 && h >= 0 && h < H, "sc_attn_softmax_bwd_dropout: bad dropout arguments");
     // forward element index = ((b*H + h)*L + i)*L + j with b = z
     hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((Lp + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, S, dP, ld, stride, (const bf16_t*)dO, ld_do,
-                       (const bf16_t*)O, ld_o, rows_per_batch, klens, (bf16_t*)P, (bf16_t*)dS, L, Lp, scale, seed, drop_thresh(drop_p), 1.0f / (1.0f - drop_p),
-                       all_heads ? 0u : (uint32_t)h * (uint32_t)L * (uint32_t)L, (all_heads ? 1u : (uint32_t)H) * (uint32_t)L * (uint32_t)L,
+                       (const bf16_t*)O, ld_o, rows_per_batch, klens, (bf16_t*)P, (bf16_t*)dS, L, Lp, scale, seed, drop_thresh16(drop_p), 1.0f / (1.0f - drop_p),
+                       all_heads ? 0u : (uint32_t)h * (uint32_t)L, (all_heads ? 1u : (uint32_t)H) * (uint32_t)L,      // row id = (b*H + h)*L + i
                        all_heads ? H : 0);
     SC_CHECK_LAUNCH();
     return 0;

@@ -128,6 +128,17 @@ def _keep(seed, idx, p):
     return torch.from_numpy((h >= np.uint64(int(p * 4294967296.0))).astype(np.float32))
 
 
+def _keep_attn(seed, B, H, T, p):
+    """The attention-probability mask (csrc/common.h hash_pair): one hash per pair of adjacent keys of a query row, 16 bits each;
+    pair index = ((b*H + h)*T + query) * ceil(T/2) + (key >> 1); keep iff the half's 16 bits >= p * 2^16."""
+    rows = np.arange(B * H * T, dtype=np.uint64)[:, None]
+    keys = np.arange(T, dtype=np.uint64)[None, :]
+    pair = (rows * np.uint64((T + 1) // 2) + (keys >> np.uint64(1))) & np.uint64(0xffffffff)
+    h = _hash32(((pair * np.uint64(0x9E3779B1)) + np.uint64(seed & 0xffffffff)) & np.uint64(0xffffffff))
+    bits = np.where((keys & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xffff))
+    return torch.from_numpy((bits >= np.uint64(int(p * 65536.0))).astype(np.float32)).view(B, H, T, T)
+
+
 def test_trained_layer_with_dropout_matches_autograd_with_the_same_masks():
     """One post-LN layer through train_hubert.HubertLayersTrainFn with meta["drop"]: forward and every gradient against an fp32 torch
     re-statement of the fairseq layer (dropout1 / dropout3 / attention dropout) that uses the SAME counter-based masks, regenerated in numpy."""
@@ -171,7 +182,7 @@ def test_trained_layer_with_dropout_matches_autograd_with_the_same_masks():
     s = (q * 0.125) @ k.transpose(-1, -2)
     kmask = torch.arange(Tp)[None, :] >= torch.tensor(lens)[:, None]
     pr = torch.softmax(s.masked_fill(kmask[:, None, None, :], float("-inf")), dim=-1)
-    am = _keep(sa, np.arange(B * H * Tp * Tp), p_a).view(B, H, Tp, Tp) / (1 - p_a)
+    am = _keep_attn(sa, B, H, Tp, p_a) / (1 - p_a)
     att = ((pr * am) @ v).transpose(1, 2).reshape(M, d)
     m1 = _keep(s1, np.arange(M * d), p_h).view(M, d) / (1 - p_h)
     m3 = _keep(s3, np.arange(M * d), p_h).view(M, d) / (1 - p_h)
