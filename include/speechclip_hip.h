@@ -359,6 +359,10 @@ int sc_attn_softmax_bwd_dropout(const float* S, const float* dP, int64_t ld, int
 int sc_attn_softmax_bwd_heads(const float* S, const float* dP, int64_t ld, int64_t stride, const void* dO, int64_t ld_do, const void* O, int64_t ld_o,
                               int64_t rows_per_batch, const int32_t* klens, void* P, void* dS, int L, int Lp, int B, int H, float scale, float drop_p,
                               uint32_t seed, void* stream);
+/* Fused form of the two recompute products + sc_attn_softmax_bwd_heads for head dim 64: P / dS bf16 [B*H, Lp, Lp] straight from the packed q | k | v
+ * rows (row b*L + t of stride ld_qkv, head h at column h*64), dO and O (stride ld_o); the fp32 S / dP images are never written. */
+int sc_attn_bwd_probs(const void* q, const void* k, const void* v, int64_t ld_qkv, const void* dO, const void* O, int64_t ld_o, const int32_t* klens,
+                      void* P, void* dS, int B, int H, int L, int Lp, float scale, float drop_p, uint32_t seed, void* stream);
 int sc_gelu_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, void* stream);
 int64_t sc_layernorm_bwd_bf16_partials(int64_t rows);
 int sc_layernorm_bwd_bf16(const void* x, const void* dy, const float* gamma, void* dx, float* part, int64_t rows, int D, float eps, void* stream);

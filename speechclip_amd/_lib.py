@@ -49,6 +49,7 @@ def _declare(L):
         "sc_attn_softmax_bwd": ([P, P, L64, L64, P, L64, P, L64, L64, P, P, P, I, I, I, F, P], c_int),
         "sc_attn_softmax_bwd_dropout": ([P, P, L64, L64, P, L64, P, L64, L64, P, P, P, I, I, I, F, F, U32, I, I, P], c_int),
         "sc_attn_softmax_bwd_heads": ([P, P, L64, L64, P, L64, P, L64, L64, P, P, P, I, I, I, I, F, F, U32, P], c_int),
+        "sc_attn_bwd_probs": ([P, P, P, L64, P, P, L64, P, P, P, I, I, I, I, F, F, U32, P], c_int),
         "sc_gemm_bf16_batched2": ([P, L64, L64, L64, P, L64, L64, L64, P, L64, L64, L64, L64, I, I, I, I, I, P], c_int),
         "sc_gelu_bwd_bf16": ([P, P, P, L64, P], c_int),
         "sc_layernorm_bwd_bf16_partials": ([L64], c_int64),

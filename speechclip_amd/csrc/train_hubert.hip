@@ -115,6 +115,112 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
     }
 }
 
+// Fused front half of the attention backward for head dim 64: recomputes S = Q K^T and dP = dO V^T on the matrix cores straight from the packed rows
+// (every MFMA fragment is ONE 16-byte global load: both products contract along the contiguous head dimension, so no LDS staging is needed) and writes
+// P (dropped, if the forward dropped) and dS = scale P (m dP - dO.O) as bf16 [B*H, Lp, Lp] images -- the fp32 S / dP images of the unfused path
+// (two batched GEMMs + sc_attn_softmax_bwd_heads: 6 GB of traffic per layer at B = 256) never exist.  One wave per 16 queries of one (b, h);
+// pass 1 runs the online max / sum over the key blocks, pass 2 recomputes each 16 x 16 block and emits it.
+// MFMA 16x16x32: first operand = key rows, second = query rows -> lane l holds query (l & 15), keys 4 (l >> 4) + r of the block.
+__global__ __launch_bounds__(256) void attn_bwd_probs_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                             int64_t ld_qkv, const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, int64_t ld_o,
+                                                             const int32_t* __restrict__ klens, bf16_t* __restrict__ P, bf16_t* __restrict__ dS, int H, int L,
+                                                             int Lp, float scale, uint32_t drop_seed, uint32_t drop_thresh_, float keep_scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int z = blockIdx.y, b = z / H, h = z - b * H;
+    const int i0 = (blockIdx.x * 4 + wave) * 16;                       // this wave's 16 queries
+    if (i0 >= Lp) return;
+    const int qi = lane & 15, fk = lane >> 4;
+    const int i = i0 + qi;
+    bf16_t* prow = P + ((int64_t)z * Lp + i) * Lp;
+    bf16_t* drow = dS + ((int64_t)z * Lp + i) * Lp;
+    const int klen = klens ? min(klens[b], L) : L;
+    const int nkb = (klen + 15) / 16;                                   // key blocks that hold at least one valid key
+    const int ic = i < L ? i : L - 1;                                   // rows >= L: clamp the loads, write zeros
+    const int64_t row = (int64_t)b * L + ic;
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    // fragments of this lane's query row: k-slots 8 fk .. 8 fk + 7 of each 32-wide half of the 64 head dims
+    bf16x8_t qf[2], dof[2];
+    float dpart = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        qf[c] = *(const bf16x8_t*)(q + row * ld_qkv + h * 64 + c * 32 + fk * 8);
+        const uint4 du = *(const uint4*)(dO + row * ld_o + h * 64 + c * 32 + fk * 8);      // raw bits: the dot below reads them as bf16 pairs
+        const uint4 ou = *(const uint4*)(O + row * ld_o + h * 64 + c * 32 + fk * 8);
+        dof[c] = __builtin_bit_cast(bf16x8_t, du);
+        dpart += lo2f(du.x) * lo2f(ou.x) + hi2f(du.x) * hi2f(ou.x) + lo2f(du.y) * lo2f(ou.y) + hi2f(du.y) * hi2f(ou.y)
+               + lo2f(du.z) * lo2f(ou.z) + hi2f(du.z) * hi2f(ou.z) + lo2f(du.w) * lo2f(ou.w) + hi2f(du.w) * hi2f(ou.w);
+    }
+    dpart += __shfl_xor(dpart, 16, 64);
+    dpart += __shfl_xor(dpart, 32, 64);                                 // D_i = dO_i . O_i (all 64 dims)
+    auto kfrag = [&](const bf16_t* base, int kb, int c) -> bf16x8_t {  // row (16 kb + qi) of K or V, clamped to the utterance
+        int key = kb * 16 + qi;
+        key = key < L ? key : L - 1;
+        return *(const bf16x8_t*)(base + ((int64_t)b * L + key) * ld_qkv + h * 64 + c * 32 + fk * 8);
+    };
+    // ---- pass 1: row maximum and sum of exp over the valid keys
+    float m = -INFINITY, l = 0.f;
+    for (int kb = 0; kb < nkb; ++kb) {
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag(k, kb, c), qf[c], sacc, 0, 0, 0);
+        float bm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kb * 16 + fk * 4 + r;
+            sacc[r] = key < klen ? sacc[r] * scale : -INFINITY;
+            bm = fmaxf(bm, sacc[r]);
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m, bm);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ps += __expf(sacc[r] - mn);
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * __expf(m - mn) + ps;
+        m = mn;
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const uint32_t row_id = (uint32_t)((b * H + h) * L + ic), pairs = (uint32_t)((L + 1) >> 1);
+    // ---- pass 2: every 16 x 16 block again, with dP, and out
+    const int nkb_all = Lp / 16;
+    for (int kb = 0; kb < nkb_all; ++kb) {
+        uint2 po = make_uint2(0u, 0u), so = make_uint2(0u, 0u);
+        if (kb < nkb) {          // wave-uniform: every lane feeds the MFMAs (its lane index is also the KEY row of the K / V fragments); rows >= L are zeroed below
+            f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag(k, kb, c), qf[c], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag(v, kb, c), dof[c], pacc, 0, 0, 0);
+            }
+            float pv[4], dv[4];
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const int key = kb * 16 + fk * 4 + r;
+                float m0 = 1.f, m1 = 1.f;
+                if (drop_thresh_) {
+                    const uint32_t hb = hash_pair(drop_seed, row_id * pairs + ((uint32_t)key >> 1));
+                    m0 = (hb & 0xffffu) >= drop_thresh_ ? keep_scale : 0.f;
+                    m1 = (hb >> 16) >= drop_thresh_ ? keep_scale : 0.f;
+                }
+                const float p0 = key < klen ? __expf(sacc[r] * scale - m) * inv : 0.f;
+                const float p1 = key + 1 < klen ? __expf(sacc[r + 1] * scale - m) * inv : 0.f;
+                dv[r] = p0 * (pacc[r] * m0 - dpart) * scale;
+                dv[r + 1] = p1 * (pacc[r + 1] * m1 - dpart) * scale;
+                pv[r] = p0 * m0;
+                pv[r + 1] = p1 * m1;
+            }
+            if (i < L) {
+                po.x = pack2bf(pv[0], pv[1]); po.y = pack2bf(pv[2], pv[3]);
+                so.x = pack2bf(dv[0], dv[1]); so.y = pack2bf(dv[2], dv[3]);
+            }
+        }
+        *(uint2*)(prow + kb * 16 + fk * 4) = po;
+        *(uint2*)(drow + kb * 16 + fk * 4) = so;
+    }
+}
+
 __global__ __launch_bounds__(256) void gelu_bwd_bf16_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ dh, bf16_t* __restrict__ du, int64_t n) {
     auto d = [](float x) { return 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x); };
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;      // 16 bytes per lane; the tail (n % 8, n even) goes pair by pair
@@ -355,6 +461,23 @@ extern "C" int sc_attn_softmax_bwd_heads(const float* S, const float* dP, int64_
                                          float scale, float drop_p, uint32_t seed, void* stream) {
     SC_CHECK_ARG(B > 0 && H > 0 && (int64_t)B * H <= 65535, "sc_attn_softmax_bwd_heads: B*H must be in [1, 65535]");
     return attn_softmax_bwd_impl(S, dP, ld, stride, dO, ld_do, O, ld_o, rows_per_batch, klens, P, dS, L, Lp, B * H, scale, drop_p, seed, H, 0, stream, 1);
+}
+
+// P / dS bf16 [B*H, Lp, Lp] (rows >= L and keys >= klens[b] zero) from the packed q | k | v rows (row b*L + t, head h at column h*64), dO and O:
+// the fused form of (S = Q K^T, dP = dO V^T as batched GEMMs) + sc_attn_softmax_bwd_heads.  drop_p > 0: the forward ran sc_attention_fwd_dropout(seed).
+extern "C" int sc_attn_bwd_probs(const void* q, const void* k, const void* v, int64_t ld_qkv, const void* dO, const void* O, int64_t ld_o,
+                                 const int32_t* klens, void* P, void* dS, int B, int H, int L, int Lp, float scale, float drop_p, uint32_t seed,
+                                 void* stream) {
+    SC_CHECK_ARG(q && k && v && dO && O && P && dS, "sc_attn_bwd_probs: null operand");
+    SC_CHECK_ARG(B > 0 && H > 0 && (int64_t)B * H <= 65535 && L > 0 && Lp >= L && Lp % 16 == 0, "sc_attn_bwd_probs: bad sizes (Lp must be a multiple of 16)");
+    SC_CHECK_ARG(ld_qkv % 8 == 0 && ld_o % 8 == 0 && ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dO | (uintptr_t)O) & 15) == 0),
+                 "sc_attn_bwd_probs: rows must be 16-byte aligned");
+    SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_attn_bwd_probs: drop_p=%f must be in [0, 1)", (double)drop_p);
+    hipLaunchKernelGGL(attn_bwd_probs_kernel, dim3((Lp + 63) / 64, B * H), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, ld_qkv, (const bf16_t*)dO, (const bf16_t*)O, ld_o, klens, (bf16_t*)P, (bf16_t*)dS, H, L, Lp, scale, seed,
+                       drop_thresh16(drop_p), 1.0f / (1.0f - drop_p));
+    SC_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int sc_gelu_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, void* stream) {

@@ -968,3 +968,16 @@ def attn_softmax_bwd_heads(S, dP, dO, O, rows_per_batch, klens_i32, L, scale, B,
     check(lib().sc_attn_softmax_bwd_heads(ptr(S), ptr(dP), Lp, Lp * Lp, ptr(dO), dO.stride(0), ptr(O), O.stride(0), rows_per_batch, ptr(klens_i32), ptr(P),
                                           ptr(dS), L, Lp, B, H, float(scale), p_, seed, stream()), "sc_attn_softmax_bwd_heads")
     return P, dS
+
+
+def attn_bwd_probs(qkv, datt, att, klens_i32, B, T, H, drop=None):
+    """P (dropped if the forward dropped) and dS bf16 [B*H, Lp, Lp] straight from the packed rows: qkv bf16 [>= B*T, 3*H*64], datt / att bf16 [B*T, H*64]."""
+    _need_cuda(qkv, datt, att)
+    d = H * 64
+    Lp = -(-T // 64) * 64
+    P = torch.empty(B * H, Lp, Lp, device=qkv.device, dtype=bf16)
+    dS = torch.empty_like(P)
+    p_, seed = (float(drop[0]), int(drop[1]) & 0xffffffff) if drop is not None else (0.0, 0)
+    check(lib().sc_attn_bwd_probs(qkv.data_ptr(), qkv.data_ptr() + d * 2, qkv.data_ptr() + 2 * d * 2, 3 * d, ptr(datt), ptr(att), d, ptr(klens_i32), ptr(P),
+                                  ptr(dS), B, H, T, Lp, 0.125, p_, seed, stream()), "sc_attn_bwd_probs")
+    return P, dS

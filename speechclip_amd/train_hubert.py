@@ -75,14 +75,10 @@ def attention_bwd(qkv: torch.Tensor, att: torch.Tensor, datt: torch.Tensor, B: i
     dev = qkv.device
     Z = B * H
     dqkv = torch.empty(M, 3 * d, device=dev, dtype=BF)
-    S = torch.empty(Z, Lp, Lp, device=dev, dtype=torch.float32)
-    dP = torch.empty(Z, Lp, Lp, device=dev, dtype=torch.float32)
     q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
     img, rq, ro = Lp * Lp, Tp * 3 * d, Tp * d
-    ops.gemm_batched2(q, 3 * d, rq, 64, k, 3 * d, rq, 64, S, Lp, H * img, img, Tp, Lp, 64, B, H)                 # S = Q K^T   [Tp, Lp] per (b, h)
-    ops.gemm_batched2(datt, d, ro, 64, v, 3 * d, rq, 64, dP, Lp, H * img, img, Tp, Lp, 64, B, H)                 # dP = dO V^T
-    P, dS = ops.attn_softmax_bwd_heads(S, dP, datt, att, Tp, klens_i32, Tp, 0.125, B, H, drop)
-    del S, dP
+    # S = Q K^T, dP = dO V^T, P = softmax(S / 8 + key mask) [dropped], dS = P (m dP - dO.O) / 8 in ONE kernel; the fp32 S / dP images are never written
+    P, dS = ops.attn_bwd_probs(qkv, datt, att, klens_i32, B, Tp, H, drop)
     PT = ops.transpose_bf16(P, Lp, img, Lp, Lp, Z)
     dST = ops.transpose_bf16(dS, Lp, img, Lp, Lp, Z)
     del P
