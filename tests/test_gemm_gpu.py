@@ -145,3 +145,46 @@ def test_gemm_256_tile_switch_counted_wait(M, N, K, res, f32):
     torch.testing.assert_close(outs[0].float(), ref, atol=tol, rtol=tol)
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("S,M,N,K", [(4, 300, 260, 128), (30, 300, 520, 128), (14, 768, 768, 1024), (3, 3072, 768, 512), (40, 256, 256, 64)])
+def test_batched_products_on_the_256_tile_kernel(S, M, N, K):
+    """sc_gemm_bf16_batched with M, N >= 256 and >= 100 tiles runs all products as one persistent tile list on gemm256 (BATCH variant: the
+    split-K partial products of the weight gradients); edge tiles (300 x 260) are shifted back inside their own product.  fp32 outputs vs torch."""
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(S * 1000 + M + N + K)
+    a = (0.5 * torch.randn(S, M, K, generator=g)).to(torch.bfloat16)
+    w = (0.5 * torch.randn(S, N, K, generator=g)).to(torch.bfloat16)
+    out = torch.full((S, M, N), float("nan"), dtype=torch.float32, device="cuda")
+    ops.gemm_batched(a.cuda(), K, M * K, w.cuda(), N * K, S, out, N, M * N, None, M, N, K, S)
+    ref = a.float() @ w.float().transpose(1, 2)
+    assert torch.isfinite(out).all()
+    torch.testing.assert_close(out.cpu(), ref, atol=2e-2 * K ** 0.5 * 0.25, rtol=2e-3)
+    # the same with a shared second operand (w_mod = 1) and bf16 outputs
+    out16 = torch.empty(S, M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_batched(a.cuda(), K, M * K, w[0].contiguous().cuda(), N * K, 1, out16, N, M * N, None, M, N, K, S)
+    ref16 = a.float() @ w[0].float().t()
+    torch.testing.assert_close(out16.float().cpu(), ref16, atol=6e-2 * K ** 0.5 * 0.25, rtol=2e-2)
+
+
+def test_two_level_batched_products_vs_torch():
+    """sc_gemm_bf16_batched2: (outer, inner) products with independent strides per level -- the (utterance, head) pairs of the attention backward."""
+    from speechclip_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H, T, L = 3, 4, 70, 128
+    q = (0.5 * torch.randn(B * T, 3 * H * 64, generator=g)).to(torch.bfloat16)
+    kT = (0.5 * torch.randn(B * H, 64, L, generator=g)).to(torch.bfloat16)
+    dS = (0.5 * torch.randn(B * H, L, L, generator=g)).to(torch.bfloat16)
+    out = torch.zeros(B * T, 3 * H * 64, dtype=torch.bfloat16, device="cuda")
+    # out[b, t, h*64:(h+1)*64] = dS[b*H + h][:T] @ kT[b*H + h]^T   (M = T rows, N = 64, contraction over L)
+    ops.gemm_batched2(dS.cuda(), L, H * L * L, L * L, kT.cuda(), L, H * 64 * L, 64 * L, out, 3 * H * 64, T * 3 * H * 64, 64, T, 64, L, B, H)
+    ref = torch.einsum("zik,zdk->zid", dS.float()[:, :T], kT.float()).view(B, H, T, 64).permute(0, 2, 1, 3).reshape(B * T, H * 64)
+    torch.testing.assert_close(out.float().cpu()[:, :H * 64], ref, atol=0.15, rtol=2e-2)
+    assert out[:, H * 64:].abs().max().item() == 0                       # nothing else was touched
+    # strided first operand: S[b*H + h] = q_h k_h^T straight from packed rows
+    S = torch.empty(B * H, T, L, dtype=torch.float32, device="cuda")
+    qq = q.cuda()
+    ops.gemm_batched2(qq, 3 * H * 64, T * 3 * H * 64, 64, qq[:, H * 64:], 3 * H * 64, T * 3 * H * 64, 64, S, L, H * T * L, T * L, T, 64, 64, B, H)
+    x = q.float().view(B, T, 3, H, 64)
+    refS = torch.einsum("bihd,bjhd->bhij", x[:, :, 0], x[:, :64, 1]).reshape(B * H, T, 64)
+    torch.testing.assert_close(S.cpu()[:, :, :64], refS, atol=0.1, rtol=2e-2)
