@@ -496,3 +496,31 @@ def test_single_utterance_batch_goes_through_the_training_path(everything):
     g = model.audio_encoder.weightedsum_layer.weights.grad
     assert g is not None and torch.isfinite(g).all()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("drop", [None, (0.2, 777)])
+def test_fused_attention_probs_kernel_vs_the_unfused_form(drop):
+    """sc_attn_bwd_probs (S, dP on MFMA fragments from the packed rows + softmax backward in registers) against the first, unfused form: the two
+    products as fp32 images (computed here by torch on the same bf16 operands) through sc_attn_softmax_bwd_heads -- same P, same dS, same mask."""
+    from speechclip_amd import ops
+    B, T, H = 3, 70, 2
+    d, Lp = H * 64, 128
+    g = _g(17)
+    qkv = (0.7 * torch.randn(B * T, 3 * d, generator=g)).to(BF)
+    att = torch.randn(B * T, d, generator=g).to(BF)
+    datt = torch.randn(B * T, d, generator=g).to(BF)
+    klens = torch.tensor([70, 33, 7], dtype=torch.int32)
+    x = qkv.float().view(B, T, 3, H, 64)
+    S = torch.zeros(B * H, Lp, Lp)
+    dP = torch.zeros(B * H, Lp, Lp)
+    S[:, :T, :T] = torch.einsum("bihd,bjhd->bhij", x[:, :, 0], x[:, :, 1]).reshape(B * H, T, T)
+    dP[:, :T, :T] = torch.einsum("bihd,bjhd->bhij", datt.float().view(B, T, H, 64), x[:, :, 2]).reshape(B * H, T, T)
+    P0, dS0 = ops.attn_softmax_bwd_heads(S.cuda(), dP.cuda(), datt.cuda(), att.cuda(), T, klens.cuda(), T, 0.125, B, H, drop)
+    P1, dS1 = ops.attn_bwd_probs(qkv.cuda(), datt.cuda(), att.cuda(), klens.cuda(), B, T, H, drop)
+    assert P1.shape == (B * H, Lp, Lp)
+    torch.testing.assert_close(P1.float(), P0.float(), atol=4e-3, rtol=2e-2)
+    torch.testing.assert_close(dS1.float(), dS0.float(), atol=2e-2, rtol=3e-2)
+    assert torch.equal(P1 == 0, P0 == 0) or ((P1 == 0) != (P0 == 0)).float().mean().item() < 1e-4      # same zeros: mask, key padding, row padding
+    for z in range(B * H):
+        n = int(klens[z // H])
+        assert P1[z, T:].abs().max().item() == 0 and P1[z, :, n:].abs().max().item() == 0 and dS1[z, :, n:].abs().max().item() == 0
