@@ -308,16 +308,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (qrow < T) {
-        bf16_t* orow = out + (row_base + qrow) * ld_out + hoff;
+    {
+        // A row is split across the half-waves: lane (g, ql) holds columns 8 rq + 4 g .. + 3 of every 8-column group rq.  v_permlane32_swap between
+        // the groups rq = 2k (vdst) and 2k + 1 (src) leaves 16 contiguous bytes in every lane (lower half: columns 16k .. 16k+7, upper half: 16k+8 ..
+        // 16k+15), so the row goes out as 4 dwordx4 stores per lane instead of 8 dwordx2: the store tail is issue-bound per instruction
+        // (MI355X_MICROARCH.md, T21).  The swaps run in every lane (outside the row test: both halves of a row take the same branch anyway).
+        bf16_t* orow = out + (row_base + qrow_c) * ld_out + hoff;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                uint2 p;
-                p.x = pack2bf(o[db][rq * 4 + 0] * inv, o[db][rq * 4 + 1] * inv);
-                p.y = pack2bf(o[db][rq * 4 + 2] * inv, o[db][rq * 4 + 3] * inv);
-                *(uint2*)(orow + db * 32 + rq * 8 + g * 4) = p;
+            for (int kp = 0; kp < 2; ++kp) {
+                const int ra = (2 * kp) * 4, rb = (2 * kp + 1) * 4;
+                const unsigned ax = pack2bf(o[db][ra + 0] * inv, o[db][ra + 1] * inv), ay = pack2bf(o[db][ra + 2] * inv, o[db][ra + 3] * inv);
+                const unsigned bx = pack2bf(o[db][rb + 0] * inv, o[db][rb + 1] * inv), by = pack2bf(o[db][rb + 2] * inv, o[db][rb + 3] * inv);
+                const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                if (qrow < T) *(uint4*)(orow + db * 32 + kp * 16 + g * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
             }
     }
     }   // id loop (every wave passed the last tile's barrier: the ring is free for the next id)
@@ -503,8 +509,8 @@ extern "C" void sc_debug_set_attn_trace(void* dev_buf) {     // per-block [8] u6
 static int attention_fwd_impl(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H, int T, int head_dim,
                               int64_t ld_qkv, int64_t ld_out, float scale, int causal, float drop_p, uint32_t seed, void* stream) {
     SC_CHECK_ARG(head_dim == 64, "sc_attention_fwd: head_dim=%d unsupported (64 only; use sc_cls_attention_fwd for pooling heads)", head_dim);
-    SC_CHECK_ARG(ld_qkv % 8 == 0 && ld_out % 4 == 0, "sc_attention_fwd: ld_qkv must be a multiple of 8, ld_out of 4");
-    SC_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "sc_attention_fwd: misaligned pointers");
+    SC_CHECK_ARG(ld_qkv % 8 == 0 && ld_out % 8 == 0, "sc_attention_fwd: ld_qkv and ld_out must be multiples of 8 (16-byte rows)");
+    SC_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "sc_attention_fwd: misaligned pointers");
     SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_attention_fwd_dropout: drop_p=%f must be in [0, 1)", (double)drop_p);
     SC_CHECK_ARG(drop_p == 0.f || (int64_t)B * H * T * T < 0xffffffffLL, "sc_attention_fwd_dropout: B*H*T*T must fit 32 bits (mask element index)");
     if (B <= 0 || T <= 0) return 0;
