@@ -136,7 +136,7 @@ int sc_attention_fwd_dropout(const void* q, const void* k, const void* v, void* 
                              int64_t ld_qkv, int64_t ld_out, float scale, int causal, float drop_p, uint32_t seed, void* stream);
 int sc_dropout_bf16(const void* x, const void* residual, void* out, int64_t n, float drop_p, uint32_t seed, void* stream);
 /* out = LayerNorm(residual + dropout(x)), bf16 [rows, D]: the post-LN sites of a [3P fairseq] TransformerSentenceEncoderLayer in train mode in ONE pass
- * (same mask as sc_dropout_bf16: element index = row*D + column).  Returns 1 when D is not covered (768 is): run sc_dropout_bf16 + sc_layernorm_fwd. */
+ * (same mask as sc_dropout_bf16: element index = row*D + column).  Returns 1 when D is not covered (768 is): run sc_dropout_bf16 + sc_layernorm. */
 int sc_dropout_add_layernorm_bf16(const void* x, const void* residual, const float* gamma, const float* beta, void* out, int64_t rows, int D, float eps,
                                   float drop_p, uint32_t seed, void* stream);
 
@@ -333,7 +333,7 @@ int sc_transpose_bf16(const void* in, int64_t ld_in, int64_t stride_in, void* ou
  * HubertModel.forward_features scales the extractor's gradient by feature_grad_mult).  GEMM-shaped parts reuse sc_gemm_bf16 / sc_gemm_bf16_batched /
  * sc_posconv_conv (speechclip_amd/train_front.py); these entries are the rest:
  *   sc_posconv_finish_train: training forward of the positional-conv tail (speech_encoder_plus.py:35-37): u = conv + bias regrouped from
- *     [B, G, Tp, D/G] to bf16 [B*Tp, D], s = mask(x) + gelu(u) (bf16; the LayerNorm after it runs as sc_layernorm_fwd) -- both kept for the backward.
+ *     [B, G, Tp, D/G] to bf16 [B*Tp, D], s = mask(x) + gelu(u) (bf16; the LayerNorm after it runs as sc_layernorm) -- both kept for the backward.
  *   sc_posconv_dgrad_finish: dx = mask(ds + time-reversed regroup of convT), convT = sc_posconv_conv of the time-reversed du with the in/out
  *     channel-swapped weights (the adjoint of "pad Kw/2, drop the last output" is the same conv on the reversed sequence).
  *   sc_reverse_rows_bf16: out[b, t, :] = in[b, T-1-t, :].

@@ -399,7 +399,7 @@ extern "C" int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, co
 }
 
 // out = LayerNorm(residual + dropout(x)) for bf16 [rows, 768] (the two post-LN sites of a HuBERT-base layer in train mode); returns 1 for any other
-// width (the caller then runs sc_dropout_bf16 + sc_layernorm_fwd).
+// width (the caller then runs sc_dropout_bf16 + sc_layernorm).
 extern "C" int sc_dropout_add_layernorm_bf16(const void* x, const void* residual, const float* gamma, const float* beta, void* out, int64_t rows, int D,
                                              float eps, float drop_p, uint32_t seed, void* stream) {
     SC_CHECK_ARG(x && residual && gamma && beta && out, "sc_dropout_add_layernorm_bf16: null operand");
