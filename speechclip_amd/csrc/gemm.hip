@@ -47,6 +47,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// Cache policy of the 256-tile kernel's LDS-DMA pieces (build options for A/B runs; aux bit 0 = sc0, bit 1 = nt, bit 4 = sc1)
+#ifndef SC_GEMM_A_AUX
+#define SC_GEMM_A_AUX 0
+#endif
+#ifndef SC_GEMM_W_AUX
+#define SC_GEMM_W_AUX 0
+#endif
+template <int AUX>
+__device__ __forceinline__ void glds16_aux(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
+}
 
 // Stage a ROWS x 64 bf16 tile: LDS image is [row][8 chunks of 16 B], chunk position p of row r holds
 // global k-chunk (p ^ (r & 7)).  256 threads => 32 rows per pass.
@@ -338,14 +350,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #if SC_GEMM_BUFDMA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, lane_a_b, (int)((g * lda64 + k0) * 2), 0, 0);
 #else
-        glds16(sa.ta + (g * lda64 + k0) + lane_a, dst);
+        glds16_aux<SC_GEMM_A_AUX>(sa.ta + (g * lda64 + k0) + lane_a, dst);
 #endif
     };
     auto piece_w = [&](int g, int k0, char* dst) {
 #if SC_GEMM_BUFDMA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, lane_w_b, (int)((g * ldw64 + k0) * 2), 0, 0);
 #else
-        glds16(sa.tw + (g * ldw64 + k0) + lane_w, dst);
+        glds16_aux<SC_GEMM_W_AUX>(sa.tw + (g * ldw64 + k0) + lane_w, dst);
 #endif
     };
     int tail_ops = 0;   // vector-memory operations the previous epilogue issued after the next tile's stage-0 pieces (0 = unknown: drain)
