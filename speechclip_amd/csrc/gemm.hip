@@ -319,6 +319,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         return true;
     };
 
+#ifndef SC_GEMM_PRIO      // build option for A/B runs: 0 = priority 1 inside every half-step (default), 1 = no s_setprio at all, 2 = static priority 1 for the
+#define SC_GEMM_PRIO 0    // second-dispatched half of the workgroup (waves 4-7, the SIMD partners of waves 0-3), 3 = static priority 1 for waves 0-3
+#endif
+#if SC_GEMM_PRIO == 2
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#elif SC_GEMM_PRIO == 3
+    if (wave < 4) __builtin_amdgcn_s_setprio(1);
+#endif
     unsigned long long t_begin = TRACE ? __builtin_readcyclecounter() : 0, t_wait = 0, t_loop = 0, t_pre = 0;
     const int64_t lda64 = 64 * p.lda, ldw64 = 64 * p.ldw;
     const int lane_a = (tid >> 3) * (int)p.lda + (((tid & 7) ^ ((tid >> 3) & 7)) << 3);   // row (tid>>3), swizzled k-chunk
@@ -417,7 +425,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         auto half_step = [&](auto dma_tag, const char* srcA, const char* srcW, int off, bool load_next, int dma_k0, char* dma_slot, int dma_ka0, char* dma_aslot) {
             constexpr bool DMA = decltype(dma_tag)::value;      // compile-time: the loop is peeled, no piece sits behind a run-time test
             bf16x8_t bn[4];
+#if SC_GEMM_PRIO == 0
             __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (ABL == 4) {   // perf probe only (results are garbage): same operand traffic, half as many 32x32x16 MFMAs
@@ -471,7 +481,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if SC_GEMM_PRIO == 0
             __builtin_amdgcn_s_setprio(0);
+#endif
             if (load_next) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bfr[j] = bn[j];
