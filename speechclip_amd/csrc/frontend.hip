@@ -232,7 +232,12 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
                 uint4 o = make_uint4(__builtin_amdgcn_ds_bpermute(bperm, r0[0]), __builtin_amdgcn_ds_bpermute(bperm, r1[0]),
                                      __builtin_amdgcn_ds_bpermute(bperm, r0[1]), __builtin_amdgcn_ds_bpermute(bperm, r1[1]));
                 if (!live_row) o = make_uint4(0, 0, 0, 0);
+#if defined(SC_CONV0_NT) && SC_CONV0_NT      // build option for A/B runs: streaming policy on the 8.4 GB output
+                typedef unsigned __attribute__((ext_vector_type(4))) u32x4_nt_t;
+                __builtin_nontemporal_store((u32x4_nt_t){o.x, o.y, o.z, o.w}, (u32x4_nt_t*)(orow + q * 64 + jp * 32));
+#else
                 *(uint4*)(orow + q * 64 + jp * 32) = o;
+#endif
             }
         }
     }
