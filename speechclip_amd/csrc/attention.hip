@@ -25,6 +25,12 @@ constexpr int KV = 64;          // keys per tile
 constexpr int K_TILE_BYTES = KV * 128;
 constexpr int STAGE_BYTES = 2 * K_TILE_BYTES;   // K tile [64 keys][128 B] + V tile [64 keys][128 B], both row-major
 constexpr int NSTAGE = 3;
+// -DSC_ATTN_PP=1 (build option): the two waves a SIMD holds of one 8-wave block (w and w + 4) run half a tile apart -- waves 4-7 enter one
+// barrier interval late, two barriers per tile (after S = K.Q^T and after the softmax arithmetic) keep the offset, so one half's softmax (VALU)
+// always runs beside the other half's P.V + next K.Q^T (MFMA).  Needs a 4-slot K/V ring (a tile stays in use for four intervals).
+#ifndef SC_ATTN_PP
+#define SC_ATTN_PP 0
+#endif
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -51,6 +57,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool PP = SC_ATTN_PP && NW == 8;
+    constexpr int NST = PP ? 4 : NSTAGE;
+    const bool gy = PP && wave >= NW / 2;       // the late half (wave-uniform)
     // XCD-aware 1-D grid: blocks id, id+8, id+16.. share an XCD (and its L2); the nq query blocks of one (b, h) unit are made
     // consecutive on ONE XCD so K/V (128 KB per unit) is fetched from HBM once instead of once per query block.
     // A block can walk `ipb` ids (same XCD: ids bid%8 + 8*(...)).  tools/attn_trace.py shows ~25 % of the resident slots empty at any time
@@ -139,9 +148,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     if (nkv > 0) {
         stage(0, 0);
         if (nkv > 1) stage(1, 1);
-        wait_stage(nkv > 1);
+        if (PP) {
+            if (nkv > 2) { stage(2, 2); asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }      // NW = 8: two DMA instructions per stage and thread
+            else wait_stage(nkv > 1);
+        } else wait_stage(nkv > 1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (gy) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     }
     // One KV tile; SLOT (ring slot of tile j) is a compile-time constant so every LDS address is lane part + immediate.
     // All LDS reads are inline asm with hand-counted lgkmcnt: for a builtin / plain load the compiler cannot prove that the read does
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     auto stamp = [&](unsigned long long& acc_) { if (TRACE) { const unsigned long long t = __builtin_readcyclecounter(); acc_ += t - tr_t; tr_t = t; } };
     auto tile_body = [&](int j, auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
-        if (j + 2 < nkv) stage(j + 2, (SLOT + 2) % NSTAGE);   // that buffer held tile j-1: every wave passed the barrier after reading it
+        if (!PP && j + 2 < nkv) stage(j + 2, (SLOT + 2) % NSTAGE);   // that buffer held tile j-1: every wave passed the barrier after reading it
         // ---- S^T = K . Q^T : all 8 K fragments are requested up front, the MFMAs then run back to back
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
@@ -184,6 +197,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
             asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); kmma(1, 1, k11);
             asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); kmma(1, 2, k12);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); kmma(1, 3, k13);
+        }
+        if (PP) {      // interval boundary a: the late half has its share of tile j+1 landed; tile j-1 is free for everyone after it
+            if (gy) wait_stage(j + 2 < nkv);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (gy && j + 3 < nkv) stage(j + 3, (SLOT + 3) % NST);
         }
 #if !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2)   // perf probe 2: no softmax arithmetic at all (MFMA + LDS + DMA skeleton)
         // ---- mask + online softmax (log2 domain).  Only a tile that crosses the key length (or the causal diagonal)
@@ -280,6 +299,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // none of the compiler's own LDS traffic (the shuffle) outstanding
+        if (PP) {      // interval boundary b
+            if (!gy) wait_stage(j + 2 < nkv);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (!gy && j + 3 < nkv) stage(j + 3, (SLOT + 3) % NST);
+        }
         issue_v(I0{});
         issue_v(I1{}); pv(I0{}, true);
         issue_v(I2{}); pv(I1{}, true);
@@ -288,17 +313,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         // tile j+1 must have landed before anyone reads it; tile j+2 (just issued) stays in flight across the barrier
         asm volatile("" :: "v"(o[0][0]), "v"(o[1][0]));
         if (TRACE) stamp(tr_pv);
+        if (!PP) {
         wait_stage(j + 2 < nkv);
 #if !(defined(SC_ATTN_NOBAR) && SC_ATTN_NOBAR)     // timing probe (garbage results): no per-tile barrier -- what the waves' lock-step costs
         __builtin_amdgcn_s_barrier();
 #endif
+        }
         asm volatile("" ::: "memory");
         stamp(tr_bar);
     };
-    for (int j = 0; j < nkv; j += 3) {
+    for (int j = 0; j < nkv; j += NST) {
         tile_body(j, std::integral_constant<int, 0>{});
         if (j + 1 < nkv) tile_body(j + 1, std::integral_constant<int, 1>{});
         if (j + 2 < nkv) tile_body(j + 2, std::integral_constant<int, 2>{});
+        if (NST == 4 && j + 3 < nkv) tile_body(j + 3, std::integral_constant<int, 3 % NST>{});
+    }
+    if (PP && nkv > 0) {
+        if (!gy) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // the early half's share of the late half's last interval
+        if (ipb > 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } // ring free for the next id
     }
 
     if (TRACE && trace && lane == 0) {     // one row per wave: [id][wave][8]
@@ -514,10 +546,10 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
     SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_attention_fwd_dropout: drop_p=%f must be in [0, 1)", (double)drop_p);
     SC_CHECK_ARG(drop_p == 0.f || (int64_t)B * H * T * T < 0xffffffffLL, "sc_attention_fwd_dropout: B*H*T*T must fit 32 bits (mask element index)");
     if (B <= 0 || T <= 0) return 0;
-    constexpr int lds = NSTAGE * STAGE_BYTES;
     // 8-wave blocks (256 query rows share the K/V ring) when there are at least 256 queries; SC_ATTN_NW=4 forces the 4-wave form
     static const int force_nw = getenv("SC_ATTN_NW") ? atoi(getenv("SC_ATTN_NW")) : 0;
     const int nw = force_nw ? force_nw : (T > 128 ? 8 : 4);
+    const int lds = ((SC_ATTN_PP && nw == 8) ? 4 : NSTAGE) * STAGE_BYTES;
     const int rows = nw * 32;
     const int nq = (T + rows - 1) / rows;
     const int64_t units8 = ((int64_t)H * B + 7) / 8;
