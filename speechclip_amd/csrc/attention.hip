@@ -47,8 +47,9 @@ __device__ __forceinline__ int swz_k(int row) { return SC_ATTN_KSWZ ? ((row >> 1
 
 __device__ unsigned long long* g_attn_trace = nullptr;   // debug: per-block phase cycles (sc_debug_set_attn_trace)
 
-template <int NW, bool TRACE, bool DROP = false>   // DROP: attention-probability dropout (train-mode frozen encoder, sc_attention_fwd_dropout); waves per block: NW x 32 query rows share one K/V ring (4: 128 rows, 8: 256 rows -- half the K/V traffic, 4 waves per SIMD)
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+template <int NW, bool TRACE, bool DROP = false, int QB = 1>   // QB: 32-row query blocks per wave (2: every K / V fragment read feeds two MFMAs, 256 registers, two waves per SIMD)
+   // DROP: attention-probability dropout (train-mode frozen encoder, sc_attention_fwd_dropout); waves per block: NW x 32 query rows share one K/V ring (4: 128 rows, 8: 256 rows -- half the K/V traffic, 4 waves per SIMD)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1 ? 4 : 2))) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
                                                        const int32_t* __restrict__ klens, int T, int64_t ld_qkv,
                                                        int64_t ld_out, float scale_log2e, int causal, int B, int H, int nq, int n_ids, int ipb,
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int ROWS = NW * 32 * QB;          // query rows per block
     constexpr bool PP = SC_ATTN_PP && NW == 8;
     constexpr int NST = PP ? 4 : NSTAGE;
     const bool gy = PP && wave >= NW / 2;       // the late half (wave-uniform)
@@ -83,19 +85,27 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     klen = klen < 0 ? 0 : (klen > T ? T : klen);
     int nkv = (klen + KV - 1) / KV;
     if (causal) {  // keys beyond the block's last query are never needed
-        const int last_q = min(T, qblk * (NW * 32) + NW * 32);
+        const int last_q = min(T, qblk * ROWS + ROWS);
         nkv = min(nkv, (last_q + KV - 1) / KV);
     }
 
-    const int qrow = qblk * (NW * 32) + wave * 32 + ql;
-    const int qrow_c = qrow < T ? qrow : T - 1;
-    const uint32_t drop_row = DROP ? (uint32_t)((b * H + h) * T + qrow_c) : 0u, drop_pairs = (uint32_t)((T + 1) >> 1);
+    int qrow[QB], qrow_c[QB];
+    uint32_t drop_row[QB];
+    const uint32_t drop_pairs = (uint32_t)((T + 1) >> 1);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        qrow[qb] = qblk * ROWS + wave * (32 * QB) + qb * 32 + ql;
+        qrow_c[qb] = qrow[qb] < T ? qrow[qb] : T - 1;
+        drop_row[qb] = DROP ? (uint32_t)((b * H + h) * T + qrow_c[qb]) : 0u;
+    }
 
     // Q fragments: B operand of S^T (col = query, k-slots = 8 dims)
-    bf16x8_t qf[4];
+    bf16x8_t qf[QB][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-        qf[c] = *(const bf16x8_t*)(q + (row_base + qrow_c) * ld_qkv + hoff + c * 16 + g * 8);
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            qf[qb][c] = *(const bf16x8_t*)(q + (row_base + qrow_c[qb]) * ld_qkv + hoff + c * 16 + g * 8);
 
     // K and V tiles both arrive by LDS-DMA (no VGPR staging): 2 + 2 instructions per thread per tile.  Source addressing is kept
     // cheap: a 64-bit per-thread base (row 0 of the unit, this thread's key row / chunk) + a 32-bit row offset per tile.
@@ -123,10 +133,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     };
 
-    f32x16_t o[2];
+    f32x16_t o[QB][2];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[qb][0][i] = 0.f; o[qb][1][i] = 0.f; }
+        m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+    }
 
     // Lane parts of the LDS fragment addresses (ring slot and kb / hb / +8-row terms are compile-time immediates below).
     // K: key = kb*32 + ql, chunk (2c+g) ^ (key & 7) -- the XOR makes the four c distinct lane parts.
@@ -172,9 +186,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         // 6 of the 8 K fragments are requested up front, the last two once the first two MFMAs have consumed theirs (their registers are
         // free again): 24 instead of 32 VGPRs at the peak of the kernel's register pressure -- what keeps it at <= 128 with the
         // persistent-block loop around it.  lgkmcnt bookkeeping: R0..R5 out -> wait 5,4 -> R6,R7 out -> wait 5,4,3,2,1,0.
-        f32x16_t s[2];
+        f32x16_t s[QB][2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[qb][0][i] = 0.f; s[qb][1][i] = 0.f; }
         auto kread = [&](int kb, int c) -> u32x4_t {
             const unsigned addr = ka[c];
             u32x4_t t;
@@ -184,7 +200,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         };
         auto kmma = [&](int kb, int c, u32x4_t t) {
             asm volatile("" : "+v"(t));
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, t), qf[c], s[kb], 0, 0, 0);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, t), qf[qb][c], s[qb][kb], 0, 0, 0);
         };
         {
             u32x4_t k00 = kread(0, 0), k01 = kread(0, 1), k02 = kread(0, 2), k03 = kread(0, 3), k10 = kread(1, 0), k11 = kread(1, 1);
@@ -207,41 +225,43 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 #if !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2)   // perf probe 2: no softmax arithmetic at all (MFMA + LDS + DMA skeleton)
         // ---- mask + online softmax (log2 domain).  Only a tile that crosses the key length (or the causal diagonal)
         //      pays for per-element masking; full tiles take the short path.
-        float mx = -INFINITY;
         const int kv0 = j * KV;
         const bool partial = (kv0 + KV > klen) || causal;
+        unsigned ppk[QB][2][8];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+        float mx = -INFINITY;
         if (partial) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    float t = s[kb][r] * scale_log2e;
-                    t = (key < klen && (!causal || key <= qrow)) ? t : -INFINITY;
-                    s[kb][r] = t;
+                    float t = s[qb][kb][r] * scale_log2e;
+                    t = (key < klen && (!causal || key <= qrow[qb])) ? t : -INFINITY;
+                    s[qb][kb][r] = t;
                     mx = fmaxf(mx, t);
                 }
         } else {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
             mx *= scale_log2e;   // scale > 0: max commutes with the scaling
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         asm volatile("" :: "v"(mx));   // phase boundary (also keeps the scheduler from interleaving the phases into a register-pressure peak)
-        if (TRACE) stamp(tr_qk);           // S complete (the max depends on every MFMA result)
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
-        m_run = m_new;
+        if (TRACE && qb == 0) stamp(tr_qk);           // S complete (the max depends on every MFMA result)
+        const float m_new = fmaxf(m_run[qb], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);  // first tile: exp2(-inf) = 0
+        m_run[qb] = m_new;
         f32x2_t psum2 = {0.f, 0.f};
-        unsigned ppk[2][8];
         const float sc = partial ? 1.0f : scale_log2e;               // partial tiles were scaled while masking
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const f32x2_t a2 = (f32x2_t){s[kb][r], s[kb][r + 1]} * sc - m_new;       // one v_pk_fma_f32 per pair
+                const f32x2_t a2 = (f32x2_t){s[qb][kb][r], s[qb][kb][r + 1]} * sc - m_new;       // one v_pk_fma_f32 per pair
 #if defined(SC_ATTN_ABL) && SC_ATTN_ABL == 1
                 const f32x2_t p2 = a2 * 0.001f;                                            // perf probe: no transcendental
 #else
@@ -251,19 +271,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
                     // torch: attn = dropout(softmax(s)) -- the row sum keeps every probability, the P.V product sees the masked, rescaled ones.
                     // this lane's registers r, r + 1 hold the adjacent keys kv0 + kb*32 + (r & 3) + 8*(r >> 2) + 4*g (even) and + 1: one hash per pair
                     const uint32_t key = (uint32_t)(kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g);
-                    const uint32_t hbits = hash_pair(drop_seed, drop_row * drop_pairs + (key >> 1));
+                    const uint32_t hbits = hash_pair(drop_seed, drop_row[qb] * drop_pairs + (key >> 1));
                     const float d0 = (hbits & 0xffffu) >= drop_thresh_ ? p2[0] * drop_keep_scale : 0.f;
                     const float d1 = (hbits >> 16) >= drop_thresh_ ? p2[1] * drop_keep_scale : 0.f;
-                    ppk[kb][r >> 1] = pack2bf(d0, d1);
+                    ppk[qb][kb][r >> 1] = pack2bf(d0, d1);
                 } else
-                ppk[kb][r >> 1] = pack2bf(p2[0], p2[1]);       // P leaves the fp32 registers right here: 16 VGPRs instead of 32 through the PV phase
+                ppk[qb][kb][r >> 1] = pack2bf(p2[0], p2[1]);       // P leaves the fp32 registers right here: 16 VGPRs instead of 32 through the PV phase
                 psum2 += p2;
             }
-        l_run = l_run * alpha + (psum2[0] + psum2[1]);
+        l_run[qb] = l_run[qb] * alpha + (psum2[0] + psum2[1]);
         if (alpha != 1.0f) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+            for (int i = 0; i < 16; ++i) { o[qb][0][i] *= alpha; o[qb][1][i] *= alpha; }
         }
+        }   // qb
 #endif
         // ---- O^T += V^T . P^T : V^T fragments come straight out of the row-major V tile via the transposing LDS read
         u32x2_t vlo[2][2], vhi[2][2];                               // [parity of c4][db]
@@ -282,8 +303,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         auto pv = [&](auto c4c, bool more) {
             constexpr int c4 = decltype(c4c)::value;
             constexpr int kb = c4 >> 1, hb = c4 & 1;
-            const u32x4_t pfu = {ppk[kb][hb * 4 + 0], ppk[kb][hb * 4 + 1], ppk[kb][hb * 4 + 2], ppk[kb][hb * 4 + 3]};
-            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pfu);
+            bf16x8_t pf[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const u32x4_t pfu = {ppk[qb][kb][hb * 4 + 0], ppk[qb][kb][hb * 4 + 1], ppk[qb][kb][hb * 4 + 2], ppk[qb][kb][hb * 4 + 3]};
+                pf[qb] = __builtin_bit_cast(bf16x8_t, pfu);
+            }
             if (more) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -291,10 +316,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
                 u32x2_t lo = vlo[c4 & 1][db], hi = vhi[c4 & 1][db];
                 asm volatile("" : "+v"(lo), "+v"(hi));                // valid only after the wait above: pin the use below it
                 const u32x4_t both = {lo[0], lo[1], hi[0], hi[1]};
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, both), pf, o[db], 0, 0, 0);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, both), pf[qb], o[qb][db], 0, 0, 0);
             }
         };
-        asm volatile("" :: "v"(l_run));
+        asm volatile("" :: "v"(l_run[0]));
         if (TRACE) stamp(tr_sm);
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -311,7 +338,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         issue_v(I3{}); pv(I2{}, true);
         pv(I3{}, false);
         // tile j+1 must have landed before anyone reads it; tile j+2 (just issued) stays in flight across the barrier
-        asm volatile("" :: "v"(o[0][0]), "v"(o[1][0]));
+        asm volatile("" :: "v"(o[0][0][0]), "v"(o[0][1][0]));
         if (TRACE) stamp(tr_pv);
         if (!PP) {
         wait_stage(j + 2 < nkv);
@@ -338,26 +365,29 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         tr[0] = tr_qk; tr[1] = tr_sm; tr[2] = tr_pv; tr[3] = tr_bar; tr[4] = nkv; tr[5] = tr_start; tr[6] = __builtin_amdgcn_s_memrealtime();
         tr[7] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | ((32 - 1) << 11));
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     {
         // A row is split across the half-waves: lane (g, ql) holds columns 8 rq + 4 g .. + 3 of every 8-column group rq.  v_permlane32_swap between
         // the groups rq = 2k (vdst) and 2k + 1 (src) leaves 16 contiguous bytes in every lane (lower half: columns 16k .. 16k+7, upper half: 16k+8 ..
         // 16k+15), so the row goes out as 4 dwordx4 stores per lane instead of 8 dwordx2: the store tail is issue-bound per instruction
         // (MI355X_MICROARCH.md, T21).  The swaps run in every lane (outside the row test: both halves of a row take the same branch anyway).
-        bf16_t* orow = out + (row_base + qrow_c) * ld_out + hoff;
+        bf16_t* orow = out + (row_base + qrow_c[qb]) * ld_out + hoff;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
                 const int ra = (2 * kp) * 4, rb = (2 * kp + 1) * 4;
-                const unsigned ax = pack2bf(o[db][ra + 0] * inv, o[db][ra + 1] * inv), ay = pack2bf(o[db][ra + 2] * inv, o[db][ra + 3] * inv);
-                const unsigned bx = pack2bf(o[db][rb + 0] * inv, o[db][rb + 1] * inv), by = pack2bf(o[db][rb + 2] * inv, o[db][rb + 3] * inv);
+                const unsigned ax = pack2bf(o[qb][db][ra + 0] * inv, o[qb][db][ra + 1] * inv), ay = pack2bf(o[qb][db][ra + 2] * inv, o[qb][db][ra + 3] * inv);
+                const unsigned bx = pack2bf(o[qb][db][rb + 0] * inv, o[qb][db][rb + 1] * inv), by = pack2bf(o[qb][db][rb + 2] * inv, o[qb][db][rb + 3] * inv);
                 const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                if (qrow < T) *(uint4*)(orow + db * 32 + kp * 16 + g * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                if (qrow[qb] < T) *(uint4*)(orow + db * 32 + kp * 16 + g * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
             }
     }
+    }   // qb
     }   // id loop (every wave passed the last tile's barrier: the ring is free for the next id)
 }
 
@@ -548,9 +578,12 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
     if (B <= 0 || T <= 0) return 0;
     // 8-wave blocks (256 query rows share the K/V ring) when there are at least 256 queries; SC_ATTN_NW=4 forces the 4-wave form
     static const int force_nw = getenv("SC_ATTN_NW") ? atoi(getenv("SC_ATTN_NW")) : 0;
-    const int nw = force_nw ? force_nw : (T > 128 ? 8 : 4);
+    // SC_ATTN_QB=2 (A/B): 4 waves x 64 query rows instead of 8 waves x 32 for the long-sequence form
+    static const int qb_env = getenv("SC_ATTN_QB") ? atoi(getenv("SC_ATTN_QB")) : 1;
+    const bool qb2 = (qb_env == 2 || qb_env == 3) && T > 128 && !force_nw && drop_p == 0.f && !g_attn_trace_host;
+    const int nw = force_nw ? force_nw : (qb2 ? (qb_env == 3 ? 8 : 4) : (T > 128 ? 8 : 4));
     const int lds = ((SC_ATTN_PP && nw == 8) ? 4 : NSTAGE) * STAGE_BYTES;
-    const int rows = nw * 32;
+    const int rows = nw * 32 * (qb2 ? 2 : 1);
     const int nq = (T + rows - 1) / rows;
     const int64_t units8 = ((int64_t)H * B + 7) / 8;
     SC_CHECK_ARG(units8 * 8 * nq < 0x7fffffff, "sc_attention_fwd: grid too large");
@@ -562,14 +595,15 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
     dim3 grid((unsigned)(groups8 * 8));
     const uint32_t th = drop_thresh16(drop_p);         // 16 random bits per probability: see hash_pair (common.h)
     const float ks = 1.0f / (1.0f - drop_p);
-#define ATTN_LAUNCH(NW_, TR_, DR_)                                                                                                          \
+#define ATTN_LAUNCH(NW_, TR_, DR_, ...)                                                                                                     \
     do {                                                                                                                                    \
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NW_, TR_, DR_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);            \
-        hipLaunchKernelGGL((attn_fwd_kernel<NW_, TR_, DR_>), grid, dim3(NW_ * 64), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, \
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NW_, TR_, DR_, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);            \
+        hipLaunchKernelGGL((attn_fwd_kernel<NW_, TR_, DR_, ##__VA_ARGS__>), grid, dim3(NW_ * 64), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, \
                            (const bf16_t*)v, (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq, n_ids, ipb, \
                            seed, th, ks);                                                                                                   \
     } while (0)
-    if (th) { if (nw == 8) ATTN_LAUNCH(8, false, true); else ATTN_LAUNCH(4, false, true); }
+    if (qb2) { if (nw == 8) ATTN_LAUNCH(8, false, false, 2); else ATTN_LAUNCH(4, false, false, 2); }
+    else if (th) { if (nw == 8) ATTN_LAUNCH(8, false, true); else ATTN_LAUNCH(4, false, true); }
     else if (g_attn_trace_host) { if (nw == 8) ATTN_LAUNCH(8, true, false); else ATTN_LAUNCH(4, true, false); }
     else if (nw == 8) ATTN_LAUNCH(8, false, false);
     else ATTN_LAUNCH(4, false, false);
