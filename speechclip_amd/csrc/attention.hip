@@ -179,7 +179,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
     auto stamp = [&](unsigned long long& acc_) { if (TRACE) { const unsigned long long t = __builtin_readcyclecounter(); acc_ += t - tr_t; tr_t = t; } };
     auto tile_body = [&](int j, auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
-        if (!PP && j + 2 < nkv) stage(j + 2, (SLOT + 2) % NSTAGE);   // that buffer held tile j-1: every wave passed the barrier after reading it
+#if !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 3)   // perf probe 3 (garbage results): no K / V DMA inside the tile loop
+        if (!PP && j + 2 < nkv) stage(j + 2, (SLOT + 2) % NSTAGE);
+#endif
+        //   // that buffer held tile j-1: every wave passed the barrier after reading it
         // ---- S^T = K . Q^T : all 8 K fragments are requested up front, the MFMAs then run back to back
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
@@ -194,15 +197,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
         auto kread = [&](int kb, int c) -> u32x4_t {
             const unsigned addr = ka[c];
             u32x4_t t;
+#if defined(SC_ATTN_ABL) && SC_ATTN_ABL == 5      // perf probe 5 (garbage results): no LDS fragment reads
+            t = (u32x4_t){addr, addr, addr, addr};
+            return t;
+#endif
             if (kb == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(addr), "i"(SLOT * STAGE_BYTES));
             else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(addr), "i"(SLOT * STAGE_BYTES + 4096));
             return t;
         };
         auto kmma = [&](int kb, int c, u32x4_t t) {
             asm volatile("" : "+v"(t));
+#if defined(SC_ATTN_ABL) && SC_ATTN_ABL == 4      // perf probe 4 (garbage results): no MFMA
+            asm volatile("" :: "v"(t));
+            s[0][kb][c] += 1.0f;
+#else
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
                 s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, t), qf[qb][c], s[qb][kb], 0, 0, 0);
+#endif
         };
         {
             u32x4_t k00 = kread(0, 0), k01 = kread(0, 1), k02 = kread(0, 2), k03 = kread(0, 3), k10 = kread(1, 0), k11 = kread(1, 1);
@@ -222,12 +234,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
             asm volatile("" ::: "memory");
             if (gy && j + 3 < nkv) stage(j + 3, (SLOT + 3) % NST);
         }
-#if !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2)   // perf probe 2: no softmax arithmetic at all (MFMA + LDS + DMA skeleton)
-        // ---- mask + online softmax (log2 domain).  Only a tile that crosses the key length (or the causal diagonal)
-        //      pays for per-element masking; full tiles take the short path.
         const int kv0 = j * KV;
         const bool partial = (kv0 + KV > klen) || causal;
         unsigned ppk[QB][2][8];
+#if defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ppk[qb][i >> 3][i & 7] = __float_as_uint(s[qb][i >> 3][i] + s[qb][i >> 3][15 - i]);
+#endif
+#if !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2)   // perf probe 2: no softmax arithmetic at all (MFMA + LDS + DMA skeleton)
+        // ---- mask + online softmax (log2 domain).  Only a tile that crosses the key length (or the causal diagonal)
+        //      pays for per-element masking; full tiles take the short path.
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
         float mx = -INFINITY;
@@ -295,8 +313,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
             for (int db = 0; db < 2; ++db) {
                 const unsigned addr = va[db];
                 u32x2_t t0, t1;
+#if defined(SC_ATTN_ABL) && SC_ATTN_ABL == 5
+                t0 = (u32x2_t){addr, addr}; t1 = t0;
+#else
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t0) : "v"(addr), "i"(off));
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t1) : "v"(addr), "i"(off + 1024));
+#endif
                 vlo[c4 & 1][db] = t0; vhi[c4 & 1][db] = t1;
             }
         };
@@ -316,9 +338,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
                 u32x2_t lo = vlo[c4 & 1][db], hi = vhi[c4 & 1][db];
                 asm volatile("" : "+v"(lo), "+v"(hi));                // valid only after the wait above: pin the use below it
                 const u32x4_t both = {lo[0], lo[1], hi[0], hi[1]};
+#if defined(SC_ATTN_ABL) && SC_ATTN_ABL == 4
+                asm volatile("" :: "v"(both), "v"(pf[0]));
+                o[0][db][c4] += 1.0f;
+#else
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
                     o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, both), pf[qb], o[qb][db], 0, 0, 0);
+#endif
             }
         };
         asm volatile("" :: "v"(l_run[0]));
