@@ -243,69 +243,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
 #pragma unroll
             for (int i = 0; i < 16; ++i) ppk[qb][i >> 3][i & 7] = __float_as_uint(s[qb][i >> 3][i] + s[qb][i >> 3][15 - i]);
 #endif
-#ifndef SC_ATTN_ILV      // 1: the softmax of the second 32 keys is issued between the P.V MFMAs of the first 32 (matrix / vector overlap inside one wave's stream)
-#define SC_ATTN_ILV 0
-#endif
-#if SC_ATTN_ILV && !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2)
-        float m_new_[QB];
-        f32x2_t psum2_[QB];
-        const float sc_ = partial ? 1.0f : scale_log2e;               // partial tiles were scaled while masking
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            float mx = -INFINITY;
-            if (partial) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                        float t = s[qb][kb][r] * scale_log2e;
-                        t = (key < klen && (!causal || key <= qrow[qb])) ? t : -INFINITY;
-                        s[qb][kb][r] = t;
-                        mx = fmaxf(mx, t);
-                    }
-            } else {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
-                mx *= scale_log2e;
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            asm volatile("" :: "v"(mx));
-            if (TRACE && qb == 0) stamp(tr_qk);
-            const float m_new = fmaxf(m_run[qb], mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
-            m_run[qb] = m_new; m_new_[qb] = m_new;
-            l_run[qb] *= alpha;
-            psum2_[qb] = (f32x2_t){0.f, 0.f};
-            if (alpha != 1.0f) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { o[qb][0][i] *= alpha; o[qb][1][i] *= alpha; }
-            }
-        }
-        auto exp_rows = [&](auto kbc, auto r0c, auto r1c) {
-            constexpr int kb = decltype(kbc)::value, r0 = decltype(r0c)::value, r1 = decltype(r1c)::value;
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int r = r0; r < r1; r += 2) {
-                    const f32x2_t a2 = (f32x2_t){s[qb][kb][r], s[qb][kb][r + 1]} * sc_ - m_new_[qb];
-                    const f32x2_t p2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
-                    if (DROP) {
-                        const uint32_t key = (uint32_t)(kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g);
-                        const uint32_t hbits = hash_pair(drop_seed, drop_row[qb] * drop_pairs + (key >> 1));
-                        const float d0 = (hbits & 0xffffu) >= drop_thresh_ ? p2[0] * drop_keep_scale : 0.f;
-                        const float d1 = (hbits >> 16) >= drop_thresh_ ? p2[1] * drop_keep_scale : 0.f;
-                        ppk[qb][kb][r >> 1] = pack2bf(d0, d1);
-                    } else
-                        ppk[qb][kb][r >> 1] = pack2bf(p2[0], p2[1]);
-                    psum2_[qb] += p2;
-                }
-        };
-        using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
-        using J8 = std::integral_constant<int, 8>; using J16 = std::integral_constant<int, 16>;
-#elif !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2)   // perf probe 2: no softmax arithmetic at all (MFMA + LDS + DMA skeleton)
+#if !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2)   // perf probe 2: no softmax arithmetic at all (MFMA + LDS + DMA skeleton)
         // ---- mask + online softmax (log2 domain).  Only a tile that crosses the key length (or the causal diagonal)
         //      pays for per-element masking; full tiles take the short path.
 #pragma unroll
@@ -421,31 +359,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
             asm volatile("" ::: "memory");
             if (!gy && j + 3 < nkv) stage(j + 3, (SLOT + 3) % NST);
         }
-#if SC_ATTN_ILV && !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2)
-        issue_v(I0{});
-        issue_v(I1{});
-        __builtin_amdgcn_sched_barrier(0);
-        exp_rows(J0{}, J0{}, J16{});          // the first V fragments travel while the first 32 keys are exponentiated
-        __builtin_amdgcn_sched_barrier(0);
-        pv(I0{}, true);
-        __builtin_amdgcn_sched_barrier(0);
-        exp_rows(J1{}, J0{}, J8{});
-        __builtin_amdgcn_sched_barrier(0);
-        issue_v(I2{}); pv(I1{}, true);
-        __builtin_amdgcn_sched_barrier(0);
-        exp_rows(J1{}, J8{}, J16{});
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) l_run[qb] += psum2_[qb][0] + psum2_[qb][1];
-        __builtin_amdgcn_sched_barrier(0);
-        issue_v(I3{}); pv(I2{}, true);
-        pv(I3{}, false);
-#else
         issue_v(I0{});
         issue_v(I1{}); pv(I0{}, true);
         issue_v(I2{}); pv(I1{}, true);
         issue_v(I3{}); pv(I2{}, true);
         pv(I3{}, false);
-#endif
         // tile j+1 must have landed before anyone reads it; tile j+2 (just issued) stays in flight across the barrier
         asm volatile("" :: "v"(o[0][0][0]), "v"(o[0][1][0]));
         if (TRACE) stamp(tr_pv);
