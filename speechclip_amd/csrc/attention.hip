@@ -180,9 +180,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
     auto tile_body = [&](int j, auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
 #if !(defined(SC_ATTN_ABL) && SC_ATTN_ABL == 3)   // perf probe 3 (garbage results): no K / V DMA inside the tile loop
-        if (!PP && j + 2 < nkv) stage(j + 2, (SLOT + 2) % NSTAGE);
+        if (!PP && j + 2 < nkv) stage(j + 2, (SLOT + 2) % NSTAGE);   // that buffer held tile j-1: every wave passed the barrier after reading it
 #endif
-        //   // that buffer held tile j-1: every wave passed the barrier after reading it
         // ---- S^T = K . Q^T : all 8 K fragments are requested up front, the MFMAs then run back to back
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
