@@ -266,7 +266,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
             mx *= scale_log2e;   // scale > 0: max commutes with the scaling
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        {   // the other half-wave's maximum by v_permlane32_swap (a VALU op) instead of an LDS-crossbar shuffle: no lgkmcnt round trip in the tile's serial chain
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         asm volatile("" :: "v"(mx));   // phase boundary (also keeps the scheduler from interleaving the phases into a register-pressure peak)
         if (TRACE && qb == 0) stamp(tr_qk);           // S complete (the max depends on every MFMA result)
         const float m_new = fmaxf(m_run[qb], mx);
@@ -393,7 +396,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
     }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qb]), __float_as_uint(l_run[qb]), false, false);
+    const float l_tot = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     {
         // A row is split across the half-waves: lane (g, ql) holds columns 8 rq + 4 g .. + 3 of every 8-column group rq.  v_permlane32_swap between
