@@ -233,6 +233,30 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
             asm volatile("" ::: "memory");
             if (gy && j + 3 < nkv) stage(j + 3, (SLOT + 3) % NST);
         }
+        // ---- O^T += V^T . P^T : V^T fragments come straight out of the row-major V tile via the transposing LDS read
+        u32x2_t vlo[2][2], vhi[2][2];                               // [parity of c4][db]
+        auto issue_v = [&](auto c4c) {
+            constexpr int c4 = decltype(c4c)::value;
+            constexpr int off = SLOT * STAGE_BYTES + (c4 >> 1) * 4096 + (c4 & 1) * 2048;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const unsigned addr = va[db];
+                u32x2_t t0, t1;
+#if defined(SC_ATTN_ABL) && SC_ATTN_ABL == 5
+                t0 = (u32x2_t){addr, addr}; t1 = t0;
+#else
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t0) : "v"(addr), "i"(off));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t1) : "v"(addr), "i"(off + 1024));
+#endif
+                vlo[c4 & 1][db] = t0; vhi[c4 & 1][db] = t1;
+            }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+#ifndef SC_ATTN_VEARLY    // 1: the first V fragments are requested before the softmax arithmetic instead of after it (8 more live VGPRs)
+#define SC_ATTN_VEARLY 0
+#endif
+        if (SC_ATTN_VEARLY && !PP) issue_v(I0{});
         const int kv0 = j * KV;
         const bool partial = (kv0 + KV > klen) || causal;
         unsigned ppk[QB][2][8];
@@ -306,24 +330,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
         }
         }   // qb
 #endif
-        // ---- O^T += V^T . P^T : V^T fragments come straight out of the row-major V tile via the transposing LDS read
-        u32x2_t vlo[2][2], vhi[2][2];                               // [parity of c4][db]
-        auto issue_v = [&](auto c4c) {
-            constexpr int c4 = decltype(c4c)::value;
-            constexpr int off = SLOT * STAGE_BYTES + (c4 >> 1) * 4096 + (c4 & 1) * 2048;
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const unsigned addr = va[db];
-                u32x2_t t0, t1;
-#if defined(SC_ATTN_ABL) && SC_ATTN_ABL == 5
-                t0 = (u32x2_t){addr, addr}; t1 = t0;
-#else
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t0) : "v"(addr), "i"(off));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t1) : "v"(addr), "i"(off + 1024));
-#endif
-                vlo[c4 & 1][db] = t0; vhi[c4 & 1][db] = t1;
-            }
-        };
         auto pv = [&](auto c4c, bool more) {
             constexpr int c4 = decltype(c4c)::value;
             constexpr int kb = c4 >> 1, hb = c4 & 1;
@@ -352,16 +358,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
         };
         asm volatile("" :: "v"(l_run[0]));
         if (TRACE) stamp(tr_sm);
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // none of the compiler's own LDS traffic (the shuffle) outstanding
+        if (!(SC_ATTN_VEARLY && !PP)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // none of the compiler's own LDS traffic outstanding
         if (PP) {      // interval boundary b
             if (!gy) wait_stage(j + 2 < nkv);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (!gy && j + 3 < nkv) stage(j + 3, (SLOT + 3) % NST);
         }
-        issue_v(I0{});
+        if (!(SC_ATTN_VEARLY && !PP)) issue_v(I0{});
         issue_v(I1{}); pv(I0{}, true);
         issue_v(I2{}); pv(I1{}, true);
         issue_v(I3{}); pv(I2{}, true);
