@@ -319,9 +319,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         return true;
     };
 
-#ifndef SC_GEMM_PRIO      // build option for A/B runs: 0 = priority 1 inside every half-step (default), 1 = no s_setprio at all, 2 = static priority 1 for the
-#define SC_GEMM_PRIO 0    // second-dispatched half of the workgroup (waves 4-7, the SIMD partners of waves 0-3), 3 = static priority 1 for waves 0-3
-#endif
+#ifndef SC_GEMM_PRIO      // wave priority in the k-loop: 1 = no s_setprio at all (default: -0.2 ms per step over 7 same-box A/B passes against 0), 0 = priority 1
+#define SC_GEMM_PRIO 1    // inside every half-step (the round-1 form), 2 = static priority 1 for the second-dispatched half of the workgroup (waves 4-7,
+#endif                    // the SIMD partners of waves 0-3), 3 = static priority 1 for waves 0-3
 #if SC_GEMM_PRIO == 2
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #elif SC_GEMM_PRIO == 3
