@@ -274,11 +274,11 @@ class HubertModel(nn.Module):
         Tp = self.frame_geometry(lmax)[3]
         return d % 256 == 0 and B * Tp >= 256 and self.cfg.encoder_ffn_embed_dim >= 256
 
-    @torch.no_grad()
     def dropout_rates(self):
         c = self.cfg
         return dict(features=float(c.dropout_input), hidden=float(c.dropout), attention=float(c.attention_dropout), activation=float(c.activation_dropout))
 
+    @torch.no_grad()
     def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int], fold_ln: bool = False, stop_layer: int = None, drop_layers=(),
                            dropout_seed: int = None):
         """wav: f32 [B, Lmax] device tensor (right zero-padded); lens: host ints.
@@ -292,9 +292,11 @@ class HubertModel(nn.Module):
         normalised state and the PRE-LayerNorm outputs of the layers with the affines of their final LayerNorms (ops.weighted_sum_ln mixes them)."""
         cfg = self.cfg
         dev = wav.device
-        # packed bf16 operands are rebuilt when a load replaced the weights (post-hook) or an optimizer step moved TRAINABLE encoder weights
-        # (fine-tuning: ops.param_epoch; frozen encoders never repack)
-        epoch = ops.param_epoch(*[p for p in self.parameters() if p.requires_grad]) if any(p.requires_grad for p in self.parameters()) else -1
+        # packed bf16 operands are rebuilt when a load replaced the weights (post-hook) or an optimizer step moved TRAINABLE encoder weights:
+        # ops.param_epoch moves on FusedAdam steps (raw-pointer writes), the tensors' own `_version` on any torch optimizer (the fallback of
+        # configure_optimizers for optim.name != "Adam" / CPU params) or in-place edit; frozen encoders never repack
+        trainable = [p for p in self.parameters() if p.requires_grad]
+        epoch = (ops.param_epoch(*trainable), sum(p._version for p in trainable)) if trainable else -1
         if self._packed is None or getattr(self, "_packed_epoch", -1) != epoch:
             self._packed = self._pack(dev)
             self._packed_epoch = epoch

@@ -63,7 +63,7 @@ def test_tiny_parallel_vs_reference_glue(tag, large):
         assert _cos(hidden[-1][b:b + 1, :L], torch.from_numpy(g["hidden_last"])[b:b + 1, :L]).item() > 0.998
         assert _cos(audio_feat[b:b + 1, :L], torch.from_numpy(g["audio_feat"])[b:b + 1, :L]).item() > 0.998
     assert_rows_match(loss_feats["image_feat"], torch.from_numpy(g["image_feat"]), 0.99, "image_feat")
-    cc = assert_rows_match(loss_feats["parallel_audio_feat"], torch.from_numpy(g["parallel_audio_feat"]), 0.98, "parallel_audio_feat")
+    cc = assert_rows_match(loss_feats["parallel_audio_feat"], torch.from_numpy(g["parallel_audio_feat"]), 0.99, "parallel_audio_feat")
     print(tag, "parallel_audio_feat centred cosine per row:", cc.tolist())
     assert abs(loss - float(g["loss"])) < 2e-2, (loss, float(g["loss"]))
     assert abs(log_metrics["cl_temp"] - 1 / 0.07) < 1e-4
@@ -122,7 +122,7 @@ def test_base_dims_vs_oracle():
         lf, _, _ = model({k: v.cuda() for k, v in batch.items()})
         loss = model.compute_loss(lf)["loss"].item()
     assert_rows_match(lf["image_feat"], o["image_feat"], 0.99, "image_feat")
-    cc = assert_rows_match(lf["parallel_audio_feat"], o["parallel_audio_feat"], 0.98, "parallel_audio_feat")
+    cc = assert_rows_match(lf["parallel_audio_feat"], o["parallel_audio_feat"], 0.99, "parallel_audio_feat")
     print("base dims: parallel_audio_feat centred cosine per row:", cc.tolist(), " raw cosine between different utterances (oracle):",
           _cos(o["parallel_audio_feat"][:1], o["parallel_audio_feat"][1:2]).item())
     logit_err = ((lf["parallel_audio_feat"].cpu() @ lf["image_feat"].cpu().t() - o["parallel_audio_feat"] @ o["image_feat"].t()) / 0.07).abs().max().item()
@@ -174,7 +174,7 @@ def test_large_dims_vs_oracle():
         loss = model.compute_loss(lf)["loss"].item()
     assert lf["image_feat"].shape == (2, 768) and lf["parallel_audio_feat"].shape == (2, 768)
     assert_rows_match(lf["image_feat"], o["image_feat"], 0.99, "image_feat")
-    cc = assert_rows_match(lf["parallel_audio_feat"], o["parallel_audio_feat"], 0.98, "parallel_audio_feat")
+    cc = assert_rows_match(lf["parallel_audio_feat"], o["parallel_audio_feat"], 0.99, "parallel_audio_feat")
     print("large dims: parallel_audio_feat centred cosine per row:", cc.tolist())
     assert abs(loss - ref_loss) < 2e-2, (loss, ref_loss)
     assert abs(lm["cl_temp"] - 1 / 0.07) < 1e-3
@@ -285,7 +285,8 @@ def test_rccl_packed_gather_on_one_gpu():
 def test_validation_hooks_recall_vs_oracle_pipeline():
     """Lightning's validation protocol end to end on the device (validation_step -> validation_step_end -> validation_epoch_end ->
     mutualRetrieval through sc_sgemm + sc_retrieval_ranks) against the oracle's features + argsort-based recall on the same batches:
-    the score matrices must agree closely and recall@K may differ only by candidates whose scores are within that tolerance."""
+    the score matrices must agree closely and the hooks' recall@K must be the argsort recall of their own score matrix.  (Recall parity
+    against the oracle: tests/test_recall_gpu.py, a trained discriminative 1000-pair set.)"""
     from oracle.speechclip_ref import SpeechClipRef, mutual_retrieval
     from oracle.clip_ref import ClipRefConfig
     from oracle.hubert_ref import HubertRefConfig
@@ -331,16 +332,14 @@ def test_validation_hooks_recall_vs_oracle_pipeline():
     img_d = torch.cat([x["image_feat"] for x in outs]).float()[torch.tensor(list(first.values()))]
     score_dev = aud_d @ img_d.t()
     tol = (score_dev - score_ref).abs().max().item()
-    assert tol < 2e-2, tol
-    n_a, n_i = score_ref.shape
+    assert tol < 1e-2, tol
+    # This 12 x 6 random-init set is NOT discriminative (the whole score matrix spans ~0.1, adjacent candidates sit 1e-3 apart), so it pins the
+    # plumbing only: the hooks' recall must equal an argsort recall of the hooks' OWN scores exactly, and the scores must match the oracle's.
+    # Recall@K parity against the oracle is asserted on the trained 1000-pair set of tests/test_recall_gpu.py (+-0.5 pt, identical top-1
+    # on margin > 0.05, no flip allowance).
+    d_ab, d_ba, _ = mutual_retrieval(score_dev, score_dev.t().contiguous(), all_ids, img_ids, [1, 5, 10])
     for k in ("recall@1", "recall@5", "recall@10"):
-        # a rank can only move if two candidates are closer than 2 * tol: bound the number of queries that may flip
-        srt = torch.sort(score_ref, dim=1, descending=True).values
-        flips_ab = ((srt[:, :-1] - srt[:, 1:]) < 2 * tol).any(dim=1).float().sum().item()
-        srt_b = torch.sort(score_ref.t(), dim=1, descending=True).values
-        flips_ba = ((srt_b[:, :-1] - srt_b[:, 1:]) < 2 * tol).any(dim=1).float().sum().item()
-        assert abs(r_ab[k] - o_ab[k]) <= 100.0 * flips_ab / n_a + 1e-4, (k, r_ab[k], o_ab[k], flips_ab)
-        assert abs(r_ba[k] - o_ba[k]) <= 100.0 * flips_ba / n_i + 1e-4, (k, r_ba[k], o_ba[k], flips_ba)
+        assert abs(r_ab[k] - d_ab[k]) < 1e-4 and abs(r_ba[k] - d_ba[k]) < 1e-4, (k, r_ab[k], d_ab[k], r_ba[k], d_ba[k])
     assert r_ab["recall@10"] == 100.0 and r_ba["recall@10"] == 100.0       # 6 images: everything is in the top 10
 
 

@@ -433,6 +433,35 @@ def test_short_finetuning_run_moves_the_encoder_layer_and_the_eval_path_sees_it(
     assert (after - before).abs().max().item() > 1e-3           # the eval path repacked the trained layer's weights (parameter epoch)
 
 
+def test_eval_path_repacks_after_a_plain_torch_optimizer_step():
+    """configure_optimizers falls back to a torch optimizer for optim.name != "Adam"; that bumps the tensors' `_version`, not
+    ops.param_epoch.  The engine's packed bf16 operands must follow either: after one AdamW step on a fine-tuned layer the eval forward
+    equals the oracle run on the UPDATED weights (and differs from the pre-step forward)."""
+    model, ref, batch = _finetune_pair([2])
+    model = model.cuda().train()
+    batch = {k: v.cuda() for k, v in batch.items()}
+    with torch.no_grad():
+        model.eval()
+        before = model(batch)[0]["parallel_audio_feat"].float().cpu().clone()       # packs the operands
+        model.train()
+    enc_params = [p for p in model.audio_encoder.encoder.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(enc_params, lr=2e-2)
+    loss = model.training_step_end(model.training_step(batch, 0))["loss"]
+    loss.backward()
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        after = model(batch)[0]["parallel_audio_feat"].float().cpu()
+    assert (after - before).abs().max().item() > 1e-3, "the eval path still runs on the pre-step packed weights"
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    ref.encoder.load_state_dict({k[len("audio_encoder.encoder."):]: v for k, v in sd.items() if k.startswith("audio_encoder.encoder.")})
+    want = ref.eval()({k: v.cpu() for k, v in batch.items()})["parallel_audio_feat"]
+    from helpers import assert_rows_match
+    assert_rows_match(after, want, 0.99, "eval forward after a torch optimizer step")
+    stale = torch.nn.functional.cosine_similarity(before - want.mean(0, keepdim=True), want - want.mean(0, keepdim=True), dim=-1)
+    print("centred cosine of the STALE forward vs the updated oracle:", stale.tolist())
+
+
 def test_cascaded_branch_passes_the_frame_gradient_down_too(tmp_path):
     """C-base layout with a fine-tuned encoder layer: the cascaded head's backward (K keyword queries, BatchNorm with batch statistics, straight-through
     VQ, frozen text tower) also returns d loss / d frames (sc_cls_pool_dz), the encoder layer receives finite, non-zero gradients, and a few

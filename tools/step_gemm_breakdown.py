@@ -27,7 +27,7 @@ for _ in range(steps):
 torch.cuda.synchronize()
 prof, ops.PROFILE = ops.PROFILE, None
 agg = collections.OrderedDict()
-for e0, e1, fl, tag in prof:
+for e0, e1, fl, tag, *_ in prof:
     a = agg.setdefault(tag, [0, 0.0, 0.0])
     a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
 tot = sum(a[1] for a in agg.values())
