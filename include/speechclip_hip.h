@@ -372,6 +372,28 @@ int sc_axpy_bf16(void* y, const void* x, float alpha, int64_t n, void* stream);
 int sc_cls_pool_dz(const float* pp, const float* ds, const float* dzbar, const float* u, const int32_t* lens, void* dz, int B, int T, int NQ, int R,
                    int D, int64_t ld_dz, void* stream);
 
+
+/* ---- Padding-free (packed) batches.  The reference pads every utterance of a batch to the longest one (collate_function.py:18-30,
+ * speech_encoder_plus.py:506-518, :540-556) and runs the conv stack and all transformer GEMMs on B x T_max rows; only rows below each
+ * utterance's own length ever reach an output (padding mask, speech_encoder_plus.py:604-611).  Here utterance b owns rows
+ * [row_off[b], row_off[b + 1]) of every transformer-level tensor (row_off: B + 1 device ints, row_off[0] = 0) and row_scale times that range at
+ * conv layer 0, so all GEMMs run on sum_b rows_b rows.  The GEMM entries need no change (rows are rows); these are the per-utterance kernels:
+ *   sc_conv0_fwd_packed      sc_conv0_fwd writing utterance b at rows row_scale * row_off[b] ..; `coef` = sc_conv0_gn_coef over the PADDED length
+ *                            (zero samples add nothing to the GroupNorm sums, the divisor stays T0: the reference's statistics exactly)
+ *   sc_posconv_conv_packed / sc_posconv_finish_packed   conv slab of utterance b = [G][rows_b][D/G] at element row_off[b] * D
+ *   sc_attention_fwd_packed  fairseq MHA with key-padding mask over packed q|k|v rows (drop_p > 0: the train-mode form)
+ *   sc_unpack_rows           packed -> the reference's padded [n_layers][B][T_out][row] layout (zeros beyond an utterance's rows) */
+int sc_conv0_fwd_packed(const float* wav, int64_t ld, int64_t L, const float* w, const float* bias, const float* coef, void* out, int B,
+                        int C, int T0, const int32_t* row_off, int row_scale, int Pmax, int mode, void* wfrag_ws, void* stream);
+int sc_posconv_conv_packed(const void* x, const int32_t* valid, const int32_t* row_off, const void* wg, void* conv, int B, int Tmax, int D, int G,
+                           int Kw, void* stream);
+int sc_posconv_finish_packed(const void* x, const int32_t* valid, const int32_t* row_off, const void* conv, const float* bias, const float* gamma,
+                             const float* beta, void* out, int B, int64_t total_rows, int D, int G, int out_f32, float eps, void* stream);
+int sc_attention_fwd_packed(const void* q, const void* k, const void* v, void* out, const int32_t* klens, const int32_t* row_off, int B, int H,
+                            int Tmax, int64_t total_rows, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, float drop_p, uint32_t seed,
+                            void* stream);
+int sc_unpack_rows(const void* src, int64_t src_layer_stride_bytes, const int32_t* row_off, void* out, int64_t out_layer_stride_bytes, int n_layers,
+                   int B, int T_out, int row_bytes, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,11 @@ def _declare(L):
         "sc_posconv_pack": ([P, P, P, I, I, I, I, I, P], c_int),
         "sc_posconv_finish": ([P, P, P, P, P, P, P, I, I, I, I, I, F, P], c_int),
         "sc_crop_pad": ([P, L64, P, P, P, I, I, P], c_int),
+        "sc_conv0_fwd_packed": ([P, L64, L64, P, P, P, P, I, I, I, P, I, I, I, P, P], c_int),
+        "sc_posconv_conv_packed": ([P, P, P, P, P, I, I, I, I, I, P], c_int),
+        "sc_posconv_finish_packed": ([P, P, P, P, P, P, P, P, I, L64, I, I, I, F, P], c_int),
+        "sc_attention_fwd_packed": ([P, P, P, P, P, P, I, I, I, L64, I, L64, L64, F, F, U32, P], c_int),
+        "sc_unpack_rows": ([P, L64, P, P, L64, I, I, I, I, P], c_int),
         "sc_image_normalize_u8": ([P, P, I, I, I, P, P, P], c_int),
         "sc_vit_patchify": ([P, P, I, I, I, I, P], c_int),
         "sc_vit_embed": ([P, P, P, P, P, P, I, I, I, F, P], c_int),

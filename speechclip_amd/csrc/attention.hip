@@ -51,9 +51,10 @@ template <int NW, bool TRACE, bool DROP = false, int QB = 1>   // QB: 32-row que
    // DROP: attention-probability dropout (train-mode frozen encoder, sc_attention_fwd_dropout); waves per block: NW x 32 query rows share one K/V ring (4: 128 rows, 8: 256 rows -- half the K/V traffic, 4 waves per SIMD)
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1 ? 4 : 2))) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
-                                                       const int32_t* __restrict__ klens, int T, int64_t ld_qkv,
+                                                       const int32_t* __restrict__ klens, int T_uniform, int64_t ld_qkv,
                                                        int64_t ld_out, float scale_log2e, int causal, int B, int H, int nq, int n_ids, int ipb,
-                                                       uint32_t drop_seed, uint32_t drop_thresh_, float drop_keep_scale) {
+                                                       uint32_t drop_seed, uint32_t drop_thresh_, float drop_keep_scale,
+                                                       const int32_t* __restrict__ row_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NSTAGE x (K 8 KiB + V 8 KiB)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -78,7 +79,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
     int lane_i = lane;
     asm volatile("" : "+v"(lane_i));        // per-id recomputation of the lane geometry: keeps the id loop's invariants out of VGPRs held across it
     const int g = lane_i >> 5, ql = lane_i & 31;
-    const int64_t row_base = (int64_t)b * T;
+    // packed (padding-free) batches: utterance b owns rows [row_off[b], row_off[b + 1]) of q / k / v / out; T = its own row count
+    // (wave-uniform scalar loads).  row_off == nullptr: the uniform layout, T rows per utterance.
+    const int T = row_off ? row_off[b + 1] - row_off[b] : T_uniform;
+    const int64_t row_base = row_off ? (int64_t)row_off[b] : (int64_t)b * T;
+    if (qblk * ROWS >= T) continue;
     const int hoff = h * 64;
 
     int klen = klens ? klens[b] : T;
@@ -91,12 +96,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
 
     int qrow[QB], qrow_c[QB];
     uint32_t drop_row[QB];
-    const uint32_t drop_pairs = (uint32_t)((T + 1) >> 1);
+    const uint32_t drop_pairs = (uint32_t)(((row_off ? T_uniform : T) + 1) >> 1);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         qrow[qb] = qblk * ROWS + wave * (32 * QB) + qb * 32 + ql;
         qrow_c[qb] = qrow[qb] < T ? qrow[qb] : T - 1;
-        drop_row[qb] = DROP ? (uint32_t)((b * H + h) * T + qrow_c[qb]) : 0u;
+        drop_row[qb] = DROP ? (row_off ? (uint32_t)((row_base + qrow_c[qb]) * H + h) : (uint32_t)((b * H + h) * T + qrow_c[qb])) : 0u;
     }
 
     // Q fragments: B operand of S^T (col = query, k-slots = 8 dims)
@@ -603,12 +608,14 @@ extern "C" void sc_debug_set_attn_trace(void* dev_buf) {     // per-block [8] u6
 }
 
 static int attention_fwd_impl(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H, int T, int head_dim,
-                              int64_t ld_qkv, int64_t ld_out, float scale, int causal, float drop_p, uint32_t seed, void* stream) {
+                              int64_t ld_qkv, int64_t ld_out, float scale, int causal, float drop_p, uint32_t seed, void* stream,
+                              const int32_t* row_off = nullptr, int64_t total_rows = 0) {
     SC_CHECK_ARG(head_dim == 64, "sc_attention_fwd: head_dim=%d unsupported (64 only; use sc_cls_attention_fwd for pooling heads)", head_dim);
     SC_CHECK_ARG(ld_qkv % 8 == 0 && ld_out % 8 == 0, "sc_attention_fwd: ld_qkv and ld_out must be multiples of 8 (16-byte rows)");
     SC_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "sc_attention_fwd: misaligned pointers");
     SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_attention_fwd_dropout: drop_p=%f must be in [0, 1)", (double)drop_p);
-    SC_CHECK_ARG(drop_p == 0.f || (int64_t)B * H * T * T < 0xffffffffLL, "sc_attention_fwd_dropout: B*H*T*T must fit 32 bits (mask element index)");
+    SC_CHECK_ARG(drop_p == 0.f || (row_off ? total_rows * H * ((T + 1) / 2) : (int64_t)B * H * T * T) < 0xffffffffLL,
+                 "sc_attention_fwd_dropout: B*H*T*T must fit 32 bits (mask element index)");
     if (B <= 0 || T <= 0) return 0;
     // 8-wave blocks (256 query rows share the K/V ring) when there are at least 256 queries; SC_ATTN_NW=4 forces the 4-wave form
     static const int force_nw = getenv("SC_ATTN_NW") ? atoi(getenv("SC_ATTN_NW")) : 0;
@@ -634,7 +641,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NW_, TR_, DR_, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);            \
         hipLaunchKernelGGL((attn_fwd_kernel<NW_, TR_, DR_, ##__VA_ARGS__>), grid, dim3(NW_ * 64), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, \
                            (const bf16_t*)v, (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq, n_ids, ipb, \
-                           seed, th, ks);                                                                                                   \
+                           seed, th, ks, row_off);                                                                                          \
     } while (0)
     if (qb2) { if (nw == 8) ATTN_LAUNCH(8, false, false, 2); else ATTN_LAUNCH(4, false, false, 2); }
     else if (th) { if (nw == 8) ATTN_LAUNCH(8, false, true); else ATTN_LAUNCH(4, false, true); }
@@ -656,6 +663,15 @@ extern "C" int sc_attention_fwd(const void* q, const void* k, const void* v, voi
 extern "C" int sc_attention_fwd_dropout(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H, int T, int head_dim,
                                         int64_t ld_qkv, int64_t ld_out, float scale, int causal, float drop_p, uint32_t seed, void* stream) {
     return attention_fwd_impl(q, k, v, out, klens, B, H, T, head_dim, ld_qkv, ld_out, scale, causal, drop_p, seed, stream);
+}
+
+// Packed (padding-free) batches: utterance b owns rows [row_off[b], row_off[b + 1]) of q / k / v / out (row_off: B + 1 device ints,
+// rows per utterance <= Tmax); klens[b] <= its row count.  drop_p > 0: the train-mode form.
+extern "C" int sc_attention_fwd_packed(const void* q, const void* k, const void* v, void* out, const int32_t* klens, const int32_t* row_off, int B, int H,
+                                       int Tmax, int64_t total_rows, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, float drop_p, uint32_t seed,
+                                       void* stream) {
+    SC_CHECK_ARG(row_off != nullptr && klens != nullptr, "sc_attention_fwd_packed: row_off and klens are required");
+    return attention_fwd_impl(q, k, v, out, klens, B, H, Tmax, head_dim, ld_qkv, ld_out, scale, 0, drop_p, seed, stream, row_off, total_rows);
 }
 
 extern "C" int sc_cls_attention_fwd(const void* cls_qkv, const void* kv_x, int64_t ld_kv, const int32_t* lens, void* out, int B, int T,

@@ -164,12 +164,17 @@ __global__ __launch_bounds__(256) void conv0_wfrag_kernel(const float* __restric
 template <int FB>   // frames per block
 __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict__ wav, int64_t ld, int64_t L, const bf16x8_t* __restrict__ wfrag,
                                                          const float* __restrict__ bias, const float2* __restrict__ coef, bf16_t* __restrict__ out,
-                                                         int C, int T0, int P, int mode) {
+                                                         int C, int T0, int P_uniform, int mode, const int32_t* __restrict__ row_off, int row_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_c0[];
     bf16x8_t* wl = (bf16x8_t*)smem_c0;                    // [32][64] W fragments (32 KiB)
     float* shs = (float*)(smem_c0 + 32 * 64 * 16);        // [512] per-channel shift (GroupNorm shift or conv bias)
     float* xs = shs + 512;                                // FB * 5 + 8 samples
     const int b = blockIdx.y, t0 = blockIdx.x * FB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // packed batches: utterance b owns output rows [row_scale * row_off[b], row_scale * row_off[b + 1]) (row_off counts transformer frames,
+    // row_scale = the conv stack's total stride after layer 0); frames >= T0 are written as zeros as in the uniform layout
+    const int P = row_off ? row_scale * (row_off[b + 1] - row_off[b]) : P_uniform;
+    const int64_t orow0 = row_off ? (int64_t)row_scale * row_off[b] : (int64_t)b * P;
+    if (t0 >= P) return;
     const float* x = wav + (int64_t)b * ld;
     const int nfr = min(FB, P - t0);
     for (int i = tid; i < nfr * CS + CK; i += 256) {
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
             xf[sidx] = kind == 1 ? (__bf16)(xv - (float)hi) : hi;
         }
         const bool live_row = (tg + srow) < T0;           // frames in [T0, P) are written as zeros
-        bf16_t* orow = out + ((int64_t)b * P + tg + srow) * C + schunk * 8;
+        bf16_t* orow = out + (orow0 + tg + srow) * C + schunk * 8;
         f32x4_t acc[2][4];                                // two 64-channel chunks in flight: MFMAs of chunk q+1 issue before the epilogue of q
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j * 64 + lane], xf, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -267,11 +272,18 @@ __global__ __launch_bounds__(256) void posconv_pack_kernel(const bf16_t* __restr
 template <bool OUT_F32>
 __global__ __launch_bounds__(256) void posconv_finish_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ valid, const bf16_t* __restrict__ conv,
                                                              const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             void* __restrict__ out, int B, int Tp, int D, int G, float eps) {
+                                                             void* __restrict__ out, int B, int Tp, int D, int G, float eps,
+                                                             const int32_t* __restrict__ row_off, int64_t total_rows) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= (int64_t)B * Tp) return;
-    const int b = (int)(row / Tp), t = (int)(row - (int64_t)b * Tp);
+    if (row >= total_rows) return;
+    int b, t;
+    int64_t conv_row0;          // first conv element row of (utterance b, group 0): conv slab of utterance b = [G][rows_b][cg]
+    if (row_off) {              // packed batch: binary search of the owning utterance (row_off[b] <= row < row_off[b + 1])
+        int lo = 0, hi = B;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)row_off[mid] <= row) lo = mid; else hi = mid; }
+        b = lo; t = (int)(row - row_off[b]); Tp = row_off[b + 1] - row_off[b]; conv_row0 = (int64_t)row_off[b] * G;
+    } else { b = (int)(row / Tp); t = (int)(row - (int64_t)b * Tp); conv_row0 = (int64_t)b * G * Tp; }
     const int cg = D / G;
     const bool live = t < valid[b];
     float v[4][4];
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(256) void posconv_finish_kernel(const bf16_t* __res
         v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
         if (e < D) {
             const int g = e / cg, ci = e - g * cg;  // cg % 4 == 0 so the 4 elements stay in one group
-            const uint2 cv = *(const uint2*)(conv + (((int64_t)b * G + g) * Tp + t) * cg + ci);
+            const uint2 cv = *(const uint2*)(conv + (conv_row0 + (int64_t)g * Tp + t) * cg + ci);
             float xv[4] = {0.f, 0.f, 0.f, 0.f};
             if (live) {
                 const uint2 xx = *(const uint2*)(x + row * D + e);
@@ -399,13 +411,14 @@ extern "C" int sc_conv0_gn_coef(const float* wav, int64_t ld, const float* w, co
 
 extern "C" int64_t sc_conv0_wfrag_workspace_bytes(int B) { return (int64_t)B * 32 * 64 * 16; }
 
-extern "C" int sc_conv0_fwd(const float* wav, int64_t ld, int64_t L, const float* w, const float* bias, const float* coef, void* out, int B,
-                            int C, int T0, int P, int mode, void* wfrag_ws, void* stream) {
+static int conv0_fwd_impl(const float* wav, int64_t ld, int64_t L, const float* w, const float* bias, const float* coef, void* out, int B,
+                          int C, int T0, int P, int mode, void* wfrag_ws, void* stream, const int32_t* row_off, int row_scale) {
     SC_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= 512, "sc_conv0_fwd: C=%d must be a multiple of 8, <= 512", C);
+    SC_CHECK_ARG(row_off == nullptr || (C % 64 == 0 && P % 64 == 0 && row_scale % 64 == 0), "sc_conv0_fwd_packed: needs C %% 64 == 0 and row_scale %% 64 == 0");
     SC_CHECK_ARG(mode == 1 || coef != nullptr, "sc_conv0_fwd: GroupNorm mode needs coef");
-    SC_CHECK_ARG(P >= T0 && B > 0 && B <= 65535, "sc_conv0_fwd: need P >= T0 and 0 < B <= 65535");
+    SC_CHECK_ARG((P >= T0 || row_off) && B > 0 && B <= 65535, "sc_conv0_fwd: need P >= T0 and 0 < B <= 65535");
     static const bool force_valu = getenv("SC_CONV0_VALU") != nullptr;
-    if (C % 64 == 0 && P % 64 == 0 && !force_valu) {      // matrix-core form (every shipped config: C = 512)
+    if (C % 64 == 0 && P % 64 == 0 && (!force_valu || row_off)) {      // matrix-core form (every shipped config: C = 512)
         SC_CHECK_ARG(wfrag_ws != nullptr, "sc_conv0_fwd: the matrix-core form needs the W-fragment workspace (sc_conv0_wfrag_workspace_bytes)");
         hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, w, (const float2*)coef, (bf16x8_t*)wfrag_ws, C, mode);
         SC_CHECK_LAUNCH();
@@ -414,7 +427,7 @@ extern "C" int sc_conv0_fwd(const float* wav, int64_t ld, int64_t L, const float
         const int lds = 32 * 64 * 16 + (512 + FB_ * CS + 16) * 4;                                                                                  \
         (void)hipFuncSetAttribute((const void*)conv0_mfma_kernel<FB_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                           \
         hipLaunchKernelGGL(conv0_mfma_kernel<FB_>, dim3((P + FB_ - 1) / FB_, B), dim3(256), lds, (hipStream_t)stream, wav, ld, L,                  \
-                           (const bf16x8_t*)wfrag_ws, bias, (const float2*)coef, (bf16_t*)out, C, T0, P, mode); } while (0)
+                           (const bf16x8_t*)wfrag_ws, bias, (const float2*)coef, (bf16_t*)out, C, T0, P, mode, row_off, row_scale); } while (0)
         if (fb == 128) CONV0_LAUNCH(128); else if (fb == 512) CONV0_LAUNCH(512); else if (fb == 1024) CONV0_LAUNCH(1024); else CONV0_LAUNCH(256);
 #undef CONV0_LAUNCH
     } else {
@@ -423,6 +436,20 @@ extern "C" int sc_conv0_fwd(const float* wav, int64_t ld, int64_t L, const float
     }
     SC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sc_conv0_fwd(const float* wav, int64_t ld, int64_t L, const float* w, const float* bias, const float* coef, void* out, int B,
+                            int C, int T0, int P, int mode, void* wfrag_ws, void* stream) {
+    return conv0_fwd_impl(wav, ld, L, w, bias, coef, out, B, C, T0, P, mode, wfrag_ws, stream, nullptr, 0);
+}
+
+// Packed (padding-free) batches: utterance b writes rows [row_scale * row_off[b], row_scale * row_off[b + 1]) of `out` (row_off: B + 1 device
+// ints in transformer frames; row_scale = product of the strides of conv layers 1.., 64 for HuBERT; Pmax = row_scale * max rows per utterance).
+// The GroupNorm statistics (`coef`) are those of the PADDED length T0: zero samples contribute nothing to sum / sum of squares, the divisor stays T0.
+extern "C" int sc_conv0_fwd_packed(const float* wav, int64_t ld, int64_t L, const float* w, const float* bias, const float* coef, void* out, int B,
+                                   int C, int T0, const int32_t* row_off, int row_scale, int Pmax, int mode, void* wfrag_ws, void* stream) {
+    SC_CHECK_ARG(row_off != nullptr && row_scale > 0 && Pmax > 0, "sc_conv0_fwd_packed: row_off, row_scale and Pmax are required");
+    return conv0_fwd_impl(wav, ld, L, w, bias, coef, out, B, C, T0, Pmax, mode, wfrag_ws, stream, row_off, row_scale);
 }
 
 extern "C" int sc_posconv_pack(const void* x, const int32_t* valid, void* xg, int B, int Tp, int D, int G, int Kw, void* stream) {
@@ -434,15 +461,26 @@ extern "C" int sc_posconv_pack(const void* x, const int32_t* valid, void* xg, in
     return 0;
 }
 
-extern "C" int sc_posconv_finish(const void* x, const int32_t* valid, const void* conv, const float* bias, const float* gamma, const float* beta,
-                                 void* out, int B, int Tp, int D, int G, int out_f32, float eps, void* stream) {
+static int posconv_finish_impl(const void* x, const int32_t* valid, const void* conv, const float* bias, const float* gamma, const float* beta,
+                               void* out, int B, int Tp, int D, int G, int out_f32, float eps, void* stream, const int32_t* row_off, int64_t rows) {
     SC_CHECK_ARG(D <= 1024 && D % G == 0 && (D / G) % 4 == 0, "sc_posconv_finish: D<=1024 and D/G multiple of 4 required");
-    const int64_t rows = (int64_t)B * Tp;
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (out_f32) hipLaunchKernelGGL((posconv_finish_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, valid, (const bf16_t*)conv, bias, gamma, beta, out, B, Tp, D, G, eps);
-    else hipLaunchKernelGGL((posconv_finish_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, valid, (const bf16_t*)conv, bias, gamma, beta, out, B, Tp, D, G, eps);
+    if (out_f32) hipLaunchKernelGGL((posconv_finish_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, valid, (const bf16_t*)conv, bias, gamma, beta, out, B, Tp, D, G, eps, row_off, rows);
+    else hipLaunchKernelGGL((posconv_finish_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, valid, (const bf16_t*)conv, bias, gamma, beta, out, B, Tp, D, G, eps, row_off, rows);
     SC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sc_posconv_finish(const void* x, const int32_t* valid, const void* conv, const float* bias, const float* gamma, const float* beta,
+                                 void* out, int B, int Tp, int D, int G, int out_f32, float eps, void* stream) {
+    return posconv_finish_impl(x, valid, conv, bias, gamma, beta, out, B, Tp, D, G, out_f32, eps, stream, nullptr, (int64_t)B * Tp);
+}
+
+// Packed batches (see sc_posconv_conv_packed): rows [row_off[b], row_off[b + 1]) belong to utterance b, total_rows = row_off[B].
+extern "C" int sc_posconv_finish_packed(const void* x, const int32_t* valid, const int32_t* row_off, const void* conv, const float* bias, const float* gamma,
+                                        const float* beta, void* out, int B, int64_t total_rows, int D, int G, int out_f32, float eps, void* stream) {
+    SC_CHECK_ARG(row_off != nullptr && valid != nullptr && total_rows > 0, "sc_posconv_finish_packed: row_off, valid and total_rows are required");
+    return posconv_finish_impl(x, valid, conv, bias, gamma, beta, out, B, 0, D, G, out_f32, eps, stream, row_off, total_rows);
 }
 
 extern "C" int sc_vit_patchify(const float* img, void* cols, int B, int R, int p, int Kpad, void* stream) {

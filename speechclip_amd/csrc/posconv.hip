@@ -21,7 +21,8 @@ constexpr int PC_NSTG = 3;
 
 template <int NJ, int NW>   // cg = 16 NJ channels per group, MB = 64 NW frames per block
 __global__ __launch_bounds__(NW * 64) void posconv_mfma_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ valid, const bf16_t* __restrict__ wg,
-                                                               bf16_t* __restrict__ conv, int Tp, int D, int G, int Kw) {
+                                                               bf16_t* __restrict__ conv, int Tp_uniform, int D, int G, int Kw,
+                                                               const int32_t* __restrict__ row_off) {
     constexpr int CG = 16 * NJ, MB = 64 * NW, NT = NW * 64;
     constexpr int STG = CG * 128;                              // one W stage: [CG rows][64 k] bf16
     constexpr int NCHUNK = CG * 8;                             // 16-byte chunks per W stage
@@ -30,6 +31,10 @@ __global__ __launch_bounds__(NW * 64) void posconv_mfma_kernel(const bf16_t* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, g = blockIdx.y, t_start = blockIdx.x * MB;
+    // packed batches: utterance b owns rows [row_off[b], row_off[b + 1]) of x; its conv slab is [G][Tp][cg] at element row_off[b] * D
+    const int Tp = row_off ? row_off[b + 1] - row_off[b] : Tp_uniform;
+    const int64_t row0 = row_off ? (int64_t)row_off[b] : (int64_t)b * Tp;
+    if (t_start >= Tp) return;
     const int K = Kw * CG, nk = K / 64;
     const int win_bytes = ((MB + Kw) * CG * 2 + 15) & ~15;
     char* ring = smem_pc + win_bytes;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(NW * 64) void posconv_mfma_kernel(const bf16_t* __r
             const int r = idx / CPR, cc = idx - r * CPR;
             const int t_in = t_start - Kw / 2 + r;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (t_in >= 0 && t_in < vlen) v = *(const uint4*)(x + ((int64_t)b * Tp + t_in) * D + g * CG + cc * 8);
+            if (t_in >= 0 && t_in < vlen) v = *(const uint4*)(x + (row0 + t_in) * D + g * CG + cc * 8);
             *(uint4*)(smem_pc + ((int64_t)r * CG + cc * 8) * 2) = v;
         }
     }
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(NW * 64) void posconv_mfma_kernel(const bf16_t* __r
     for (int i = 0; i < 4; ++i) {
         const int t = t_start + wave * 64 + i * 16 + frow;
         if (t >= Tp) continue;
-        bf16_t* orow = conv + (((int64_t)b * G + g) * Tp + t) * CG + fk * 4;
+        bf16_t* orow = conv + (row0 * G + (int64_t)g * Tp + t) * CG + fk * 4;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             uint2 o;
@@ -116,13 +121,13 @@ __global__ __launch_bounds__(NW * 64) void posconv_mfma_kernel(const bf16_t* __r
 }
 
 template <int NJ, int NW>
-int posconv_launch(const void* x, const int32_t* valid, const void* wg, void* conv, int B, int Tp, int D, int G, int Kw, hipStream_t s) {
+int posconv_launch(const void* x, const int32_t* valid, const void* wg, void* conv, int B, int Tp, int D, int G, int Kw, hipStream_t s, const int32_t* row_off) {
     constexpr int CG = 16 * NJ, MB = 64 * NW;
     const int lds = (((MB + Kw) * CG * 2 + 15) & ~15) + PC_NSTG * CG * 128;
     SC_CHECK_ARG(lds <= 160 * 1024, "sc_posconv_conv: Kw=%d too large for LDS", Kw);
     (void)hipFuncSetAttribute((const void*)posconv_mfma_kernel<NJ, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL((posconv_mfma_kernel<NJ, NW>), dim3((Tp + MB - 1) / MB, G, B), dim3(NW * 64), lds, s, (const bf16_t*)x, valid, (const bf16_t*)wg,
-                       (bf16_t*)conv, Tp, D, G, Kw);
+                       (bf16_t*)conv, Tp, D, G, Kw, row_off);
     SC_CHECK_LAUNCH();
     return 0;
 }
@@ -131,7 +136,8 @@ int posconv_launch(const void* x, const int32_t* valid, const void* wg, void* co
 
 // conv bf16 [B][G][Tp][cg] = grouped conv of x bf16 [B*Tp, D] (frames >= valid[b] read as zero) with wg bf16 [G][cg][Kw*cg]
 // (K index = tap*cg + c_in).  Returns 1 (and does nothing) when the shape is not covered (caller falls back to pack + batched GEMM).
-extern "C" int sc_posconv_conv(const void* x, const int32_t* valid, const void* wg, void* conv, int B, int Tp, int D, int G, int Kw, void* stream) {
+static int posconv_conv_impl(const void* x, const int32_t* valid, const void* wg, void* conv, int B, int Tp, int D, int G, int Kw, void* stream,
+                             const int32_t* row_off) {
     SC_CHECK_ARG(B > 0 && Tp > 0 && G > 0 && D % G == 0, "sc_posconv_conv: bad shape");
     const int cg = D / G;
     if (cg % 16 != 0 || cg > 64 || cg < 32 || (Kw * cg) % 64 != 0 || D % 8 != 0 || B > 65535 || G > 65535) return 1;
@@ -140,9 +146,21 @@ extern "C" int sc_posconv_conv(const void* x, const int32_t* valid, const void* 
     const int waste8 = (Tp + 511) / 512 * 512 - Tp, waste4 = (Tp + 255) / 256 * 256 - Tp;
     const int nw = force_nw ? force_nw : (waste8 <= waste4 + Tp / 8 ? 8 : 4);
     hipStream_t s = (hipStream_t)stream;
-#define PC_CASE(NJ_) (nw == 8 ? posconv_launch<NJ_, 8>(x, valid, wg, conv, B, Tp, D, G, Kw, s) : posconv_launch<NJ_, 4>(x, valid, wg, conv, B, Tp, D, G, Kw, s))
+#define PC_CASE(NJ_) (nw == 8 ? posconv_launch<NJ_, 8>(x, valid, wg, conv, B, Tp, D, G, Kw, s, row_off) : posconv_launch<NJ_, 4>(x, valid, wg, conv, B, Tp, D, G, Kw, s, row_off))
     if (cg == 32) return PC_CASE(2);
     if (cg == 48) return PC_CASE(3);
     return PC_CASE(4);
 #undef PC_CASE
+}
+
+extern "C" int sc_posconv_conv(const void* x, const int32_t* valid, const void* wg, void* conv, int B, int Tp, int D, int G, int Kw, void* stream) {
+    return posconv_conv_impl(x, valid, wg, conv, B, Tp, D, G, Kw, stream, nullptr);
+}
+
+// Packed (padding-free) batches: utterance b owns rows [row_off[b], row_off[b + 1]) of x (<= Tmax rows each); conv slab of utterance b =
+// [G][rows_b][cg] at element row_off[b] * D.  Same return convention as sc_posconv_conv.
+extern "C" int sc_posconv_conv_packed(const void* x, const int32_t* valid, const int32_t* row_off, const void* wg, void* conv, int B, int Tmax, int D, int G,
+                                      int Kw, void* stream) {
+    SC_CHECK_ARG(row_off != nullptr && valid != nullptr, "sc_posconv_conv_packed: row_off and valid are required");
+    return posconv_conv_impl(x, valid, wg, conv, B, Tmax, D, G, Kw, stream, row_off);
 }

@@ -427,6 +427,36 @@ extern "C" int sc_weighted_sum_fwd(const void* hidden, int64_t layer_stride, con
     return 0;
 }
 
+// Packed -> padded row layout (the API boundary of the padding-free engine): out[l][b][t][:] = t < rows_b ? src[l][row_off[b] + t][:] : 0,
+// rows of `row_bytes` bytes (a multiple of 16), rows_b = row_off[b + 1] - row_off[b].  One wave per output row.
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const char* __restrict__ src, int64_t src_layer_stride, const int32_t* __restrict__ row_off,
+                                                          char* __restrict__ out, int64_t out_layer_stride, int B, int T_out, int row_bytes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (int64_t)B * T_out) return;
+    const int b = (int)(r / T_out), t = (int)(r - (int64_t)b * T_out);
+    const int l = blockIdx.y;
+    const int rows_b = row_off[b + 1] - row_off[b];
+    const char* s = src + l * src_layer_stride + ((int64_t)row_off[b] + t) * row_bytes;
+    char* o = out + l * out_layer_stride + r * row_bytes;
+    for (int c = lane * 16; c < row_bytes; c += 64 * 16) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t < rows_b) v = *(const uint4*)(s + c);
+        *(uint4*)(o + c) = v;
+    }
+}
+
+extern "C" int sc_unpack_rows(const void* src, int64_t src_layer_stride_bytes, const int32_t* row_off, void* out, int64_t out_layer_stride_bytes, int n_layers,
+                              int B, int T_out, int row_bytes, void* stream) {
+    SC_CHECK_ARG(src && row_off && out && n_layers >= 1 && n_layers <= 65535 && row_bytes > 0 && row_bytes % 16 == 0, "sc_unpack_rows: bad arguments (row_bytes must be a multiple of 16)");
+    if (B <= 0 || T_out <= 0) return 0;
+    const int64_t rows = (int64_t)B * T_out;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((rows + 3) / 4), n_layers), dim3(256), 0, (hipStream_t)stream, (const char*)src, src_layer_stride_bytes,
+                       row_off, (char*)out, out_layer_stride_bytes, B, T_out, row_bytes);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sc_weighted_sum_ln_fwd(const void* h0, const void* ypre, int64_t layer_stride, const float* gamma, const float* beta, const float* weights,
                                       void* out, int n_layers, int64_t rows, int D, float eps, void* stream) {
     SC_CHECK_ARG(D > 0 && D <= 1024 && D % 4 == 0, "sc_weighted_sum_ln: D=%d must be a multiple of 4, <= 1024", D);

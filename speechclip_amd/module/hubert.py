@@ -235,7 +235,22 @@ class HubertModel(nn.Module):
         P["ln2_gamma"] = torch.stack([L["ln2"][0] for L in P["layers"]]).contiguous()
         P["ln2_beta"] = torch.stack([L["ln2"][1] for L in P["layers"]]).contiguous()
 
-    def _buf(self, name, shape, dtype, dev, zero=False):
+    def _buf(self, name, shape, dtype, dev, zero=False, cap=False):
+        """Workspace tensors, reused across steps.  cap=False: keyed by the exact shape (fixed-shape batches).  cap=True (packed batches, whose
+        row count changes every step): ONE flat allocation per (name, dtype) that only grows (in 1/8 steps, zero-filled so rows nobody wrote
+        stay finite), viewed at the requested shape."""
+        if cap:
+            key = (name, "cap", dtype)
+            need = 1
+            for v in shape:
+                need *= int(v)
+            t = self._ws.get(key)
+            if t is None or t.device != dev or t.numel() < need:
+                self._ws.pop(key, None)
+                t = None                                          # free the old block before growing
+                t = torch.zeros(need + need // 8, device=dev, dtype=dtype)
+                self._ws[key] = t
+            return t[:need].view(*shape)
         key = (name, tuple(shape), dtype)
         t = self._ws.get(key)
         if t is None or t.device != dev:
@@ -261,6 +276,25 @@ class HubertModel(nn.Module):
         chunk = (lmax - lmax % T) // T
         return [min(T, -(-int(l) // chunk)) for l in lens]
 
+    def packed_geometry(self, lens: Sequence[int], lmax: int, need_rows: Sequence[int] = None):
+        """Row allotment of the padding-free engine.  The reference pads every utterance to the batch maximum and runs the conv stack and the
+        transformer GEMMs on B x T rows (speech_encoder_plus.py:506-518, :540-556); only frames below each utterance's own length reach an
+        output.  Here utterance b gets r_b = max(valid_b, need_b) + 1 transformer rows (valid_b: fairseq's padding-mask rule; need_b: rows the
+        caller will read, e.g. round(len / 320)) and 2^(6-l) r_b rows at conv layer l, laid back to back: row offsets double per level
+        (o_l = 2 o_{l+1}), so every stride-2 conv layer is still ONE overlapping-row GEMM over the whole batch.  The extra row covers the
+        receptive-field halo: output frame F - 1 needs 64 F + 15 layer-0 frames <= 64 (F + 1); they are computed from the zero-padded wave
+        exactly as the padded layout computes them (GroupNorm statistics stay those of the padded length: sc_conv0_gn_coef over all T0
+        frames, zero samples adding nothing)."""
+        T0, T, P0, Tp = self.frame_geometry(lmax)
+        valid = self.valid_frames(lens, lmax, T)
+        need = [0] * len(lens) if need_rows is None else [min(int(n), T) for n in need_rows]
+        rows = [max(v, n) + 1 for v, n in zip(valid, need)]
+        off = [0]
+        for r in rows:
+            off.append(off[-1] + r)
+        ds = P0 // Tp
+        return dict(rows=rows, row_off=off, total=off[-1], rows_max=max(rows), valid=valid, scale0=ds, T0=T0, T=T, padded_rows=len(lens) * Tp)
+
     # ------------------------------------------------------------------ forward
     def fold_ln_supported(self, B: int, lmax: int) -> bool:
         """The folded-LayerNorm eval path (no separate LayerNorm pass, hidden states kept PRE-norm) exists for post-LN models whose rows
@@ -280,7 +314,7 @@ class HubertModel(nn.Module):
 
     @torch.no_grad()
     def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int], fold_ln: bool = False, stop_layer: int = None, drop_layers=(),
-                           dropout_seed: int = None):
+                           dropout_seed: int = None, pack: dict = None):
         """wav: f32 [B, Lmax] device tensor (right zero-padded); lens: host ints.
         Returns (hidden [n_layers+1, B, Tp, d] (bf16 for post-LN, f32 for pre-LN), T, Tp, valid_frames); with `stop_layer` = L only
         hidden[0..L] are computed.  `drop_layers` (layerdrop, speech_encoder_plus.py:49-53): the listed layers are skipped and leave NO entry
@@ -289,9 +323,14 @@ class HubertModel(nn.Module):
         features, `dropout` after the positional conv + LayerNorm and after out_proj / fc2 (before the residual add), attention_dropout on the
         probabilities, activation_dropout after the GELU; masks are counter-based, one stream per site derived from the seed.
         fold_ln (caller checked fold_ln_supported): returns ((h0 [M,d], ypre [n_layers, M, d], gamma2, beta2), T, Tp, valid) instead -- layer 0's
-        normalised state and the PRE-LayerNorm outputs of the layers with the affines of their final LayerNorms (ops.weighted_sum_ln mixes them)."""
+        normalised state and the PRE-LayerNorm outputs of the layers with the affines of their final LayerNorms (ops.weighted_sum_ln mixes them).
+        pack (packed_geometry): the padding-free layout -- every tensor has pack["total"] rows, utterance b at rows pack["row_off"][b] ...;
+        returns (hidden [n, total, d], T, None, valid); ops.unpack_rows restores the padded [B, T, d] view where a caller needs it."""
         cfg = self.cfg
         dev = wav.device
+
+        def buf(name, shape, dtype, dev_, zero=False):
+            return self._buf(name, shape, dtype, dev_, zero=zero, cap=pack is not None)
         # packed bf16 operands are rebuilt when a load replaced the weights (post-hook) or an optimizer step moved TRAINABLE encoder weights:
         # ops.param_epoch moves on FusedAdam steps (raw-pointer writes), the tensors' own `_version` on any torch optimizer (the fallback of
         # configure_optimizers for optim.name != "Adam" / CPU params) or in-place edit; frozen encoders never repack
@@ -310,29 +349,41 @@ class HubertModel(nn.Module):
         if cfg.normalize:
             wav = ops.wave_layernorm(wav.contiguous(), lens_i32)
         ln_mode = cfg.extractor_mode == "layer_norm"
+        if pack is not None:
+            assert not fold_ln and pack["scale0"] * Tp == P0
+            off_i32 = ops.dev_ints(pack["row_off"], torch.int32, dev)
+            Mt = pack["total"]
+            rows_all = pack["scale0"] * Mt            # rows of the whole batch at conv layer 0
+        else:
+            rows_all = B * P0
         # ---- conv layer 0
-        x = self._buf("conv0", (B * P0 + 8, C), bf, dev, zero=True)
-        if ln_mode:
+        x = buf("conv0", (rows_all + 8, C), bf, dev, zero=True)
+        if pack is not None:
+            if ln_mode:
+                ops.conv0_packed(wav, P["conv0_w"], T0, off_i32, pack["scale0"], pack["rows_max"], Mt, bias=P["conv0_b"], out=x)
+                ops.layernorm(x[:rows_all], *P["conv_ln"][0], gelu=True, out=x[:rows_all])
+            else:
+                ops.conv0_packed(wav, P["conv0_w"], T0, off_i32, pack["scale0"], pack["rows_max"], Mt, gn_gamma=P["gn"][0], gn_beta=P["gn"][1], out=x)
+        elif ln_mode:
             ops.conv0(wav, P["conv0_w"], T0, P0, bias=P["conv0_b"], out=x)
             ops.layernorm(x[: B * P0], *P["conv_ln"][0], gelu=True, out=x[: B * P0])
         else:
             ops.conv0(wav, P["conv0_w"], T0, P0, gn_gamma=P["gn"][0], gn_beta=P["gn"][1], out=x)
-        # ---- conv layers 1.. as overlapping-row GEMMs
-        rows = P0
+        # ---- conv layers 1.. as overlapping-row GEMMs (packed batches: the same ONE GEMM per layer, over sum_b rows_b rows)
         for i, (dim, k, s) in enumerate(cfg.conv_layers[1:]):
-            rows //= s
-            y = self._buf(f"conv{i + 1}", (B * rows + 8, dim), bf, dev, zero=True)
-            ops.gemm(x, P["conv_w"][i], P["conv_b"][i], ACT_NONE if ln_mode else ACT_GELU, out=y[: B * rows],
-                     M=B * rows, K=k * C, lda=s * C)
+            rows_all //= s
+            y = buf(f"conv{i + 1}", (rows_all + 8, dim), bf, dev, zero=True)
+            ops.gemm(x, P["conv_w"][i], P["conv_b"][i], ACT_NONE if ln_mode else ACT_GELU, out=y[:rows_all],
+                     M=rows_all, K=k * C, lda=s * C)
             if ln_mode:
-                ops.layernorm(y[: B * rows], *P["conv_ln"][i + 1], gelu=True, out=y[: B * rows])
+                ops.layernorm(y[:rows_all], *P["conv_ln"][i + 1], gelu=True, out=y[:rows_all])
             x, C = y, dim
-        assert rows == Tp
-        M = B * Tp
+        assert rows_all == (pack["total"] if pack is not None else B * Tp)
+        M = rows_all
         d = cfg.encoder_embed_dim
         # ---- feature LayerNorm + projection
-        feats = ops.layernorm(x[:M], *P["feat_ln"], out=self._buf("feat_ln", (M, C), bf, dev))
-        xp = ops.gemm(feats, P["proj_w"], P["proj_b"], out=self._buf("proj", (M, d), bf, dev))
+        feats = ops.layernorm(x[:M], *P["feat_ln"], out=buf("feat_ln", (M, C), bf, dev))
+        xp = ops.gemm(feats, P["proj_w"], P["proj_b"], out=buf("proj", (M, d), bf, dev))
         rates = self.dropout_rates() if dropout_seed is not None else None
         if rates is not None and any(v > 0 for v in rates.values()):
             if cfg.layer_norm_first:
@@ -353,33 +404,37 @@ class HubertModel(nn.Module):
         nl = cfg.encoder_layers
         pre_ln = cfg.layer_norm_first
         hid_dtype = torch.float32 if pre_ln else bf
-        hidden = self._buf("hidden0", (1, M, d), hid_dtype, dev) if fold_ln else self._buf("hidden", (nl + 1, M, d), hid_dtype, dev)
+        hidden = buf("hidden0", (1, M, d), hid_dtype, dev) if fold_ln else buf("hidden", (nl + 1, M, d), hid_dtype, dev)
         g, bta = (None, None) if pre_ln else P["enc_ln"]
-        ops.posconv(xp, valid_i32, P["pos_w"], P["pos_b"], g, bta, B, Tp, d, cfg.conv_pos_groups, cfg.conv_pos, out=hidden[0])
+        if pack is not None:
+            ops.posconv_packed(xp, valid_i32, off_i32, P["pos_w"], P["pos_b"], g, bta, B, pack["rows_max"], M, d, cfg.conv_pos_groups, cfg.conv_pos,
+                               out=hidden[0])
+        else:
+            ops.posconv(xp, valid_i32, P["pos_w"], P["pos_b"], g, bta, B, Tp, d, cfg.conv_pos_groups, cfg.conv_pos, out=hidden[0])
         if rates and rates["hidden"] > 0:
             ops.dropout_bf16(hidden[0], rates["hidden"], next_seed(), out=hidden[0])            # F.dropout before the layers (:42); layer_results[0] is the dropped state
         # ---- transformer layers
         H = cfg.encoder_attention_heads
-        qkv = self._buf("qkv", (M, 3 * d), bf, dev)
-        att = self._buf("att", (M, d), bf, dev)
-        ffn = self._buf("ffn", (M, cfg.encoder_ffn_embed_dim), bf, dev)
-        tmp = self._buf("tmp", (M, d), bf, dev)
-        tmp2 = self._buf("tmp2", (M, d), bf, dev)
+        qkv = buf("qkv", (M, 3 * d), bf, dev)
+        att = buf("att", (M, d), bf, dev)
+        ffn = buf("ffn", (M, cfg.encoder_ffn_embed_dim), bf, dev)
+        tmp = buf("tmp", (M, d), bf, dev)
+        tmp2 = buf("tmp2", (M, d), bf, dev)
         if fold_ln:
             assert not pre_ln
             if "ln2_gamma" not in P:
                 self._pack_fold(P, dev)
             # LayerNorm folded into the GEMMs around it: per layer  qkv <- LN2_{l-1} folded;  y1 = att Wo + bo + LN2_{l-1}(y2_{l-1}) (+ stats);
             # ffn = gelu(LN1 folded);  y2 = ffn W2 + b2 + LN1(y1) (+ stats).  Neither LN1's nor LN2's output is ever written.
-            ypre = self._buf("ypre", (nl, M, d), bf, dev)
+            ypre = buf("ypre", (nl, M, d), bf, dev)
             y1 = tmp
             npart = d // 64
-            part = self._buf("ln_part", (M, npart, 2), torch.float32, dev)
-            st1 = self._buf("ln_st1", (M, 2), torch.float32, dev)
-            st2 = self._buf("ln_st2", (M, 2), torch.float32, dev)
+            part = buf("ln_part", (M, npart, 2), torch.float32, dev)
+            st1 = buf("ln_st1", (M, 2), torch.float32, dev)
+            st2 = buf("ln_st2", (M, 2), torch.float32, dev)
             fresh = ("ln_ident", (M, 2), torch.float32) not in self._ws
-            ident = self._buf("ln_ident", (M, 2), torch.float32, dev)          # (mean, rstd) = (0, 1): layer 0's residual is already normalised
-            ones, zeros = self._buf("ln_ones", (d,), torch.float32, dev), self._buf("ln_zeros", (d,), torch.float32, dev, zero=True)
+            ident = buf("ln_ident", (M, 2), torch.float32, dev)          # (mean, rstd) = (0, 1): layer 0's residual is already normalised
+            ones, zeros = buf("ln_ones", (d,), torch.float32, dev), buf("ln_zeros", (d,), torch.float32, dev, zero=True)
             if fresh:
                 ident[:, 0] = 0.0
                 ident[:, 1] = 1.0
@@ -402,6 +457,12 @@ class HubertModel(nn.Module):
                     ops.ln_stats_finalize(part, d, out=st2)
             return (hidden[0], ypre, P["ln2_gamma"], P["ln2_beta"]), T, Tp, valid
         assert not (fold_ln and drop_layers)
+
+        def attn(qkv_, att_):
+            if pack is not None:
+                ops.attention_packed(qkv_, B, pack["rows_max"], H, valid_i32, off_i32, out=att_)
+            else:
+                ops.attention(qkv_, B, Tp, H, valid_i32, out=att_)
         kept = 0
         for i, L in enumerate(P["layers"]):
             if stop_layer is not None and i >= stop_layer:      # fine-tuning: the layers from here on run as one autograd node (train_hubert.py)
@@ -412,7 +473,10 @@ class HubertModel(nn.Module):
             kept += 1
             if not pre_ln and rates:      # [3P fairseq] TransformerSentenceEncoderLayer in train mode: x = LN(x + dropout1(attn(x))); x = LN(x + dropout3(fc2(dropout2(act(fc1 x)))))
                 ops.gemm(h, L["wqkv"], L["bqkv"], out=qkv)
-                ops.attention_dropout(qkv, B, Tp, H, valid_i32, rates["attention"], next_seed(), out=att)
+                if pack is not None:
+                    ops.attention_packed(qkv, B, pack["rows_max"], H, valid_i32, off_i32, out=att, drop_p=rates["attention"], seed=next_seed())
+                else:
+                    ops.attention_dropout(qkv, B, Tp, H, valid_i32, rates["attention"], next_seed(), out=att)
                 ops.gemm(att, L["wo"], L["bo"], out=tmp)
                 ops.dropout_add_layernorm(tmp, h, *L["ln1"], rates["hidden"], next_seed(), out=tmp2)
                 ops.gemm(tmp2, L["w1"], L["b1"], ACT_GELU, out=ffn)
@@ -422,21 +486,23 @@ class HubertModel(nn.Module):
                 ops.dropout_add_layernorm(tmp, tmp2, *L["ln2"], rates["hidden"], next_seed(), out=h_out)
             elif not pre_ln:
                 ops.gemm(h, L["wqkv"], L["bqkv"], out=qkv)
-                ops.attention(qkv, B, Tp, H, valid_i32, out=att)
+                attn(qkv, att)
                 ops.gemm(att, L["wo"], L["bo"], residual=h, out=tmp)
                 ops.layernorm(tmp, *L["ln1"], out=tmp2)
                 ops.gemm(tmp2, L["w1"], L["b1"], ACT_GELU, out=ffn)
                 ops.gemm(ffn, L["w2"], L["b2"], residual=tmp2, out=tmp)
                 ops.layernorm(tmp, *L["ln2"], out=h_out)
             else:
-                xmid = self._buf("xmid", (M, d), torch.float32, dev)
+                xmid = buf("xmid", (M, d), torch.float32, dev)
                 ops.layernorm(h, *L["ln1"], out=tmp)
                 ops.gemm(tmp, L["wqkv"], L["bqkv"], out=qkv)
-                ops.attention(qkv, B, Tp, H, valid_i32, out=att)
+                attn(qkv, att)
                 ops.gemm(att, L["wo"], L["bo"], residual=h, out=xmid, out_f32=True)
                 ops.layernorm(xmid, *L["ln2"], out=tmp)
                 ops.gemm(tmp, L["w1"], L["b1"], ACT_GELU, out=ffn)
                 ops.gemm(ffn, L["w2"], L["b2"], residual=xmid, out=h_out, out_f32=True)
+        if pack is not None:
+            return (hidden[: kept + 1] if (drop_layers or stop_layer is not None) else hidden), T, None, valid
         if drop_layers:
             return hidden[: kept + 1].view(kept + 1, B, Tp, d), T, Tp, valid
         return hidden.view(nl + 1, B, Tp, d), T, Tp, valid

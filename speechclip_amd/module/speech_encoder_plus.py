@@ -212,9 +212,22 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             return (mixed, feat_len)
         if self.train_layers and torch.is_grad_enabled():
             return self._forward_finetune(padded, lens, feat_select_idx, return_hidden_states, drop_seed)
-        hidden, T, Tp, _valid = self.encoder.extract_all_layers(padded, lens, drop_layers=drop, dropout_seed=drop_seed)      # [n, B, Tp, d]
+        pack = self._pack_plan(padded, lens)
+        hidden, T, Tp, _valid = self.encoder.extract_all_layers(padded, lens, drop_layers=drop, dropout_seed=drop_seed, pack=pack)      # [n, B, Tp, d]
         # speech_encoder_plus.py:604-611: Python round() (banker's) of len / 320, clamped to T
         feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()   # escapes to the caller
+        if pack is not None:
+            # Padding-free engine (module/hubert.py: packed_geometry): `hidden` is [n, sum_b rows_b, d].  The padded [B, T, d] layout of the
+            # reference is restored at this boundary only -- for the mixed frames when nobody needs the states themselves, else for all states.
+            # Rows beyond an utterance's own frames (the reference holds padded-frame outputs there, which the heads mask: :604-611) are zeros.
+            off = ops.dev_ints(pack["row_off"], torch.int32, dev)
+            ws = getattr(self, "weightedsum_layer", None)
+            if (feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE and not return_hidden_states
+                    and not (torch.is_grad_enabled() and ws.weights.requires_grad)):
+                assert hidden.shape[0] == ws.n_weights, hidden.shape[0]
+                mixed = ops.unpack_rows(ops.weighted_sum(hidden, ws.weights.detach().float(), ws.normalize_features), off, padded.shape[0], T)
+                return (mixed, feat_len)
+            hidden = ops.unpack_rows(hidden, off, padded.shape[0], T)                                                  # [n, B, T, d]
         layers = lambda: tuple(hidden[i, :, :T] for i in range(hidden.shape[0]))  # noqa: E731
         out = []
         if feat_select_idx == "all":
@@ -239,6 +252,24 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if return_hidden_states:
             out.append(layers())
         return tuple(out)
+
+
+def _pack_plan(self, padded, lens):
+    """Packed (padding-free) geometry of this batch, or None for the uniform layout.  SC_VARLEN_PACK: "auto" (default: pack when it removes at
+    least 10 % of the transformer rows), "1" (always, when the kernels cover the shape), "0" (never)."""
+    mode = os.environ.get("SC_VARLEN_PACK", "auto")
+    cfg = self.encoder.cfg
+    cg = cfg.encoder_embed_dim // cfg.conv_pos_groups
+    if mode == "0" or padded.shape[0] < 1 or cg not in (32, 48, 64) or cfg.conv_layers[0][0] % 64 or cfg.encoder_embed_dim // cfg.encoder_attention_heads != 64:
+        return None
+    T = self.encoder.frame_geometry(padded.shape[1])[1]
+    pack = self.encoder.packed_geometry(lens, padded.shape[1], need_rows=[min(round(l / self.downsample_rate), T) for l in lens])
+    if mode != "1" and pack["total"] > 0.9 * pack["padded_rows"]:
+        return None
+    return pack
+
+
+FairseqSpeechEncoder_Hubert._pack_plan = _pack_plan
 
 
 def _forward_finetune(self, padded, lens, feat_select_idx, return_hidden_states, drop_seed=None):

@@ -375,6 +375,68 @@ def posconv(x, valid_i32, wg, bias, gamma, beta, B, Tp, D, G, Kw, out=None, out_
     return out
 
 
+# ---------------------------------------------------------------------------------------------- padding-free (packed) batches
+# Utterance b owns rows [row_off[b], row_off[b + 1]) of every transformer-level tensor (module/hubert.py: extract_all_layers_packed).
+def conv0_packed(wav, w, T0, row_off_i32, row_scale, rows_max, total_rows, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5, out=None):
+    """ops.conv0 writing utterance b at rows row_scale * row_off[b] ...; the GroupNorm statistics are those of the padded length T0."""
+    _need_cuda(wav, w, row_off_i32)
+    B, L = wav.shape
+    C = w.shape[0]
+    assert wav.dtype == torch.float32 and wav.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous() and row_off_i32.dtype == torch.int32
+    assert out is not None and out.dtype == bf16 and out.is_contiguous() and out.shape[0] >= row_scale * total_rows and out.shape[1] == C
+    wfrag = torch.empty(lib().sc_conv0_wfrag_workspace_bytes(B), device=wav.device, dtype=torch.uint8)
+    coef = None
+    if gn_gamma is not None:
+        ws = torch.empty(lib().sc_conv0_stats_workspace_bytes(B), device=wav.device, dtype=torch.uint8)
+        coef = torch.empty(B, C, 2, device=wav.device, dtype=torch.float32)
+        check(lib().sc_conv0_gn_coef(ptr(wav), L, ptr(w), ptr(gn_gamma), ptr(gn_beta), ptr(ws), ptr(coef), B, C, T0, eps, stream()), "sc_conv0_gn_coef")
+    check(lib().sc_conv0_fwd_packed(ptr(wav), L, L, ptr(w), None if gn_gamma is not None else ptr(bias), ptr(coef), ptr(out), B, C, T0, ptr(row_off_i32),
+                                    row_scale, row_scale * rows_max, 0 if gn_gamma is not None else 1, ptr(wfrag), stream()), "sc_conv0_fwd_packed")
+    return out
+
+
+def posconv_packed(x, valid_i32, row_off_i32, wg, bias, gamma, beta, B, rows_max, total_rows, D, G, Kw, out=None, out_f32=False, eps=1e-5):
+    """ops.posconv over packed rows: x bf16 [total_rows, D]."""
+    _need_cuda(x, wg, row_off_i32)
+    cg = D // G
+    conv = torch.empty(total_rows * D, device=x.device, dtype=bf16)
+    rc = lib().sc_posconv_conv_packed(ptr(x), ptr(valid_i32), ptr(row_off_i32), ptr(wg), ptr(conv), B, rows_max, D, G, Kw, stream())
+    if rc == 1:
+        raise SpeechClipHipError(f"packed batches need the windowed positional-conv kernel (D/G in 32/48/64), got D/G = {cg}")
+    check(rc, "sc_posconv_conv_packed")
+    if out is None:
+        out = torch.empty(total_rows, D, device=x.device, dtype=torch.float32 if out_f32 else bf16)
+    check(lib().sc_posconv_finish_packed(ptr(x), ptr(valid_i32), ptr(row_off_i32), ptr(conv), ptr(bias), ptr(gamma), ptr(beta), ptr(out), B, total_rows, D, G,
+                                         int(out.dtype == torch.float32), eps, stream()), "sc_posconv_finish_packed")
+    return out
+
+
+def attention_packed(qkv, B, rows_max, H, klens_i32, row_off_i32, out=None, drop_p=0.0, seed=0):
+    """ops.attention / ops.attention_dropout over packed rows: qkv bf16 [total_rows, 3*H*64]."""
+    _need_cuda(qkv, klens_i32, row_off_i32)
+    D = H * 64
+    total = qkv.shape[0]
+    assert qkv.dtype == bf16 and qkv.shape == (total, 3 * D) and qkv.is_contiguous()
+    if out is None:
+        out = torch.empty(total, D, device=qkv.device, dtype=bf16)
+    check(lib().sc_attention_fwd_packed(qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2, ptr(out), ptr(klens_i32), ptr(row_off_i32),
+                                        B, H, rows_max, total, 64, 3 * D, D, 0.125, float(drop_p), int(seed) & 0xffffffff, stream()), "sc_attention_fwd_packed")
+    return out
+
+
+def unpack_rows(src, row_off_i32, B, T_out):
+    """src [n, total_rows, D] or [total_rows, D] (packed) -> [n, B, T_out, D] / [B, T_out, D], zeros beyond each utterance's rows."""
+    _need_cuda(src, row_off_i32)
+    three = src.dim() == 3
+    s3 = src if three else src.unsqueeze(0)
+    n, total, D = s3.shape
+    assert s3.is_contiguous() and (D * s3.element_size()) % 16 == 0
+    out = torch.empty(n, B, T_out, D, device=src.device, dtype=src.dtype)
+    rb = D * s3.element_size()
+    check(lib().sc_unpack_rows(ptr(s3), total * rb, ptr(row_off_i32), ptr(out), B * T_out * rb, n, B, T_out, rb, stream()), "sc_unpack_rows")
+    return out if three else out[0]
+
+
 _DEV_INTS = {}
 
 

@@ -554,3 +554,36 @@ def test_vq_temperature_forms_follow_the_reference():
     assert s.temperature_value() == 0.5
     f.set_num_updates(5)
     assert abs(f.temperature_value() - 0.1) < 1e-7
+
+
+def test_packed_geometry_covers_the_receptive_field_halo():
+    """Padding-free row allotment (module/hubert.py: packed_geometry): utterance b gets max(valid_b, need_b) + 1 transformer rows and
+    2^(6-l) times that at conv layer l.  The frames a kept output depends on must fit the allotment at EVERY conv level, and the frame
+    mask / feat_len rules stay those of the padded reference (speech_encoder_plus.py:604-611, fairseq forward_padding_mask)."""
+    from speechclip_amd.module.hubert import CONV_LAYERS, HubertConfig, HubertModel, conv_lengths
+    enc = HubertModel(HubertConfig(encoder_layers=1))
+    rng = np.random.RandomState(0)
+    for trial in range(50):
+        B = int(rng.randint(1, 9))
+        lens = [int(x) for x in rng.randint(400, 160001, size=B)]
+        lmax = max(lens)
+        T0, T, P0, Tp = enc.frame_geometry(lmax)
+        need = [min(round(l / 320), T) for l in lens]
+        geo = enc.packed_geometry(lens, lmax, need_rows=need)
+        assert geo["valid"] == enc.valid_frames(lens, lmax, T) and geo["scale0"] == 64 and geo["padded_rows"] == B * Tp
+        assert geo["row_off"][0] == 0 and geo["row_off"][-1] == geo["total"] == sum(geo["rows"])
+        pad_lens = conv_lengths(lmax, CONV_LAYERS)
+        for b in range(B):
+            F = max(geo["valid"][b], need[b])
+            assert geo["rows"][b] == F + 1 and F <= T
+            n = F                                            # frames needed at the last conv level, walking down to layer 0
+            scale = 1
+            for lvl in range(len(CONV_LAYERS) - 1, 0, -1):
+                _, k, s = CONV_LAYERS[lvl]
+                n = (n - 1) * s + k                          # frames of level lvl-1 that n frames of level lvl read
+                scale *= s
+                assert n <= scale * geo["rows"][b], (lvl, n, scale * geo["rows"][b])
+                assert n <= pad_lens[lvl - 1], "a kept frame never needs a frame the padded layout does not have"
+    # equal lengths: nothing to gain, one extra row per utterance at most
+    geo = enc.packed_geometry([160000] * 4, 160000, need_rows=[499] * 4)
+    assert geo["rows"] == [500] * 4 and geo["total"] == geo["padded_rows"]
