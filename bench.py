@@ -171,7 +171,20 @@ def cpu_baseline(model_sd, n_pairs, L, iters=3):
     n_c1 = 16 if n_pairs >= 16 else max(2, n_pairs)           # C1 = 16 pairs (BASELINE configs[0]); smaller only for the quick contract test
     c1_lens = [int(x) for x in torch.randint(L // 4, L + 1, (n_c1,), generator=g)]
     c1 = run(lambda: mk(n_c1, c1_lens), n_c1)
+    # SURVEY.md section 8(d) asks for ALL host cores: the same oracle with torch.set_num_threads(os.cpu_count()), one warm-up + one timed pass of
+    # half the sample, reported beside the best-of-probe figure (`value` stays the faster of the two protocols' best thread count)
+    all_cores = None
+    if ncpu != cores and n_pairs >= 8:
+        torch.set_num_threads(ncpu)
+        it_save, iters = iters, 1
+        try:
+            r = run(lambda: mk(max(2, n_pairs // 2)), max(2, n_pairs // 2))
+        finally:
+            iters = it_save
+            torch.set_num_threads(cores)
+        all_cores = {"cores": ncpu, "pairs_per_s": r["pairs_per_s"], "iter_s": r["iter_s"], "pairs": max(2, n_pairs // 2)}
     return {"value": fixed["pairs_per_s"], "unit": "pairs/s", "cores": cores, "kind": "port", "host_hw_threads": ncpu, "cpu_model": _cpu_model(),
+            "all_host_cores": all_cores,
             "timed_iterations": iters, "fixed_length": fixed, "c1_varlen_b16": dict(c1, pairs=n_c1, lens_min_max=[min(c1_lens), max(c1_lens)]),
             "sample": f"{iters} timed iterations (after 1 warm-up) of {n_pairs} pairs (10 s audio + 224^2 image) through oracle/speechclip_ref.py fp32 "
                       f"with {cores} torch threads (best of 8/16/32/64/all on a 2-pair probe; host: {ncpu} hardware threads, {_cpu_model()}), "
@@ -291,6 +304,11 @@ def main():
     ap.add_argument("--model", choices=["base", "large", "cascaded"], default="base", help="base = the headline workload (BASELINE configs[1]); large = "
                     "HuBERT-large + ViT-L/14 (configs[4]), informational")
     ap.add_argument("--audio-len", type=int, default=160000)
+    ap.add_argument("--varlen", action="store_true", help="SURVEY.md section 8(d) C2 varlen variant: L_i ~ U{32000..160000} (seed 7122) instead of every wave at "
+                    "--audio-len; the step runs on the padding-free engine and the flop model uses each utterance's own frame count.  The same batch on the "
+                    "padded engine (SC_VARLEN_PACK=0) is timed beside it as `varlen_padded_comparator`")
+    ap.add_argument("--global-batch", type=int, default=None, help="STRONG scaling: the global batch is fixed (e.g. 2048 = spchclp_p.yaml:10 x 8 GPUs) and split "
+                    "over the ranks (pairs per GPU = global / N); the line says \"scaling\": \"strong\"")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="pairs for the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--train", action="store_true", help="time the TRAINING step of the trainable tail instead (forward in train mode + loss.backward() "
@@ -332,6 +350,11 @@ def main():
 
     from speechclip_amd import ops, parallel
     large = args.model == "large"
+    strong = args.global_batch is not None
+    if strong:
+        if args.global_batch % world:
+            sys.exit(f"bench.py: --global-batch {args.global_batch} is not divisible by {world} ranks")
+        args.batch = args.global_batch // world
     if args.batch is None:
         args.batch = 64 if large else 256
     casc = args.model == "cascaded"
@@ -341,7 +364,12 @@ def main():
     B, L = args.batch, args.audio_len
     g = torch.Generator(device="cpu").manual_seed(7122 + rank)
     wav = (0.1 * torch.randn(B, L, generator=g)).to(dev)
-    batch = {"wav": wav, "wav_len": torch.full((B,), L, dtype=torch.long), "image": torch.randn(B, 3, 224, 224, generator=g).to(dev),
+    lens = [L] * B
+    if args.varlen:          # L_i ~ U{32000..160000}; zero right-padding to the batch maximum, as collate_general hands it over
+        lens = [int(x) for x in torch.randint(min(32000, L), L + 1, (B,), generator=g)]
+        wav = wav[:, :max(lens)].contiguous()
+        wav *= (torch.arange(wav.shape[1], device=dev)[None, :] < torch.tensor(lens, device=dev)[:, None])
+    batch = {"wav": wav, "wav_len": torch.tensor(lens, dtype=torch.long), "image": torch.randn(B, 3, 224, 224, generator=g).to(dev),
              "id": (torch.arange(B) + rank * B).to(dev)}
 
     if args.train:
@@ -372,15 +400,18 @@ def main():
     # roofline instrumentation: HIP events around every GEMM launch of every THIRD timed step (two events per launch, ~220 launches per
     # step: on every step they cost ~1 % of the step time they are meant to explain)
     prof = None if args.no_roofline_events else []
+    hbm_prof, xchg_prof = [], []
     ops.PROFILE_SIDE = []
     ev_steps = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         instrumented = prof is not None and (i % 3 == 2 or args.steps < 3)
         ops.PROFILE = prof if instrumented else None
+        ops.PROFILE_HBM = hbm_prof if instrumented else None
+        parallel.PROFILE_EXCHANGE = xchg_prof if instrumented else None       # the exchange measured INSIDE the step (events around the gather)
         ev_steps += int(instrumented)
         loss = step()
-    ops.PROFILE = None
+    ops.PROFILE = ops.PROFILE_HBM = parallel.PROFILE_EXCHANGE = None
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -408,6 +439,52 @@ def main():
             t = torch.tensor([x0.elapsed_time(x1) / 20], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             exchange_ms = round(t.item(), 4)
+    exchange_in_step_ms = None
+    if world > 1 and xchg_prof:
+        t = torch.tensor([sum(a.elapsed_time(b) for a, b in xchg_prof) / max(1, ev_steps)], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        exchange_in_step_ms = round(t.item(), 4)
+    # the same batch on the PADDED engine (what every round before the packed engine measured): comparator, never part of `value`
+    varlen_cmp = None
+    if args.varlen and not args.train:
+        os.environ["SC_VARLEN_PACK"] = "0"
+        for _ in range(2):
+            step()
+        fence()
+        v0 = time.perf_counter()
+        nv = max(3, min(args.steps, 8))
+        for _ in range(nv):
+            step()
+        fence()
+        vdt = time.perf_counter() - v0
+        os.environ.pop("SC_VARLEN_PACK")
+        if world > 1:
+            t = torch.tensor([vdt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            vdt = t.item()
+        varlen_cmp = {"engine": "padded layout (SC_VARLEN_PACK=0): every GEMM on B x T_max rows, the reference's own shape", "steps": nv,
+                      "ms_per_step": round(vdt / nv * 1e3, 3), "value": round(world * B * nv / vdt, 2), "unit": "pairs/s"}
+    # measured ceiling of the vendor library on this box, beside the 2.5 PF/s datasheet peak: hipBLASLt and the hand-written kernel on 8192^3 bf16
+    ceiling = None
+    if world == 1 and not args.no_vendor_comparator and not args.train:
+        n8 = 8192
+        a8 = torch.randn(n8, n8, device=dev, dtype=torch.bfloat16)
+        w8 = torch.randn(n8, n8, device=dev, dtype=torch.bfloat16)
+        c8 = torch.empty(n8, n8, device=dev, dtype=torch.bfloat16)
+        ceiling = {"shape": "8192^3 bf16, 30 back-to-back launches after 10 warm-up launches"}
+        for name, on in (("hand_written_gemm256_tflops", False), ("hipblaslt_tflops", True)):
+            ops.set_vendor_gemm(on)
+            for _ in range(10):
+                ops.gemm(a8, w8, out=c8)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(30):
+                ops.gemm(a8, w8, out=c8)
+            e1.record()
+            torch.cuda.synchronize()
+            ceiling[name] = round(30 * 2.0 * n8 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+        ops.set_vendor_gemm(False)
+        del a8, w8, c8
     clock = None
     if world == 1 and not args.no_clock_probe:
         clock = clock_under_load(step, fence)
@@ -435,7 +512,17 @@ def main():
     # train mode crops every utterance to audio_encoder.max_audio_len (102400 samples, T = 319) exactly as the reference trains
     mal = int(getattr(model.audio_encoder, "max_audio_len", -1))
     L_eff = min(L, mal) if (args.train and mal > 0) else L
-    total_gf, gemm_gf = algorithmic_gflop_per_pair(L_eff, **(LARGE if large else {}))
+    if args.varlen:          # "padding is not work" (SURVEY.md section 8d): each utterance is credited with ITS OWN frames
+        cache = {}
+        for n in lens:
+            n = min(n, mal) if (args.train and mal > 0) else n
+            if n not in cache:
+                cache[n] = algorithmic_gflop_per_pair(n, **(LARGE if large else {}))
+        per = [cache[min(n, mal) if (args.train and mal > 0) else n] for n in lens]
+        total_gf, gemm_gf = sum(p[0] for p in per) / B, sum(p[1] for p in per) / B
+        L_eff = int(sum(lens) / B)
+    else:
+        total_gf, gemm_gf = algorithmic_gflop_per_pair(L_eff, **(LARGE if large else {}))
     mode_str = "forward + loss"
     if args.train:
         what = " + the whole HuBERT encoder" if args.finetune_all else (" + HuBERT layers %s" % args.finetune_layers if args.finetune_layers else "")
@@ -451,11 +538,18 @@ def main():
             # HBM traffic of the kernel cannot be measured from inside this process (PMC counters need rocprofv3 and their own passes):
             # report the committed per-launch figure of the same command, with its source, or null if it is not there / not this workload
             traffic, tsrc = None, None
-            tf = os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")
-            if os.path.exists(tf) and not args.train and not large and not casc and B == 256 and L == 160000:
-                tj = json.load(open(tf))
+            import glob
+            import hashlib
+            tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_hbm_traffic.json")))      # the newest round's PMC pass
+            if tfs and not args.train and not large and not casc and B == 256 and L == 160000 and not args.varlen:
+                tj = json.load(open(tfs[-1]))
                 traffic = tj["gemm_main_stream"]["bytes_per_launch"]
-                tsrc = tj["source"] + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; main-stream gemm256_kernel + gemm_bf16_kernel launches of the same command)"
+                from speechclip_amd import _lib as _l
+                sha = hashlib.sha256(open(_l.LIB_PATH, "rb").read()).hexdigest()[:16]
+                same = tj.get("lib_sha16") == sha
+                tsrc = (tj["source"] + " (%s; separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; main-stream gemm256_kernel + gemm_bf16_kernel launches of the "
+                        "same command; NOT measured in this run -- PMC counters need rocprofv3; collected on library %s, this run's library is %s: %s)"
+                        % (os.path.basename(tfs[-1]), tj.get("lib_sha16", "unstamped"), sha, "the same build" if same else "a DIFFERENT build"))
             # the entry serves two kernels (vendor_gemm.hip): the hand-written gemm256_kernel family (everything fused / overlapping rows /
             # small) and hipBLASLt (plain GEMMs).  The DOMINANT kernel of the step is the hand-written one: `achieved` is ITS flops / ITS time;
             # the whole entry and the library part are reported beside it.
@@ -499,22 +593,37 @@ def main():
                     "gemm_ms_per_step": round(tot_ms / ev_steps, 3),
                     "instrumented_steps": ev_steps,
                     "executed_over_algorithmic": round(exe / alg, 4)}
+        # HBM-bound segments, each against the 8 TB/s HBM3E peak: algorithmic bytes (unique input + output) / HIP-event time
+        hbm = None
+        if hbm_prof and ev_steps:
+            hbm = {}
+            for tag in sorted({e[3] for e in hbm_prof}):
+                sel = [e for e in hbm_prof if e[3] == tag]
+                ms = sum(e[0].elapsed_time(e[1]) for e in sel)
+                by = sum(e[2] for e in sel)
+                hbm[tag] = {"launches_per_step": len(sel) // ev_steps, "ms_per_step": round(ms / ev_steps, 3), "gbytes_per_step": round(by / ev_steps / 1e9, 3),
+                            "achieved_gb_s": round(by / max(ms, 1e-9) / 1e6, 1), "frac_of_8tb_s": round(by / max(ms, 1e-9) / 1e6 / 8000.0, 4)}
+            hbm["note"] = "algorithmic bytes / event time, main and side stream launches together; peak 8000 GB/s (datasheet), ~6300 GB/s is what a copy reaches"
         out = {"metric": "speech-image pairs/sec/node (%s)" % ("Cascaded SpeechCLIP base" if casc else "Parallel SpeechCLIP %s" % args.model), "value": round(pairs_per_s, 2), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic" if not args.share_gpu else "synthetic; TEST HOOK --share-gpu: all ranks on one GPU over gloo, not a scaling measurement",
                "config": {"workload": ("Cascaded SpeechCLIP base (HuBERT-base + ViT-B/32 + CLIP text tower; flop model = the encoders' GEMMs, the keyword head adds < 1 %)" if casc else
                                        "Parallel SpeechCLIP large (HuBERT-large + ViT-L/14)" if large else "Parallel SpeechCLIP base (HuBERT-base + ViT-B/32)")
-                          + " forward + InfoNCE, 10 s/16 kHz audio + 224^2 images",
+                          + (" forward + InfoNCE, VARLEN 16 kHz audio L_i ~ U{%d..%d} samples (seed 7122, zero-padded to the batch maximum as collate hands it over; "
+                             "padding-free engine: %s) + 224^2 images" % (min(32000, L), L, os.environ.get("SC_VARLEN_PACK", "auto")) if args.varlen
+                             else " forward + InfoNCE, 10 s/16 kHz audio + 224^2 images"),
                           "pairs_per_gpu": B, "global_batch": world * B, "audio_samples": L_eff, "frames": conv_lens(L_eff)[-1],
+                          "audio_samples_min_max": [min(lens), max(lens)],
                           "parallelism": f"dp{world}" if world > 1 else "single", "weights": "random-init (no network)",
                           "algorithmic_gflop_per_pair": round(total_gf, 2), "mode": mode_str},
                "e2e_tflops_per_gpu": round(total_gf * 1e9 * pairs_per_s / world / 1e12, 1),
                "e2e_frac_of_bf16_peak": round(total_gf * 1e9 * pairs_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
-               "rccl_ranks_seen": int(seen.item()), "exchange_ms_per_step": exchange_ms,
+               "rccl_ranks_seen": int(seen.item()), "exchange_ms_per_step": exchange_ms, "exchange_in_step_ms": exchange_in_step_ms,
                "exchange": ("one packed all_gather_into_tensor over RCCL per step (speechclip_amd/parallel.py); exchange_ms_per_step = pack + collective + unpack, "
-                            "timed beside the step, max over ranks") if world > 1 else None,
-               "vendor_comparator": vendor, "clock": clock,
+                            "timed beside the step with random payloads; exchange_in_step_ms = the same three operations timed by HIP events INSIDE the instrumented "
+                            "steps (includes waiting for the slowest rank's towers); both max over ranks") if world > 1 else None,
+               "vendor_comparator": vendor, "varlen_padded_comparator": varlen_cmp, "measured_ceiling_8k_cubed": ceiling, "hbm_segments": hbm, "clock": clock,
                "loss": round(float(loss), 5), "roofline": roof, "cpu_baseline": None}
         if sd_cpu is not None:
             del model

@@ -15,6 +15,29 @@ bf16 = torch.bfloat16
 # Optional HIP-event instrumentation of the dominant kernel (bench.py roofline leg): when PROFILE is a list, every
 # sc_gemm_bf16 launch appends (start_event, end_event, flops, shape_tag) recorded on the launch stream.
 PROFILE = None
+# HBM-bound segments (conv layer 0, LayerNorm, layer mix): when PROFILE_HBM is a list, each launch appends
+# (start, end, algorithmic bytes, tag, stream) -- bench.py reports their GB/s against the 8 TB/s HBM peak
+PROFILE_HBM = None
+
+
+class _HbmSpan:
+    __slots__ = ("tag", "nbytes", "e0")
+
+    def __init__(self, tag, nbytes):
+        self.tag, self.nbytes, self.e0 = tag, nbytes, None
+
+    def __enter__(self):
+        if PROFILE_HBM is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.e0 is not None and PROFILE_HBM is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE_HBM.append((self.e0, e1, float(self.nbytes), self.tag, torch.cuda.current_stream().cuda_stream))
+        return False
 PROFILE_SIDE = []     # (start, end) HIP events of every side-stream window (the image tower running beside the speech tower) while PROFILE is on
 
 _GEMM_WS = {}
@@ -189,7 +212,8 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, out_f32=False, gelu=False, row
         out = torch.empty(shape, device=x.device, dtype=torch.float32 if out_f32 else bf16)
     flags = (LN_IN_F32 if x.dtype == torch.float32 else 0) | (LN_OUT_F32 if out.dtype == torch.float32 else 0) | (LN_GELU if gelu else 0)
     assert x.dtype in (bf16, torch.float32)
-    check(lib().sc_layernorm(ptr(x), ld_in, ptr(gamma), ptr(beta), ptr(out), D, rows, D, eps, flags, stream()), "sc_layernorm")
+    with _HbmSpan("layernorm", rows * D * (x.element_size() + out.element_size())):
+        check(lib().sc_layernorm(ptr(x), ld_in, ptr(gamma), ptr(beta), ptr(out), D, rows, D, eps, flags, stream()), "sc_layernorm")
     return out
 
 
@@ -200,7 +224,8 @@ def weighted_sum(hidden, weights, normalize=False, eps=1e-5):
     assert hidden.is_contiguous() and weights.dtype == torch.float32
     out = torch.empty(rows, D, device=hidden.device, dtype=bf16)
     flags = (1 if normalize else 0) | (2 if hidden.dtype == torch.float32 else 0)
-    check(lib().sc_weighted_sum_fwd(ptr(hidden), rows * D, ptr(weights), ptr(out), n, rows, D, flags, eps, stream()), "sc_weighted_sum_fwd")
+    with _HbmSpan("layer_mix", rows * D * (n * hidden.element_size() + 2)):
+        check(lib().sc_weighted_sum_fwd(ptr(hidden), rows * D, ptr(weights), ptr(out), n, rows, D, flags, eps, stream()), "sc_weighted_sum_fwd")
     return out
 
 
@@ -349,10 +374,13 @@ def conv0(wav, w, T0, P, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5, out=N
     if gn_gamma is not None:
         ws = torch.empty(lib().sc_conv0_stats_workspace_bytes(B), device=wav.device, dtype=torch.uint8)
         coef = torch.empty(B, C, 2, device=wav.device, dtype=torch.float32)
-        check(lib().sc_conv0_gn_coef(ptr(wav), L, ptr(w), ptr(gn_gamma), ptr(gn_beta), ptr(ws), ptr(coef), B, C, T0, eps, stream()), "sc_conv0_gn_coef")
-        check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), None, ptr(coef), ptr(buf), B, C, T0, P, 0, ptr(wfrag), stream()), "sc_conv0_fwd")
+        with _HbmSpan("conv0_gn_stats", B * L * 4):
+            check(lib().sc_conv0_gn_coef(ptr(wav), L, ptr(w), ptr(gn_gamma), ptr(gn_beta), ptr(ws), ptr(coef), B, C, T0, eps, stream()), "sc_conv0_gn_coef")
+        with _HbmSpan("conv0", B * L * 4 + B * P * C * 2):
+            check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), None, ptr(coef), ptr(buf), B, C, T0, P, 0, ptr(wfrag), stream()), "sc_conv0_fwd")
     else:
-        check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), ptr(bias), None, ptr(buf), B, C, T0, P, 1, ptr(wfrag), stream()), "sc_conv0_fwd")
+        with _HbmSpan("conv0", B * L * 4 + B * P * C * 2):
+            check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), ptr(bias), None, ptr(buf), B, C, T0, P, 1, ptr(wfrag), stream()), "sc_conv0_fwd")
     return buf
 
 
@@ -389,9 +417,12 @@ def conv0_packed(wav, w, T0, row_off_i32, row_scale, rows_max, total_rows, gn_ga
     if gn_gamma is not None:
         ws = torch.empty(lib().sc_conv0_stats_workspace_bytes(B), device=wav.device, dtype=torch.uint8)
         coef = torch.empty(B, C, 2, device=wav.device, dtype=torch.float32)
-        check(lib().sc_conv0_gn_coef(ptr(wav), L, ptr(w), ptr(gn_gamma), ptr(gn_beta), ptr(ws), ptr(coef), B, C, T0, eps, stream()), "sc_conv0_gn_coef")
-    check(lib().sc_conv0_fwd_packed(ptr(wav), L, L, ptr(w), None if gn_gamma is not None else ptr(bias), ptr(coef), ptr(out), B, C, T0, ptr(row_off_i32),
-                                    row_scale, row_scale * rows_max, 0 if gn_gamma is not None else 1, ptr(wfrag), stream()), "sc_conv0_fwd_packed")
+        with _HbmSpan("conv0_gn_stats", B * L * 4):
+            check(lib().sc_conv0_gn_coef(ptr(wav), L, ptr(w), ptr(gn_gamma), ptr(gn_beta), ptr(ws), ptr(coef), B, C, T0, eps, stream()), "sc_conv0_gn_coef")
+    with _HbmSpan("conv0", row_scale * total_rows * (5 * 4 + C * 2)):
+        check(lib().sc_conv0_fwd_packed(ptr(wav), L, L, ptr(w), None if gn_gamma is not None else ptr(bias), ptr(coef), ptr(out), B, C, T0,
+                                        ptr(row_off_i32), row_scale, row_scale * rows_max, 0 if gn_gamma is not None else 1, ptr(wfrag), stream()),
+              "sc_conv0_fwd_packed")
     return out
 
 

@@ -13,6 +13,11 @@ import torch
 import torch.distributed as dist
 
 
+# bench instrumentation: when a list, every exchange (pack + the ONE collective + unpack) appends its (start, end) HIP events -- the exchange
+# measured INSIDE the step, on the stream it runs on
+PROFILE_EXCHANGE = None
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -58,8 +63,15 @@ def gather_loss_feats(feats: Dict[str, torch.Tensor], force: bool = False) -> Di
     rank, ws = world()
     if ws == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return feats
+    if PROFILE_EXCHANGE is not None and feats["id"].is_cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     packed, keys, widths = pack_feats(feats)
-    return unpack_feats(all_gather_packed(packed), keys, widths)
+    out = unpack_feats(all_gather_packed(packed), keys, widths)
+    if PROFILE_EXCHANGE is not None and feats["id"].is_cuda:
+        e1.record()
+        PROFILE_EXCHANGE.append((e0, e1))
+    return out
 
 
 def gather_rows_dict(d: dict) -> dict:

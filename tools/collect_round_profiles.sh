@@ -18,6 +18,8 @@ SC_OVERLAP_VIT=0 trace fwd_serial_towers
 trace train --train
 trace casc_fwd --model cascaded
 trace casc_train --model cascaded --train
+trace large_fwd --model large
+trace varlen_fwd --varlen
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 3 --warmup 0 --cpu-pairs 0 --no-roofline-events --no-vendor-comparator --no-clock-probe > $O/pmc_$c.log 2>&1
 done
@@ -25,4 +27,9 @@ python $R/tools/pmc_summary.py $O/pmc_FETCH_SIZE/* $O/pmc_WRITE_SIZE/* > $O/pmc_
 python $R/tools/make_traffic_json.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE 3 "profiles/${1:-round}_bench_pmc_hbm_traffic.txt" > $O/gemm_hbm_traffic.json 2>$O/gemm_hbm_traffic.err
 python $R/bench.py > $O/default_run.json 2> $O/default_run.err
 python $R/bench.py --train --cpu-pairs 0 > $O/train_run.json 2> $O/train_run.err
+python $R/bench.py --varlen --cpu-pairs 0 > $O/varlen_run.json 2> $O/varlen_run.err
+python $R/bench.py --model large --cpu-pairs 0 > $O/large_run.json 2> $O/large_run.err
+python $R/bench.py --model large --varlen --audio-len 240000 --cpu-pairs 0 > $O/large_varlen_run.json 2> $O/large_varlen_run.err
+python $R/bench.py --model cascaded --cpu-pairs 0 > $O/casc_run.json 2> $O/casc_run.err
+SC_OVERLAP_VIT=0 python $R/tools/step_gemm_breakdown.py > $O/step_gemm_breakdown.txt 2>&1
 tail -c 600 $O/default_run.json

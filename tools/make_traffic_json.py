@@ -16,6 +16,13 @@ def load(d):
     return agg, cnt
 
 
+def lib_sha16():
+    """sha256[:16] of the product library the passes ran on: bench.py compares it with the library of the run that quotes these numbers."""
+    import hashlib
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speechclip_amd", "libspeechclip_hip.so")
+    return hashlib.sha256(open(p, "rb").read()).hexdigest()[:16] if os.path.exists(p) else None
+
+
 def main():
     fd, wd, steps, label = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     fetch, fc = load(fd)
@@ -30,7 +37,7 @@ def main():
     out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `python bench.py --steps %d --warmup 0 --cpu-pairs 0 "
                      "--no-roofline-events --no-vendor-comparator` (tools/collect_round_profiles.sh); FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950; "
                      "both counters in KiB" % steps,
-           "source": label}
+           "source": label, "lib_sha16": lib_sha16()}
     for name, pred in (("gemm_all", is_gemm), ("gemm_main_stream", lambda k: is_gemm(k) and not is_vit(k))):
         g = group(pred)
         g["bytes_per_launch"] = int((g["fetch_bytes_per_step"] + g["write_bytes_per_step"]) / max(1, g["launches_per_step"]))
