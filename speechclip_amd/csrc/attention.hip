@@ -28,6 +28,20 @@ constexpr int NSTAGE = 3;
 // -DSC_ATTN_PP=1 (build option): the two waves a SIMD holds of one 8-wave block (w and w + 4) run half a tile apart -- waves 4-7 enter one
 // barrier interval late, two barriers per tile (after S = K.Q^T and after the softmax arithmetic) keep the offset, so one half's softmax (VALU)
 // always runs beside the other half's P.V + next K.Q^T (MFMA).  Needs a 4-slot K/V ring (a tile stays in use for four intervals).
+// Timing probes and measured-and-rejected variants (SC_ATTN_ABL, SC_ATTN_NOBAR, SC_ATTN_PP, SC_ATTN_VEARLY; env SC_ATTN_NW / SC_ATTN_QB / SC_ATTN_IPB) are
+// honoured only in the PROBES build (`make PROBES=1`, -DSC_PROBES=1); the product library compiles the default form alone.
+#ifndef SC_PROBES
+#define SC_PROBES 0
+#endif
+#if !SC_PROBES
+#undef SC_ATTN_ABL
+#undef SC_ATTN_NOBAR
+#undef SC_ATTN_PP
+#undef SC_ATTN_VEARLY
+#define SC_ATTN_ENV_INT(name, dflt) (dflt)
+#else
+#define SC_ATTN_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#endif
 #ifndef SC_ATTN_PP
 #define SC_ATTN_PP 0
 #endif
@@ -603,7 +617,7 @@ __global__ __launch_bounds__(256) void cls_pool_kernel(const bf16_t* __restrict_
 static bool g_attn_trace_host = false;
 extern "C" void sc_debug_set_attn_trace(void* dev_buf) {     // per-block [8] u64: QK / softmax / PV / wait cycles, tiles, start, end (100 MHz)
     unsigned long long* p = (unsigned long long*)dev_buf;
-    g_attn_trace_host = dev_buf != nullptr;
+    g_attn_trace_host = SC_PROBES && dev_buf != nullptr;      // the product library instantiates no TRACE variant (`make PROBES=1`)
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &p, sizeof(p));
 }
 
@@ -618,9 +632,9 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
                  "sc_attention_fwd_dropout: B*H*T*T must fit 32 bits (mask element index)");
     if (B <= 0 || T <= 0) return 0;
     // 8-wave blocks (256 query rows share the K/V ring) when there are at least 256 queries; SC_ATTN_NW=4 forces the 4-wave form
-    static const int force_nw = getenv("SC_ATTN_NW") ? atoi(getenv("SC_ATTN_NW")) : 0;
+    static const int force_nw = SC_ATTN_ENV_INT("SC_ATTN_NW", 0);
     // SC_ATTN_QB=2 (A/B): 4 waves x 64 query rows instead of 8 waves x 32 for the long-sequence form
-    static const int qb_env = getenv("SC_ATTN_QB") ? atoi(getenv("SC_ATTN_QB")) : 1;
+    static const int qb_env = SC_ATTN_ENV_INT("SC_ATTN_QB", 1);
     const bool qb2 = (qb_env == 2 || qb_env == 3) && T > 128 && !force_nw && drop_p == 0.f && !g_attn_trace_host;
     const int nw = force_nw ? force_nw : (qb2 ? (qb_env == 3 ? 8 : 4) : (T > 128 ? 8 : 4));
     const int lds = ((SC_ATTN_PP && nw == 8) ? 4 : NSTAGE) * STAGE_BYTES;
@@ -629,7 +643,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
     const int64_t units8 = ((int64_t)H * B + 7) / 8;
     SC_CHECK_ARG(units8 * 8 * nq < 0x7fffffff, "sc_attention_fwd: grid too large");
     const int n_ids = (int)(units8 * 8 * nq);
-    static const int ipb_env = getenv("SC_ATTN_IPB") ? atoi(getenv("SC_ATTN_IPB")) : 0;
+    static const int ipb_env = SC_ATTN_ENV_INT("SC_ATTN_IPB", 0);
     int ipb = ipb_env > 0 ? ipb_env : 1;
     ipb = ipb < 1 ? 1 : (ipb > 16 ? 16 : ipb);
     const int groups8 = (n_ids / 8 + ipb - 1) / ipb;           // n_ids is a multiple of 8
@@ -643,9 +657,14 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
                            (const bf16_t*)v, (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq, n_ids, ipb, \
                            seed, th, ks, row_off);                                                                                          \
     } while (0)
+#if SC_PROBES
     if (qb2) { if (nw == 8) ATTN_LAUNCH(8, false, false, 2); else ATTN_LAUNCH(4, false, false, 2); }
-    else if (th) { if (nw == 8) ATTN_LAUNCH(8, false, true); else ATTN_LAUNCH(4, false, true); }
+    else
+#endif
+    if (th) { if (nw == 8) ATTN_LAUNCH(8, false, true); else ATTN_LAUNCH(4, false, true); }
+#if SC_PROBES
     else if (g_attn_trace_host) { if (nw == 8) ATTN_LAUNCH(8, true, false); else ATTN_LAUNCH(4, true, false); }
+#endif
     else if (nw == 8) ATTN_LAUNCH(8, false, false);
     else ATTN_LAUNCH(4, false, false);
 #undef ATTN_LAUNCH

@@ -47,18 +47,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-// Cache policy of the 256-tile kernel's LDS-DMA pieces (build options for A/B runs; aux bit 0 = sc0, bit 1 = nt, bit 4 = sc1)
-#ifndef SC_GEMM_A_AUX
-#define SC_GEMM_A_AUX 0
+// Timing probes (SC_GEMM_ABL ablations, the per-phase s_memtime trace, the 2-slot-ring A/B switch) are compiled only into the PROBES build
+// (`make PROBES=1` -> libspeechclip_hip_probes.so, -DSC_PROBES=1); the product library instantiates the kernel without them.  The operand
+// cache-policy (nt / sc bits on the LDS-DMA pieces), buffer-form DMA, wave-priority and DMA-placement variants measured in rounds 1-2 are
+// recorded in DESIGN.md section 3.1 with their numbers and no longer live in this file.
+#ifndef SC_PROBES
+#define SC_PROBES 0
 #endif
-#ifndef SC_GEMM_W_AUX
-#define SC_GEMM_W_AUX 0
+// host-side A/B knobs (tile order, epilogue mode, dispatcher thresholds): environment variables in the PROBES build, constants in the product
+#if SC_PROBES
+#define SC_TUNE_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define SC_TUNE_SET(name) (getenv(name) != nullptr)
+#else
+#define SC_TUNE_INT(name, dflt) (dflt)
+#define SC_TUNE_SET(name) false
 #endif
-template <int AUX>
-__device__ __forceinline__ void glds16_aux(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
-}
 
 // Stage a ROWS x 64 bf16 tile: LDS image is [row][8 chunks of 16 B], chunk position p of row r holds
 // global k-chunk (p ^ (r & 7)).  256 threads => 32 rows per pass.
@@ -204,15 +207,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 //  * epilogue: bias/activation in registers -> bf16 -> wave-private LDS image -> full-row 16-byte stores
 //    (the direct fragment-shaped store is 32 x 8-byte stores per lane touching 16 lines each: issue-bound).
 constexpr int BK2 = 64;
-// -DSC_GEMM_BUFDMA=1 (build option, off): the LDS-DMA pieces go out as `buffer_load_dwordx4 ... offen lds` (one SGPR resource per operand and tile,
-// ONE loop-invariant 32-bit lane offset, the k / row-group offset in an SGPR) instead of `global_load_lds_dwordx4` on a 64-bit per-lane address.
-// Round-2 PMC (profiles/r02_gemm_qkv_pmc_stalls.txt) showed the global form costing 8 scalar + 5 vector instructions per piece -- 120 of the ~290
-// instructions a wave issues per k-step next to its 64 MFMAs; the buffer form needs 2 scalar ones (197 per k-step).  Same results on the whole GEMM test
-// suite, and the SAME time on every shape of the step (qkv 851 vs 850, fc1 812-828 vs 802-816, fc2 1104 vs 1131-1138, conv1 1076-1078 vs 1068-1071 TF/s;
-// step 46.66 vs 46.58 ms): the loop is not instruction-issue bound either.  The k-loop peeling that came with it (no piece behind a branch) is kept.
-#ifndef SC_GEMM_BUFDMA
-#define SC_GEMM_BUFDMA 0
-#endif
 constexpr int SLOT_BYTES = 2 * 256 * BK2 * 2;  // 64 KiB: A [256][128 B] then B [256][128 B]
 
 // Source addressing of one tile: two WAVE-UNIFORM tile base pointers (SGPRs) + two 32-bit per-lane offsets fixed for the whole
@@ -319,21 +313,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         return true;
     };
 
-#ifndef SC_GEMM_PRIO      // wave priority in the k-loop: 1 = no s_setprio at all (default: -0.2 ms per step over 7 same-box A/B passes against 0), 0 = priority 1
-#define SC_GEMM_PRIO 1    // inside every half-step (the round-1 form), 2 = static priority 1 for the second-dispatched half of the workgroup (waves 4-7,
-#endif                    // the SIMD partners of waves 0-3), 3 = static priority 1 for waves 0-3
-#if SC_GEMM_PRIO == 2
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#elif SC_GEMM_PRIO == 3
-    if (wave < 4) __builtin_amdgcn_s_setprio(1);
-#endif
+    // (no s_setprio anywhere in the k-loop: -0.2 ms per step against priority 1 inside every half-step, 7 of 7 same-box A/B passes, round 2)
     unsigned long long t_begin = TRACE ? __builtin_readcyclecounter() : 0, t_wait = 0, t_loop = 0, t_pre = 0;
     const int64_t lda64 = 64 * p.lda, ldw64 = 64 * p.ldw;
     const int lane_a = (tid >> 3) * (int)p.lda + (((tid & 7) ^ ((tid >> 3) & 7)) << 3);   // row (tid>>3), swizzled k-chunk
     const int lane_w = (tid >> 3) * (int)p.ldw + (((tid & 7) ^ ((tid >> 3) & 7)) << 3);
-#if SC_GEMM_BUFDMA
-    const int lane_a_b = lane_a * 2, lane_w_b = lane_w * 2;       // byte offsets of this lane inside a 64-row group (buffer form)
-#endif
     auto tile_m0 = [&](int t) -> int64_t { const int64_t m = (int64_t)t * 256; return m + 256 <= p.M ? m : p.M - 256; };
     auto tile_n0 = [&](int t) -> int { const int n = t * 256; return n + 256 <= p.N ? n : p.N - 256; };
     // ABL 8 (timing probe, garbage results): every tile reads its A rows from the first 2048 rows -- distinct lines per k-step, but L2-resident:
@@ -342,32 +326,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     int tm, tn, tz;
     bool have = tile_of(0, tm, tn, tz);
     StageAddr sa{nullptr, nullptr};
-#if SC_GEMM_BUFDMA
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
-    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
-#endif
-    auto set_tile = [&](const bf16_t* ta, const bf16_t* tw) {
-        sa = StageAddr{ta, tw};
-#if SC_GEMM_BUFDMA
-        ra = __builtin_amdgcn_make_buffer_rsrc((void*)ta, 0, 0x7fffffff, 0x00020000);      // per-tile bases: every offset below stays far inside 2 GiB
-        rw = __builtin_amdgcn_make_buffer_rsrc((void*)tw, 0, 0x7fffffff, 0x00020000);
-#endif
-    };
+    auto set_tile = [&](const bf16_t* ta, const bf16_t* tw) { sa = StageAddr{ta, tw}; };
     // one LDS-DMA piece (64 rows x 128 B... 8 rows per wave): row group g of A / W at k offset k0 (elements) into LDS at dst
-    auto piece_a = [&](int g, int k0, char* dst) {
-#if SC_GEMM_BUFDMA
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, lane_a_b, (int)((g * lda64 + k0) * 2), 0, 0);
-#else
-        glds16_aux<SC_GEMM_A_AUX>(sa.ta + (g * lda64 + k0) + lane_a, dst);
-#endif
-    };
-    auto piece_w = [&](int g, int k0, char* dst) {
-#if SC_GEMM_BUFDMA
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, lane_w_b, (int)((g * ldw64 + k0) * 2), 0, 0);
-#else
-        glds16_aux<SC_GEMM_W_AUX>(sa.tw + (g * ldw64 + k0) + lane_w, dst);
-#endif
-    };
+    auto piece_a = [&](int g, int k0, char* dst) { glds16(sa.ta + (g * lda64 + k0) + lane_a, dst); };
+    auto piece_w = [&](int g, int k0, char* dst) { glds16(sa.tw + (g * ldw64 + k0) + lane_w, dst); };
     int tail_ops = 0;   // vector-memory operations the previous epilogue issued after the next tile's stage-0 pieces (0 = unknown: drain)
     // q-th prologue DMA instruction of a tile, in issue order: A(0) x4, W(0) x4, A(1) x4, W(1) x4
     constexpr int NPRO = 16;
@@ -425,9 +387,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         auto half_step = [&](auto dma_tag, const char* srcA, const char* srcW, int off, bool load_next, int dma_k0, char* dma_slot, int dma_ka0, char* dma_aslot) {
             constexpr bool DMA = decltype(dma_tag)::value;      // compile-time: the loop is peeled, no piece sits behind a run-time test
             bf16x8_t bn[4];
-#if SC_GEMM_PRIO == 0
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (ABL == 4) {   // perf probe only (results are garbage): same operand traffic, half as many 32x32x16 MFMAs
@@ -455,23 +414,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                             if (i < 4) piece_a(i, dk, dma_slot + (i * 512 + wave * 64) * 16);
                             else piece_w(i - 4, dk, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
                         } else {
-#ifndef SC_GEMM_RING3_LATE     // one piece every other MFMA group (1, 3, 5, 7): the 8 pieces of a k-step spread evenly over its 16 groups
-#ifndef SC_GEMM_RING3_PHASE
-#define SC_GEMM_RING3_PHASE 0
-#endif
-#ifndef SC_GEMM_RING3_EARLY
-#define SC_GEMM_RING3_EARLY 0
-#endif
-#if SC_GEMM_RING3_EARLY == 1   // pieces in MFMA groups 0..3 of their half-step: the last W piece gets 0.81 instead of 0.63 k-steps of lead
-                            const bool slot_ = i < 4; const int g_ = i;
-#elif SC_GEMM_RING3_EARLY == 2 // groups 0, 1, 2, 4
-                            const bool slot_ = i < 3 || i == 4; const int g_ = i < 3 ? i : 3;
-#else
-                            const bool slot_ = (i & 1) == SC_GEMM_RING3_PHASE; const int g_ = i >> 1;
-#endif
-#else                          // (measured alternative: groups 4..7 of each half-step -- two bursts per k-step: -5 ... 0 %)
-                            const bool slot_ = i >= 4; const int g_ = i - 4;
-#endif
+                            // one piece in MFMA groups 0, 2, 4, 6 of each half-step: the 8 pieces of a k-step spread evenly over its 16 groups
+                            // (measured alternatives, DESIGN.md section 3.1: odd groups +0.17 ms per step, groups 0-3 +-0.05, groups 4-7 -5 ... 0 %)
+                            const bool slot_ = (i & 1) == 0; const int g_ = i >> 1;
                             if (slot_) {
                                 if (dma_k0 >= 0) piece_w(g_, dma_k0, dma_slot + (g_ * 512 + wave * 64) * 16);
                                 else if (dma_ka0 >= 0) piece_a(g_, dma_ka0, dma_aslot + (g_ * 512 + wave * 64) * 16);
@@ -481,9 +426,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#if SC_GEMM_PRIO == 0
-            __builtin_amdgcn_s_setprio(0);
-#endif
             if (load_next) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bfr[j] = bn[j];
@@ -820,8 +762,11 @@ int launch256(const GemmParams& p, hipStream_t s) {
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     const int ntiles = p.tiles_m * p.tiles_n;
     int grid = ntiles < n_cu ? ntiles : n_cu;
-    // instrumentation switches, read once: SC_GEMM_GRID caps the number of blocks (per-CU vs chip-wide limits), SC_GEMM_ABL ablates
-    // 1 = the LDS-DMA in the main loop, 2 = the MFMAs, 3 = the epilogue stores (results are garbage; timing only)
+#if SC_PROBES
+    // PROBES build only.  Instrumentation switches, read once: SC_GEMM_GRID caps the number of blocks (per-CU vs chip-wide limits), SC_GEMM_ABL
+    // ablates 1 = the LDS-DMA in the main loop, 2 = the MFMAs, 3 = the epilogue stores, 4 = 32x32x16 MFMAs, 5 / 6 = half / a quarter of the
+    // fragment reads, 7 = DMA re-reads k-chunk 0, 8 = A rows from an L2-resident window (results are garbage; timing only);
+    // SC_GEMM_RING3=0 selects the two-slot [A|W] ring; sc_debug_set_gemm_trace records per-phase s_memtime stamps
     static const int grid_cap = getenv("SC_GEMM_GRID") ? atoi(getenv("SC_GEMM_GRID")) : 0;
     static const char* abl = getenv("SC_GEMM_ABL");
     if (grid_cap > 0 && grid_cap < grid) grid = grid_cap;
@@ -836,11 +781,11 @@ int launch256(const GemmParams& p, hipStream_t s) {
     if (abl && abl[0] == '6') return launch256_var<6, false>(p, grid, s);
     if (abl && abl[0] == '7') return launch256_var<7, false>(p, grid, s);
     if (abl && abl[0] == '8') return launch256_var<8, false, true>(p, grid, s);
-    // Default: the three-slot A ring with the refill spread over all 16 MFMA groups of a k-step (RING3 in gemm256_kernel).  SC_GEMM_RING3=0 selects
-    // the two-slot [A|W] ring (A/B; also what the folded-LayerNorm epilogue variants use).
     static const bool ring3 = !(getenv("SC_GEMM_RING3") && atoi(getenv("SC_GEMM_RING3")) == 0);
-    if (ring3) return launch256_var<0, false, true>(p, grid, s);
-    return launch256_var<0, false>(p, grid, s);
+    if (!ring3) return launch256_var<0, false>(p, grid, s);
+#endif
+    // the three-slot A ring with the refill spread over all 16 MFMA groups of a k-step (RING3 in gemm256_kernel)
+    return launch256_var<0, false, true>(p, grid, s);
 }
 
 template <int BM, int BN>
@@ -866,8 +811,8 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
                  "sc_gemm: A/W/C must be 16-byte aligned");
     if (batch == 1 && p.N >= 256 && p.M >= 256 && p.K % 64 == 0) {
         const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-        static const int min_tiles = getenv("SC_GEMM_MIN_TILES") ? atoi(getenv("SC_GEMM_MIN_TILES")) : 100;
-        static const bool force_v1 = getenv("SC_GEMM_V1") != nullptr;
+        static const int min_tiles = SC_TUNE_INT("SC_GEMM_MIN_TILES", 100);
+        static const bool force_v1 = SC_TUNE_SET("SC_GEMM_V1");
         if (t256 >= min_tiles && !force_v1) {
             p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (p.N + 255) / 256;
             if (p.band < 0) p.band = p.tiles_n >= 16 ? 4 : 0;   // measured: 8192^3 +20 %; N <= 3072 (the step's shapes) neutral
@@ -876,7 +821,7 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
     }
     if (batch > 1 && p.inner == 0 && !p.bias && !p.residual && p.act == SC_ACT_NONE && p.N >= 256 && p.M >= 256) {
         // independent same-shape products (split-K partials of a weight gradient) on the 256-tile kernel: one persistent tile list over all of them
-        static const bool no_b256 = getenv("SC_GEMM_NOBATCH256") != nullptr;
+        static const bool no_b256 = SC_TUNE_SET("SC_GEMM_NOBATCH256");
         const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * (int64_t)batch;
         if (!no_b256 && t256 >= 100 && t256 < 0x7fffffff) {
             p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (p.N + 255) / 256;
@@ -903,7 +848,8 @@ int sc_vendor_gemm_try(const void* A, int64_t lda, const void* W, int64_t ldw, v
 static int g_last_path = 0;   // 0: hand-written kernels of this file, 1: vendor library (instrumentation: which kernel a bench launch hit)
 extern "C" int sc_gemm_last_path(void) { return g_last_path; }
 static unsigned long long* g_gemm_trace = nullptr;
-extern "C" void sc_debug_set_gemm_trace(void* dev_buf) { g_gemm_trace = (unsigned long long*)dev_buf; }
+// per-phase s_memtime stamps of the 256-tile kernel: effective only in the PROBES build (the product library instantiates no TRACE variant)
+extern "C" void sc_debug_set_gemm_trace(void* dev_buf) { g_gemm_trace = SC_PROBES ? (unsigned long long*)dev_buf : nullptr; }
 
 extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                             const float* bias, const void* residual, int64_t ldr, int64_t M, int N, int K,
@@ -922,13 +868,13 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     p.M = M; p.N = N; p.K = K;
     p.act = flags & SC_GEMM_ACT_MASK; p.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0;
     p.trace = g_gemm_trace;
-    // tuning knobs kept for A/B timing (read once); the defaults are the measured best
-    static const int k_rot = getenv("SC_GEMM_NOROT") ? 0 : 1;
-    static const int k_band = getenv("SC_GEMM_BAND") ? atoi(getenv("SC_GEMM_BAND")) : -1;   // -1: chosen by the dispatcher
-    static const int k_epi = getenv("SC_GEMM_EPI") ? atoi(getenv("SC_GEMM_EPI")) : 2;
-    static const int k_epi_res = getenv("SC_GEMM_EPI_RES") ? atoi(getenv("SC_GEMM_EPI_RES")) : 2;   // 2 since late round 2 (four-ahead residual ring): -0.13 ms per step vs 3 in 7 of 7 A/B passes
+    // the measured best (A/B knobs of the PROBES build: SC_GEMM_NOROT, SC_GEMM_BAND, SC_GEMM_EPI, SC_GEMM_EPI_RES, SC_GEMM_NOKPAIR)
+    static const int k_rot = SC_TUNE_SET("SC_GEMM_NOROT") ? 0 : 1;
+    static const int k_band = SC_TUNE_INT("SC_GEMM_BAND", -1);   // -1: chosen by the dispatcher
+    static const int k_epi = SC_TUNE_INT("SC_GEMM_EPI", 2);
+    static const int k_epi_res = SC_TUNE_INT("SC_GEMM_EPI_RES", 2);   // 2 since late round 2 (four-ahead residual ring): -0.13 ms per step vs 3 in 7 of 7 A/B passes
     p.rot = k_rot; p.band = k_band; p.epi_mode = k_epi; p.epi_mode_res = k_epi_res;
-    static const int k_pair = getenv("SC_GEMM_NOKPAIR") ? 0 : 1;
+    static const int k_pair = SC_TUNE_SET("SC_GEMM_NOKPAIR") ? 0 : 1;
     if (k_pair && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) p.kpair = (int)(lda / 2 / 64);   // k = 3, stride-2 conv layers of the extractor
     return gemm_dispatch(p, 1, (hipStream_t)stream);
 }

@@ -587,3 +587,14 @@ def test_packed_geometry_covers_the_receptive_field_halo():
     # equal lengths: nothing to gain, one extra row per utterance at most
     geo = enc.packed_geometry([160000] * 4, 160000, need_rows=[499] * 4)
     assert geo["rows"] == [500] * 4 and geo["total"] == geo["padded_rows"]
+
+
+def test_product_library_links_no_vendor_blas():
+    """The shipped libspeechclip_hip.so contains no vendor GEMM: hipBLASLt is reachable only through the separate comparator library
+    (libspeechclip_vendor_cmp.so), dlopen()ed when bench.py's comparator leg registers a workspace."""
+    import subprocess
+    from speechclip_amd import _lib
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout.lower()
+    assert "blas" not in out and "miopen" not in out, out
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "hipblas" not in syms.lower()

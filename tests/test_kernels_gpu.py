@@ -118,28 +118,6 @@ def test_flash_attention(B, T, H, lens):
     torch.testing.assert_close(y.float(), ref, atol=2e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("qb", ["2", "3"])
-def test_flash_attention_two_query_blocks_per_wave(qb):
-    """SC_ATTN_QB=2 / 3 (opt-in A/B forms: 4 or 8 waves x 64 query rows, every K / V fragment read feeds two MFMAs) against the same fp32
-    reference; the switch is read once per process, so the cases run in a child process."""
-    import os, subprocess, sys, textwrap
-    code = textwrap.dedent("""
-        import os, sys, torch
-        sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-        from test_kernels_gpu import _attn_ref, _g, BF
-        from speechclip_amd import ops
-        for B, T, H, lens in [(3, 500, 12, [500, 499, 37]), (2, 129, 2, [1, 64]), (2, 319, 16, [319, 65]), (1, 700, 3, [513]), (2, 256, 1, None)]:
-            qkv = torch.randn(B * T, 3 * H * 64, generator=_g(T + H)).to("cuda", BF)
-            klens = torch.tensor(lens, dtype=torch.int32, device="cuda") if lens is not None else None
-            y = ops.attention(qkv, B, T, H, klens)
-            torch.testing.assert_close(y.float(), _attn_ref(qkv, B, T, H, klens), atol=2e-2, rtol=2e-2)
-        print("QB_OK")
-    """)
-    env = dict(os.environ, SC_ATTN_QB=qb)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert "QB_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
-
-
 def test_flash_attention_online_softmax_rescale():
     """Force a late, much larger score so the running max jumps at the last tile (rule 26)."""
     from speechclip_amd import ops

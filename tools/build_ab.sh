@@ -14,5 +14,7 @@ IN=$CS/$SRC
 if [ -n "$REV" ]; then IN=$ROOT/tools/ab/${NAME}_$SRC; git -C $ROOT show $REV:speechclip_amd/csrc/$SRC > $IN; fi
 hipcc $FLAGS $EXTRA -c $IN -o $ROOT/tools/ab/${NAME}_${SRC%.hip}.o
 OBJS=$(ls $CS/*.o | grep -v "/${SRC%.hip}.o$")
-hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $ROOT/tools/ab/${NAME}_${SRC%.hip}.o -L/opt/rocm/lib -lhipblaslt -Wl,-rpath,/opt/rocm/lib -o $ROOT/tools/ab/lib$NAME.so
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $ROOT/tools/ab/${NAME}_${SRC%.hip}.o -ldl -o $ROOT/tools/ab/lib$NAME.so
+# the comparator library is looked up next to the library that loads it
+cp -f $ROOT/speechclip_amd/libspeechclip_vendor_cmp.so $ROOT/tools/ab/ 2>/dev/null || true
 ls -la $ROOT/tools/ab/lib$NAME.so
