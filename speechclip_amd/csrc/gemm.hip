@@ -54,6 +54,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 #ifndef SC_PROBES
 #define SC_PROBES 0
 #endif
+#ifndef SC_GEMM_FAST_EPI          // 0: every tile takes the general (predicated) epilogue; 1: fast path for the variants without a residual operand;
+#define SC_GEMM_FAST_EPI 1        // 2: also for the residual variants (A/B builds)
+#endif
 // host-side A/B knobs (tile order, epilogue mode, dispatcher thresholds): environment variables in the PROBES build, constants in the product
 #if SC_PROBES
 #define SC_TUNE_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
@@ -456,20 +459,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             mid_sync(kt);
             half_step(F_{}, a_slot(kt + 1), w_slot(kt + 1), off_h0, true, -1, nullptr, -1, nullptr);
         }
+        // bias for this lane's 4 x 4 output columns: loaded BEFORE the next tile's LDS-DMA is issued (an ordinary load
+        // issued behind the DMA would have to drain it first: vmcnt is in-order)
+        f32x4_t bias4[4];
+        auto load_bias = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nn = n0 + wn * 64 + j * 16 + fk * 4;
+                bias4[j] = p.bias ? *(const f32x4_t*)(p.bias + nn) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+        };
         {   // last k-step (peeled: nothing left to prefetch after its first half)
             const int kl = nk - 1;
             half_step(F_{}, a_slot(kl), w_slot(kl), off_h1, true, -1, nullptr, -1, nullptr);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             half_step(F_{}, nullptr, nullptr, 0, false, -1, nullptr, -1, nullptr);
         }
-        // bias for this lane's 4 x 4 output columns: loaded BEFORE the next tile's LDS-DMA is issued (an ordinary load
-        // issued behind the DMA would have to drain it first: vmcnt is in-order)
-        f32x4_t bias4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nn = n0 + wn * 64 + j * 16 + fk * 4;
-            bias4[j] = p.bias ? *(const f32x4_t*)(p.bias + nn) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        }
+        load_bias();    // (measured, round 3: loading them before the last half-step instead -- latency under 32 MFMAs -- costs +1.5 ms per step)
         f32x4_t c4[4];
         float2 rs_acc[8];
         if (EPI == 1) {   // folded-LN operands in the accumulator layout: c for this lane's 16 columns, (mean, rstd) for its 8 rows
@@ -500,7 +506,83 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 
         if (TRACE) { unsigned long long t = __builtin_readcyclecounter(); t_pre += t - t_begin; t_begin = t; }
         // ------------------------------------------------------------------------------------------ epilogue
-        if (vec_ok) {
+        // FAST PATH (round 3): interior tile + bf16 vector stores + a next tile with at least two k-steps.  The general path below predicates
+        // every store on (m >= m_lo && n >= n_lo) and recomputes kofs() -- with its rot / kpair branches -- for each of the 16 prologue pieces:
+        // ~40 basic blocks per epilogue, which pins every ds_bpermute result wait directly in front of its store (no scheduling across a
+        // block boundary) and costs ~250 scalar predicate / address instructions per wave.  Here nothing is predicated, the two k offsets of
+        // the next tile's prologue are computed once, stores and residual loads run off one per-lane base pointer + uniform row steps, and
+        // row block i + 1's convert / permlane / crossbar shuffles are issued BEFORE row block i's stores, so the shuffle latency hides
+        // under the stores and the next tile's LDS-DMA pieces.  sched_barrier between row blocks keeps the issue order of the vector-memory
+        // operations what `tail_ops` below counts on.
+        const bool fast_epi = SC_GEMM_FAST_EPI && (!RES || SC_GEMM_FAST_EPI >= 2) && vec_ok && EPI == 0 && nhave && nk >= 2 && emode == 2 && m0 == m_lo && n0 == n_lo;
+        if (fast_epi) {
+            bf16_t* Cb = (bf16_t*)p.C + c_off;
+            const int srow = lane >> 2, schunk = lane & 3;
+            const int src_fk = ((schunk & 1) << 1) | (schunk >> 1);
+            const int bperm = (src_fk * 16 + srow) << 2;
+            const int ncol0 = n0 + wn * 64 + schunk * 8;
+            const int64_t mrow0 = m0 + wm * 128 + srow;
+            bf16_t* cptr = Cb + mrow0 * p.ldc + ncol0;
+            const bf16_t* rptr = RES ? (const bf16_t*)p.residual + mrow0 * p.ldr + ncol0 : nullptr;
+            const int64_t cstep = 16 * p.ldc, rstep = 16 * p.ldr;
+            const int kq0 = kofs(0), kq1 = kofs(1);                      // `rot` already addresses the next tile
+            auto issue_fast = [&](int q) {                                // q-th prologue DMA instruction: A(0) x4, W(0) x4, A(1) x4, W(1) x4
+                const int st = q >> 3, g = q & 7;
+                const int k0 = st ? kq1 : kq0;
+                if (g < 4) piece_a(g, k0, a_slot(st) + (g * 512 + wave * 64) * 16);
+                else piece_w(g - 4, k0, w_dst(st) + ((g - 4) * 512 + wave * 64) * 16);
+            };
+            uint4 res[RES ? 4 : 1][2];
+            auto load_res_fast = [&](int i) {
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) res[i & 3][jp] = *(const uint4*)(rptr + i * rstep + jp * 32);
+            };
+            if (RES) { load_res_fast(0); load_res_fast(1); load_res_fast(2); load_res_fast(3); }
+            auto shuffled = [&](int i, uint4 (&o)[2]) {                  // row block i: bias / activation -> bf16 -> 16 rows x 64 contiguous bytes per store
+                uint2 pk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4_t v4 = acc[i][j] + bias4[j];
+                    if (ACT == SC_ACT_GELU) {
+                        const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
+                        v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+                    } else if (ACT == SC_ACT_QUICKGELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
+                    }
+                    pk[j].x = pack2bf(v4[0], v4[1]);
+                    pk[j].y = pack2bf(v4[2], v4[3]);
+                }
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].x, pk[2 * jp + 1].x, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].y, pk[2 * jp + 1].y, false, false);
+                    o[jp] = make_uint4(__builtin_amdgcn_ds_bpermute(bperm, r0[0]), __builtin_amdgcn_ds_bpermute(bperm, r1[0]),
+                                       __builtin_amdgcn_ds_bpermute(bperm, r0[1]), __builtin_amdgcn_ds_bpermute(bperm, r1[1]));
+                }
+            };
+            uint4 oc[2][2];
+            shuffled(0, oc[0]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i + 1 < 8) shuffled(i + 1, oc[(i + 1) & 1]);          // next block's shuffles fly under this block's stores
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    uint4 o = oc[i & 1][jp];
+                    if (RES) {
+                        const uint4 rv = res[i & 3][jp];
+                        o.x = pack2bf(lo2f(o.x) + lo2f(rv.x), hi2f(o.x) + hi2f(rv.x));
+                        o.y = pack2bf(lo2f(o.y) + lo2f(rv.y), hi2f(o.y) + hi2f(rv.y));
+                        o.z = pack2bf(lo2f(o.z) + lo2f(rv.z), hi2f(o.z) + hi2f(rv.z));
+                        o.w = pack2bf(lo2f(o.w) + lo2f(rv.w), hi2f(o.w) + hi2f(rv.w));
+                    }
+                    *(uint4*)(cptr + i * cstep + jp * 32) = o;
+                }
+                if (RES && i + 4 < 8) load_res_fast(i + 4);               // slot i & 3 was consumed just above
+                issue_fast(2 * i); issue_fast(2 * i + 1);       // (all 8 stage-0 pieces before the first store instead: +-0.02 ms per step, round 3)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (vec_ok) {
             // Lane (frow, fk) holds row frow, columns 16j + 4fk .. +3 of each 16-column block j.  v_permlane16_swap between the
             // 16-lane rows fk and fk^1 regroups a block PAIR (j0, j1) so that even-fk lanes own 8 consecutive columns of j0 and
             // odd-fk lanes 8 consecutive columns of j1 (16 bytes per lane).  Stored from there, the four lanes of every lane QUAD
