@@ -188,3 +188,34 @@ def test_two_level_batched_products_vs_torch():
     x = q.float().view(B, T, 3, H, 64)
     refS = torch.einsum("bihd,bjhd->bhij", x[:, :, 0], x[:, :64, 1]).reshape(B * H, T, 64)
     torch.testing.assert_close(S.cpu()[:, :, :64], refS, atol=0.1, rtol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K,lda", [(128000, 768, 768, None), (32768, 2304, 256, None), (40960, 512, 1536, 1024), (65536, 512, 1024, 1024),
+                                       (23040, 3072, 768, None), (30720, 768, 3072, None), (196608, 256, 512, None), (15360, 1280, 384, None)])
+@pytest.mark.parametrize("act,use_res", [(0, False), (1, False), (0, True), (2, False), (1, True)])
+def test_gemm_large_full_tile_shapes(M, N, K, lda, act, use_res):
+    """Large shapes made of interior 256 x 256 tiles only (M, N multiples of 256): every tile takes the branch-free fast epilogue (plain / GELU /
+    QuickGELU) or the residual epilogue; with and without bias; run-to-run bitwise stable.  (The shape list is the one the round-3 staggered
+    two-group kernel was validated on: profiles/r03_gemm_stagger_experiment.txt.)"""
+    from speechclip_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + act)
+    ld = lda or K
+    flat = (torch.randn(M * ld + K + 8, generator=g) * 0.5).to("cuda", torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16)
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to("cuda", torch.bfloat16) if use_res else None
+    y = ops.gemm(flat, w, bias, act, res, M=M, K=K, lda=ld)
+    y2 = ops.gemm(flat, w, bias, act, res, M=M, K=K, lda=ld)
+    assert torch.equal(y, y2), "not run-to-run deterministic"
+    a = torch.as_strided(flat, (M, K), (ld, 1))
+    # reference in row chunks (fp32 [M, N] of the largest shape is 1.5 GB: fine, but keep the peak low)
+    worst = 0.0
+    for r0 in range(0, M, 16384):
+        sl = slice(r0, min(M, r0 + 16384))
+        ref = _ref(a[sl], w, bias, act, res[sl] if use_res else None)
+        torch.testing.assert_close(y[sl].float(), ref, atol=2e-2, rtol=2e-2)
+        worst = max(worst, (y[sl].float() - ref).abs().max().item())
+    # no bias, too
+    y0 = ops.gemm(flat, w, None, act, res, M=M, K=K, lda=ld)
+    ref0 = _ref(a[:4096], w, None, act, res[:4096] if use_res else None)
+    torch.testing.assert_close(y0[:4096].float(), ref0, atol=2e-2, rtol=2e-2)
