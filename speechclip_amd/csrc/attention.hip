@@ -45,6 +45,9 @@ constexpr int NSTAGE = 3;
 #ifndef SC_ATTN_PP
 #define SC_ATTN_PP 0
 #endif
+#ifndef SC_ATTN_LAZY_LOG2          // rescale threshold of the online softmax in log2 units (0: the textbook form, every rise of the maximum rescales)
+#define SC_ATTN_LAZY_LOG2 8.0f
+#endif
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -315,9 +318,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
         }
         asm volatile("" :: "v"(mx));   // phase boundary (also keeps the scheduler from interleaving the phases into a register-pressure peak)
         if (TRACE && qb == 0) stamp(tr_qk);           // S complete (the max depends on every MFMA result)
-        const float m_new = fmaxf(m_run[qb], mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);  // first tile: exp2(-inf) = 0
-        m_run[qb] = m_new;
+        // Lazy rescale (round 3): the kernel runs at the speed of its vector instruction stream (profiles/r03_attention_two_score_tile_experiment.txt), and
+        // rescaling O by alpha is 1/6 of that stream while the running maximum of SOME row of a wave moves on nearly every tile.  The reference
+        // maximum m_run therefore follows the true running maximum only when that rose by more than 2^SC_ATTN_LAZY_LOG2: otherwise P = exp2(s - m_run)
+        // is simply up to 2^8 instead of <= 1 (bf16 and the fp32 sums have the range; l_run uses the same reference, so the quotient is unchanged).
+        float alpha = 1.0f;
+        {
+            const float m_cand = fmaxf(m_run[qb], mx);
+            if (m_cand - m_run[qb] > SC_ATTN_LAZY_LOG2) {             // first tile: -inf -> finite
+                alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_cand);   // exp2(-inf) = 0 on the first tile
+                m_run[qb] = m_cand;
+            }
+        }
+        const float m_new = m_run[qb];
         f32x2_t psum2 = {0.f, 0.f};
         const float sc = partial ? 1.0f : scale_log2e;               // partial tiles were scaled while masking
 #pragma unroll
