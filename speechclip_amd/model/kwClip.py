@@ -194,10 +194,11 @@ class KWClipBase(BaseLightningModel):
         print("kw_hit_rate", hit_rate)
         if getattr(self, "logger", None) is not None:
             self.log("kw_hit_rate", {"kw_{}".format(i): hit_rate[i].item() for i in range(self.keyword_num)}, sync_dist=True)
-        with open(os.path.join(root, "kw_hit_ep{}.json".format(epoch)), "w") as f:
-            json.dump(kw_top_ret, f)
-        with open(os.path.join(root, "keywords_ep{}.json".format(epoch)), "w") as f:
-            json.dump(all_retok_outputs, f)
+        if parallel.world()[0] == 0:      # every rank holds the gathered outputs (validation_step_end): one writer
+            with open(os.path.join(root, "kw_hit_ep{}.json".format(epoch)), "w") as f:
+                json.dump(kw_top_ret, f)
+            with open(os.path.join(root, "keywords_ep{}.json".format(epoch)), "w") as f:
+                json.dump(all_retok_outputs, f)
         return hit_rate, kw_top_ret, all_retok_outputs
 
     def validation_epoch_end(self, outputs: list):

@@ -8,6 +8,7 @@ checkpoint key names (hubert.HubertModel) whose forward runs on HIP kernels.  No
 loaded only if it is already on disk ($SPEECHCLIP_HUBERT_CKPT or ~/.cache/speechclip_amd/<file name of the URL>).
 """
 import logging
+import math
 import os
 from typing import List, Tuple, Union
 
@@ -87,8 +88,13 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         for p in self.encoder.parameters():
             p.requires_grad = False
         self.encoder.eval()
-        # speech_encoder_plus.py:416-446: the listed transformer layers train (reinit_layers: re-initialised first, fairseq init_bert_params);
+        # speech_encoder_plus.py:416-446: the listed transformer layers train (reinit_layers: re-initialised first, as `layer.apply(init_weights)` does);
         # every other layer, pos_conv, layer_norm, the feature extractor and post_extract_proj stay frozen (feature_grad_mult = 0)
+        # KNOWN DIVERGENCE (documented in DESIGN.md section 5c): the reference freezes the unlisted layers, pos_conv, the FEATURE
+        # LayerNorm (`encoder.layer_norm`), the extractor and post_extract_proj -- but not `encoder.encoder.layer_norm`, the LayerNorm behind the
+        # positional conv of post-LN HuBERT-base, nor the never-reached mask_emb / final_proj / label_embs_concat.  That LayerNorm sits below
+        # every layer, so the reference back-propagates through ALL frozen layers just to train its 2 x 768 numbers.  Here it stays frozen and
+        # the backward stops at the lowest listed layer (`HubertLayersTrainFn` gets a detached input): trainable set = listed layers + mix + head.
         self.train_layers = sorted(set(int(i) for i in (list(reinit_layers) + list(unfreeze_layers))))
         # speech_encoder_plus.py:399-401: trainable without layer lists -- nothing is frozen: the conv feature extractor (its gradient scaled by
         # the checkpoint's feature_grad_mult [3P fairseq forward_features]), layer_norm, post_extract_proj, the positional conv and all layers train
@@ -110,13 +116,18 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             for i in self.train_layers:
                 lyr = self.encoder.encoder.layers[i]
                 if i in reinit_layers:
+                    # `layer.apply(init_weights)` (speech_encoder_plus.py:421, avssl/util/init_model.py): reset_parameters() of every sub-module,
+                    # children first -- torch's Linear / LayerNorm defaults -- then [3P fairseq] MultiheadAttention.reset_parameters on top of its
+                    # projections: xavier_uniform with gain 1/sqrt(2) on q / k / v, xavier_uniform on out_proj, out_proj.bias = 0 (the q / k / v
+                    # biases keep torch's uniform init)
                     for m in lyr.modules():
-                        if isinstance(m, nn.Linear):
-                            nn.init.normal_(m.weight, mean=0.0, std=0.02)
-                            nn.init.zeros_(m.bias)
-                        elif isinstance(m, nn.LayerNorm):
-                            nn.init.ones_(m.weight)
-                            nn.init.zeros_(m.bias)
+                        if isinstance(m, (nn.Linear, nn.LayerNorm)):
+                            m.reset_parameters()
+                    a = lyr.self_attn
+                    for proj in (a.k_proj, a.v_proj, a.q_proj):
+                        nn.init.xavier_uniform_(proj.weight, gain=1 / math.sqrt(2))
+                    nn.init.xavier_uniform_(a.out_proj.weight)
+                    nn.init.constant_(a.out_proj.bias, 0.0)
                 for p in lyr.parameters():
                     p.requires_grad = True
             self.encoder.feature_grad_mult = 0

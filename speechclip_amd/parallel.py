@@ -83,7 +83,13 @@ def gather_rows_dict(d: dict) -> dict:
     if ws == 1:
         return d
     B = d["id"].shape[0]
-    flt = {k: v for k, v in d.items() if torch.is_tensor(v) and v.is_floating_point() and v.dim() >= 2 and v.shape[0] == B}
+    # all_gather_into_tensor needs the same local batch on every rank (the reference's DataParallel splits evenly too): fail loudly otherwise
+    bmm = torch.tensor([B, -B], device=d["id"].device, dtype=torch.int64)
+    dist.all_reduce(bmm, op=dist.ReduceOp.MAX)
+    if int(bmm[0]) != B or int(-bmm[1]) != B:
+        raise ValueError(f"gather_rows_dict: local batch {B} differs across ranks (max {int(bmm[0])}, min {int(-bmm[1])}); use drop_last / equal shards")
+    # every float tensor whose dim 0 is the local batch is a row tensor, 1-D ones included ([B] -> [B, 1])
+    flt = {k: v for k, v in d.items() if torch.is_tensor(v) and v.is_floating_point() and v.dim() >= 1 and v.shape[0] == B}
     shapes = {k: v.shape[1:] for k, v in flt.items()}
     feats = {k: v.reshape(B, -1) for k, v in flt.items()}
     feats["id"] = d["id"]

@@ -336,7 +336,8 @@ def _one_collective_worker(rank, world, port, q):
     ok_grad = bool(torch.all(feats["parallel_audio_feat"].grad == 2) and torch.all(feats["cascaded_audio_feat"].grad == 3))
     calls.clear()
     others = {"id": feats["id"], "audio_feat": feats["parallel_audio_feat"].detach(), "image_feat": feats["image_feat"],
-              "keywords": torch.randn(B, 2, 4, generator=g), "gold_text": torch.arange(B * 5).view(B, 1, 5) + 100 * rank, "note": "x"}
+              "keywords": torch.randn(B, 2, 4, generator=g), "gold_text": torch.arange(B * 5).view(B, 1, 5) + 100 * rank, "note": "x",
+              "row_score": torch.randn(B, generator=g)}        # a 1-D per-row float tensor travels in the packed collective too
     go = parallel.gather_rows_dict(others)
     q.put((rank, n_train, ok_grad, len(calls), {k: (v.numpy().copy() if torch.is_tensor(v) else v) for k, v in go.items()},
            {k: (v.numpy().copy() if torch.is_tensor(v) else v) for k, v in others.items()},
@@ -363,7 +364,7 @@ def test_train_gather_is_one_collective_and_validation_outputs_are_gathered_gloo
         assert ok_grad
         assert n_val == 2, n_val                           # packed floats+ids, and the one integer tensor (gold_text)
         assert go["note"] == "x"
-    for k in ("id", "audio_feat", "image_feat", "keywords", "gold_text"):
+    for k in ("id", "audio_feat", "image_feat", "keywords", "gold_text", "row_score"):
         want = np.concatenate([res[0][5][k], res[1][5][k]], 0)
         for r in res:
             assert r[4][k].dtype == want.dtype and np.array_equal(r[4][k], want), k
@@ -516,7 +517,16 @@ def test_encoder_fine_tuning_flags_follow_the_reference():
     re = FairseqSpeechEncoder_Hubert("hubert", trainable=True, reinit_layers=[2], feat_select_idx="weighted_sum", hubert_config=hc)
     l2b, l2r = base.encoder.encoder.layers[2], re.encoder.encoder.layers[2]
     assert not torch.equal(l2b.fc1.weight, l2r.fc1.weight) and torch.equal(base.encoder.encoder.layers[1].fc1.weight, re.encoder.encoder.layers[1].fc1.weight)
-    assert float(l2r.fc1.bias.abs().max()) == 0.0 and abs(float(l2r.fc1.weight.std()) - 0.02) < 2e-3
+    # `layer.apply(init_weights)` = reset_parameters() of every sub-module, then fairseq MultiheadAttention.reset_parameters on top:
+    # fc1 / fc2: torch's kaiming-uniform Linear default (|w| <= 1/sqrt(fan_in), uniform biases); q / k / v: xavier_uniform with gain 1/sqrt(2)
+    # (bound sqrt(6 / (2 d)) / sqrt(2)); out_proj: xavier_uniform, zero bias; LayerNorms: ones / zeros
+    d = hc.encoder_embed_dim
+    assert float(l2r.fc1.weight.abs().max()) <= d ** -0.5 + 1e-6 and float(l2r.fc1.bias.abs().max()) > 0
+    assert abs(float(l2r.fc1.weight.std()) - d ** -0.5 / 3 ** 0.5) < 0.1 * d ** -0.5
+    qb = (6.0 / (2 * d)) ** 0.5 / 2 ** 0.5
+    assert float(l2r.self_attn.q_proj.weight.abs().max()) <= qb + 1e-6 and float(l2r.self_attn.q_proj.weight.abs().max()) > 0.9 * qb
+    assert float(l2r.self_attn.out_proj.weight.abs().max()) > qb and float(l2r.self_attn.out_proj.bias.abs().max()) == 0.0
+    assert float(l2r.self_attn.q_proj.bias.abs().max()) > 0 and torch.equal(l2r.final_layer_norm.weight, torch.ones(d))
     assert len(base.trainable_params()) == 1 and not any(p.requires_grad for p in base.encoder.parameters())
     # bare trainable=True (speech_encoder_plus.py:399-401): nothing is frozen; the extractor keeps the checkpoint's feature_grad_mult
     full = FairseqSpeechEncoder_Hubert("hubert", trainable=True, feat_select_idx="weighted_sum", hubert_config=hc)
