@@ -114,7 +114,7 @@ def test_recall_at_k_parity_on_a_trained_1000_pair_set():
         loss.backward()
         opt.step()
         sch["scheduler"].step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(math.isfinite(x) for x in losses)
     print(f"tail training: loss {sum(losses[:5]) / 5:.3f} -> {sum(losses[-5:]) / 5:.3f}")
     assert sum(losses[-20:]) / 20 < 0.5 * sum(losses[:5]) / 5, (losses[:5], losses[-5:])
