@@ -77,6 +77,7 @@ __global__ __launch_bounds__(NW * 64) void posconv_mfma_kernel(const bf16_t* __r
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const char* a_base = smem_pc + ((wave * 64 + frow) * CG + fk * 8) * 2;
+    const bool wave_live = t_start + wave * 64 < Tp;            // wave-uniform
     const int w_off0 = frow * 128 + ((fk ^ (frow & 7)) << 4), w_off1 = frow * 128 + (((4 + fk) ^ (frow & 7)) << 4);
 
     auto wait_mine = [&](bool keep_one) {                      // all of this wave's stages landed, except (keep_one) the newest
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(NW * 64) void posconv_mfma_kernel(const bf16_t* __r
         asm volatile("" ::: "memory");
         if (kt + 2 < nk) stage(kt + 2);                        // into the slot of stage kt-1
         const char* slot = ring + (kt % PC_NSTG) * STG;
+        if (!wave_live) continue;                                // (packed batches) this wave's 64 frames lie beyond the utterance: DMA + barriers only
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             bf16x8_t af[4], wf[NJ];
