@@ -222,6 +222,10 @@ def dry_run(args, world, rank):
     from speechclip_amd import parallel
     if world > 1:
         dist.init_process_group("gloo")
+    if args.global_batch is not None:
+        if args.global_batch % world:
+            sys.exit(f"bench.py: --global-batch {args.global_batch} is not divisible by {world} ranks")
+        args.batch = args.global_batch // world
     B, E = args.batch or 8, 512
     g = torch.Generator().manual_seed(7122 + rank)
 
@@ -250,7 +254,8 @@ def dry_run(args, world, rank):
     if rank == 0:
         print(json.dumps({"metric": "speech-image pairs/sec/node (dry run)", "value": round(world * B * args.steps / dt, 2), "unit": "pairs/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dry-run: launcher + exchange protocol on CPU/gloo, no kernels, not a measurement",
+                          "scaling": "strong" if args.global_batch is not None else "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "dry-run: launcher + exchange protocol on CPU/gloo, no kernels, not a measurement",
                           "config": {"workload": "dry run", "pairs_per_gpu": B, "global_batch": int(bg), "parallelism": f"dp{world}"},
                           "ranks_seen": int(seen.item()), "loss": round(float(loss), 5), "roofline": None, "cpu_baseline": None}), flush=True)
     if world > 1:

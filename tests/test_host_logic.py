@@ -453,6 +453,9 @@ def test_bench_gpus2_self_launches_and_runs_under_torchrun_dry_run():
     d = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                      "--master-port", str(_free_port()), bench, "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0", "--batch", "4"])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    # strong scaling: the GLOBAL batch is fixed and split over the ranks
+    d = _bench_line([sys.executable, bench, "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0", "--global-batch", "12"])
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 12 and d["config"]["pairs_per_gpu"] == 6 and d["n_gpus"] == 2
     # a launcher that started the wrong number of ranks is reported, not asserted on
     import subprocess
     r = subprocess.run([sys.executable, bench, "--gpus", "4", "--dry-run"], capture_output=True, text=True, cwd=root,
