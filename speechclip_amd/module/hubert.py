@@ -330,7 +330,10 @@ class HubertModel(nn.Module):
         dev = wav.device
 
         def buf(name, shape, dtype, dev_, zero=False):
-            return self._buf(name, shape, dtype, dev_, zero=zero, cap=pack is not None)
+            # every large workspace is ONE flat allocation per name that only grows: a job whose batch maximum (hence T) differs from step to step
+            # would otherwise keep a full set of buffers per distinct shape (tools/soak_varlen.py: +107 GB over ten distinct T before this).  The few
+            # small constant tables of the folded-LayerNorm path are keyed by shape (their `fresh` initialisation relies on it).
+            return self._buf(name, shape, dtype, dev_, zero=zero, cap=not name.startswith("ln_"))
         # packed bf16 operands are rebuilt when a load replaced the weights (post-hook) or an optimizer step moved TRAINABLE encoder weights:
         # ops.param_epoch moves on FusedAdam steps (raw-pointer writes), the tensors' own `_version` on any torch optimizer (the fallback of
         # configure_optimizers for optim.name != "Adam" / CPU params) or in-place edit; frozen encoders never repack

@@ -169,3 +169,28 @@ def test_unpack_rows_kernel():
         assert out[:, b, n:].abs().max().item() == 0 if n < 7 else True
     one = ops.unpack_rows(src[0].float().contiguous(), torch.tensor(off, dtype=torch.int32).cuda(), 4, 9)
     assert one.shape == (4, 9, 64) and torch.equal(one[2, :9], src[0, off[2]:off[2] + 9].float())
+
+
+def test_workspaces_do_not_multiply_with_the_batch_maximum():
+    """A job whose longest utterance differs from batch to batch must not keep a workspace set per distinct frame count (round 3: the padded
+    engine's shape-keyed buffers grew by 107 GB over ten distinct T at B = 256): every large buffer is one growing flat allocation per name."""
+    model, _, _ = _tiny(False)
+    enc = model.audio_encoder.encoder
+    sizes = []
+    for pack in ("0", "1"):
+        for lmax in (8000, 7000, 7680, 6100, 5000, 7990, 6400):
+            batch = _batch([lmax, lmax - 900, 2500, lmax - 10], seed=lmax)
+            old = os.environ.get("SC_VARLEN_PACK")
+            os.environ["SC_VARLEN_PACK"] = pack
+            try:
+                with torch.no_grad():
+                    model.forward_audio(batch["wav"], batch["wav_len"])
+            finally:
+                if old is None:
+                    os.environ.pop("SC_VARLEN_PACK")
+                else:
+                    os.environ["SC_VARLEN_PACK"] = old
+            sizes.append((len(enc._ws), sum(t.numel() * t.element_size() for t in enc._ws.values())))
+    n_first, b_first = sizes[0]
+    assert sizes[-1][0] <= n_first + 2, sizes                     # no new entries per shape
+    assert sizes[-1][1] <= 1.3 * max(s[1] for s in sizes[:1]) + 4096, sizes      # the largest batch came first: capacity never had to grow
