@@ -60,6 +60,33 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {   // two values: the p
 // (relative error 7e-6 on the positive side, |x| * 7e-6 absolute on the negative side).
 #define SC_GELU_P_C 4.25f
 #define SC_GELU_P_S 0.11072665f
+#ifndef SC_GELU_F16
+#define SC_GELU_F16 1
+#endif
+#if SC_GELU_F16
+// Default since round 3 (-DSC_GELU_F16=0: the fp32 degree-8 form below).  The GELU of every bf16-OUTPUT epilogue (conv stack, fc1, conv layer 0) is
+// evaluated in PACKED HALF precision (v_pk_*_f16: two elements per lane per full-rate instruction instead of one half-rate packed-fp32
+// instruction): Phi(x) = 0.5 + xc g(t), xc = clamp(x, +-4), t = xc^2 / 8 - 1, g = degree-6 minimax; the conversion to half rounds toward zero, so
+// |x| > 65504 saturates instead of overflowing.  Against the exact erf form (numpy float16 simulation, 2.2 M samples) the bf16-ROUNDED result has
+// 1.06x the rms error of rounding the exact value to bf16 (absolute error <= ~1e-3, in the negative tail where 0.5 + xc g cancels in half
+// precision): below the resolution of the bf16 activations it feeds.  Measured: -0.62 ms per step (44.52-44.56 vs 45.07-45.21, three interleaved
+// passes), end-to-end parity metrics unchanged (centred cosines 0.9925-0.9995 on the same fixtures, loss equal to 5 digits).
+typedef _Float16 sc_half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
+    const sc_half2_t h = __builtin_bit_cast(sc_half2_t, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
+    const sc_half2_t c4 = {(_Float16)4.0f, (_Float16)4.0f};
+    const sc_half2_t hc = __builtin_elementwise_min(__builtin_elementwise_max(h, -c4), c4);
+    const sc_half2_t t = hc * hc * (_Float16)0.125f - (_Float16)1.0f;
+    sc_half2_t g = t * (_Float16)5.972025641e-03f + (_Float16)-1.655089296e-02f;
+    g = g * t + (_Float16)2.409105964e-02f;
+    g = g * t + (_Float16)-3.546234617e-02f;
+    g = g * t + (_Float16)5.541019052e-02f;
+    g = g * t + (_Float16)-8.442661829e-02f;
+    g = g * t + (_Float16)1.759702165e-01f;
+    const sc_half2_t y = h * (hc * g + (_Float16)0.5f);
+    return (f32x2_t){(float)y[0], (float)y[1]};
+}
+#else
 __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
     const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -SC_GELU_P_C, SC_GELU_P_C), __builtin_amdgcn_fmed3f(x[1], -SC_GELU_P_C, SC_GELU_P_C)};
     const f32x2_t t = xc * xc * SC_GELU_P_S - 1.0f;
@@ -73,6 +100,7 @@ __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
     g = g * t + 1.659348977e-01f;
     return x * (xc * g + 0.5f);
 }
+#endif
 __device__ __forceinline__ float gelu_erf_precise(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
 // Counter-based dropout masks: element idx of a tensor is kept iff hash(seed, idx) >= thresh (thresh = p * 2^32); the backward regenerates the
 // mask from (seed, idx) instead of storing it.
