@@ -71,20 +71,37 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {   // two values: the p
 // 1.06x the rms error of rounding the exact value to bf16 (absolute error <= ~1e-3, in the negative tail where 0.5 + xc g cancels in half
 // precision): below the resolution of the bf16 activations it feeds.  Measured: -0.62 ms per step (44.52-44.56 vs 45.07-45.21, three interleaved
 // passes), end-to-end parity metrics unchanged (centred cosines 0.9925-0.9995 on the same fixtures, loss equal to 5 digits).
+#ifndef SC_GELU_DEG
+#define SC_GELU_DEG 6
+#endif
 typedef _Float16 sc_half2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
+    // y = x Phi(x), Phi = clamp(1/2 + x g(t), 0, 1), t = min(x^2 / 8 - 1, 1).  Only t is clamped (one v_pk_min): beyond |x| = 4 the product x g(1)
+    // leaves [-1/2, 1/2] and the [0, 1] clamp -- the VOP3P clamp bit of the v_pk_fma that forms Phi -- pins Phi to 0 / 1.  The last product is
+    // formed in fp32 from the half operands (v_fma_mix_f32), which is also the conversion the bf16 pack needs.
     const sc_half2_t h = __builtin_bit_cast(sc_half2_t, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
-    const sc_half2_t c4 = {(_Float16)4.0f, (_Float16)4.0f};
-    const sc_half2_t hc = __builtin_elementwise_min(__builtin_elementwise_max(h, -c4), c4);
-    const sc_half2_t t = hc * hc * (_Float16)0.125f - (_Float16)1.0f;
+    const sc_half2_t one = {(_Float16)1.0f, (_Float16)1.0f}, zero = {(_Float16)0.0f, (_Float16)0.0f};
+    const sc_half2_t t = __builtin_elementwise_min(h * h * (_Float16)0.125f - (_Float16)1.0f, one);
+#if SC_GELU_DEG == 5
+    sc_half2_t g = t * (_Float16)-1.177580447e-02f + (_Float16)2.993807372e-02f;
+    g = g * t + (_Float16)-3.959858472e-02f;
+    g = g * t + (_Float16)5.414790186e-02f;
+    g = g * t + (_Float16)-8.377277171e-02f;
+    g = g * t + (_Float16)1.760021146e-01f;
+#else
     sc_half2_t g = t * (_Float16)5.972025641e-03f + (_Float16)-1.655089296e-02f;
     g = g * t + (_Float16)2.409105964e-02f;
     g = g * t + (_Float16)-3.546234617e-02f;
     g = g * t + (_Float16)5.541019052e-02f;
     g = g * t + (_Float16)-8.442661829e-02f;
     g = g * t + (_Float16)1.759702165e-01f;
-    const sc_half2_t y = h * (hc * g + (_Float16)0.5f);
-    return (f32x2_t){(float)y[0], (float)y[1]};
+#endif
+    const sc_half2_t phi = __builtin_elementwise_min(__builtin_elementwise_max(h * g + (_Float16)0.5f, zero), one);
+    // (as asm: left to the compiler, one of the two epilogue copies converts all four halves and SLP-packs the products into v_pk_fma_f32)
+    f32x2_t y;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,1,0]" : "=v"(y[0]) : "v"(h), "v"(phi));
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(y[1]) : "v"(h), "v"(phi));
+    return y;
 }
 #else
 __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {

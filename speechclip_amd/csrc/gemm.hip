@@ -38,6 +38,8 @@ struct GemmParams {
     const float* res_stats;                    // EPI 2: [M,2] stats of the LayerNorm whose output is the RESIDUAL; `residual` holds the pre-norm rows
     const float* res_gamma; const float* res_beta;   // EPI 2: [N] affine of that LayerNorm
     float* ln_partial;                         // EPI 2: [M, 4*tiles_n, 2] per-(row, 64-column strip) partial (sum, sum of squares) of the OUTPUT rows
+    int stagger;                               // PROBES: block group (b >> 3) & 3 sleeps g * stagger * 4096 cycles before its first tile (de-synchronised epilogues)
+    int eprobe;                                // PROBES, fast epilogue only (garbage results): 1 no stores, 2 no next-tile DMA pieces, 4 stores wrap inside 2 MiB of C, 8 no shuffles
     int kpair;                                 // > 0: stride-2 kernel-3 conv as GEMM (K = 3C, lda = 2C), kpair = C / 64: walk K as (tap0 c, tap2 c) pairs, then tap1
 };
 
@@ -261,11 +263,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     // two touches one k-step apart (an L2 / TCP hit) instead of 16 k-steps apart (evicted: every CU streams 64 KiB per k-step through a 4 MiB
     // L2 shared by 32 CUs) -- the sum over K is order-free.  kpair = C / 64 chunks per tap.
     const int kpair = p.kpair;
+    auto kmap = [&](int c) -> int {       // k offset (elements) of the c-th chunk of the walk
+        if (kpair > 0) c = c < 2 * kpair ? (c >> 1) + (c & 1) * 2 * kpair : c - kpair;
+        return c * BK2;
+    };
     auto kofs = [&](int st) -> int {
         int c = st + rot;
         c = c >= nk ? c - nk : c;
-        if (kpair > 0) c = c < 2 * kpair ? (c >> 1) + (c & 1) * 2 * kpair : c - kpair;
-        return c * BK2;
+        return kmap(c);
     };
     const int frow = lane & 15, fk = lane >> 4;
     const int off_h0 = frow * 128 + ((fk ^ (frow & 7)) << 4);
@@ -274,9 +279,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int a_base = wm * 128 * 128;
     const int b_base = (RING3 ? 0 : 256 * 128) + wn * 64 * 128;   // RING3: relative to the W slot; else relative to the combined slot
     // slot addresses: 2-ring = [A|W] x 2 (64 KiB each); 3-ring = A0 A1 A2 W0 W1 (32 KiB each)
-    auto a_slot = [&](int st) -> char* { return RING3 ? smem + (st % 3) * HALF_SLOT : smem + (st & 1) * SLOT_BYTES; };
-    auto w_slot = [&](int st) -> char* { return RING3 ? smem + (3 + (st & 1)) * HALF_SLOT : smem + (st & 1) * SLOT_BYTES; };
-    auto w_dst = [&](int st) -> char* { return RING3 ? w_slot(st) : w_slot(st) + HALF_SLOT; };   // where the W pieces of stage st land
+    // Ring state: the LDS slots of stages kt, kt+1, kt+2 (A) and kt, kt+1 (W) of the k-step being computed, ROTATED once per k-step and never
+    // reset -- the ring does not restart at a tile boundary (stage j of the next tile takes the place stage nk + j of this one would), and the
+    // loop carries no modulo arithmetic.  2-ring: A and W share a slot (sW == sA), stage kt+2 goes where stage kt was (sA2 == sA0).
+    char* sA0 = smem;
+    char* sA1 = smem + (RING3 ? HALF_SLOT : SLOT_BYTES);
+    char* sA2 = RING3 ? smem + 2 * HALF_SLOT : sA0;
+    char* sW0 = RING3 ? smem + 3 * HALF_SLOT : sA0;
+    char* sW1 = RING3 ? smem + 4 * HALF_SLOT : sA1;
+    auto rotate_ring = [&]() {
+        if (RING3) { char* t = sA0; sA0 = sA1; sA1 = sA2; sA2 = t; t = sW0; sW0 = sW1; sW1 = t; }
+        else { char* t = sA0; sA0 = sA1; sA1 = t; sA2 = sA0; sW0 = sA0; sW1 = sA1; }
+    };
+    auto w_dst = [&](char* wslot) -> char* { return RING3 ? wslot : wslot + HALF_SLOT; };   // where the W pieces of a stage land
     const bool k_counted_wait = p.epi_mode >= 0 && !(p.epi_mode & 0x100);   // SC_GEMM_EPI |= 0x100: always drain at tile start (A/B)
     const bool vec_ok = !p.out_f32 && (p.N % 8 == 0) && (p.ldc % 8 == 0) && (!RES || p.ldr % 8 == 0);
     const bool f32_ok = p.out_f32 && (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!RES || p.ldr % 4 == 0);
@@ -328,6 +343,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     auto a_row0 = [&](int t) -> int64_t { const int64_t m = tile_m0(t); return ABL == 8 ? (m & 2047) : m; };
     int tm, tn, tz;
     bool have = tile_of(0, tm, tn, tz);
+    if (SC_PROBES && p.stagger > 0) {
+        const int g = (blockIdx.x >> 3) & 3;
+        for (int i = 0; i < g * p.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+    }
     StageAddr sa{nullptr, nullptr};
     auto set_tile = [&](const bf16_t* ta, const bf16_t* tw) { sa = StageAddr{ta, tw}; };
     // one LDS-DMA piece (64 rows x 128 B... 8 rows per wave): row group g of A / W at k offset k0 (elements) into LDS at dst
@@ -339,8 +358,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     auto issue_q = [&](int q) {
         const int st = q >> 3, g = q & 7;
         if (st >= nk) return;
-        if (g < 4) piece_a(g, kofs(st), a_slot(st) + (g * 512 + wave * 64) * 16);
-        else if (st < 2) piece_w(g - 4, kofs(st), w_dst(st) + ((g - 4) * 512 + wave * 64) * 16);
+        if (g < 4) piece_a(g, kofs(st), (st ? sA1 : sA0) + (g * 512 + wave * 64) * 16);
+        else if (st < 2) piece_w(g - 4, kofs(st), w_dst(st ? sW1 : sW0) + ((g - 4) * 512 + wave * 64) * 16);
     };
     if (have) {
         rot = p.rot ? tm % nk : 0;
@@ -379,16 +398,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         asm volatile("" ::: "memory");
         if (TRACE) { unsigned long long t = __builtin_readcyclecounter(); t_wait += t - t_begin; t_begin = t; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8_t*)(w_slot(0) + b_base + off_h0 + j * 16 * 128);
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8_t*)(sW0 + b_base + off_h0 + j * 16 * 128);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8_t*)(a_slot(0) + a_base + off_h0 + i * 16 * 128);
+        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8_t*)(sA0 + a_base + off_h0 + i * 16 * 128);
 
         // One half-step: 32 MFMAs on (bfr, af) while the next half's fragments are read ({4 MFMA, 1 ds_read} x 8).  The B
         // fragments of the next half go into bn right after the first MFMA group, so no LDS wait gates the group head.
         // srcA / srcW: slots the next half's fragments are read from; dma_k0 >= 0: refill stage (2-ring: A and W of one stage into dma_slot;
         // RING3: W of that stage into dma_slot and, dma_ka0 >= 0, A of the stage after it into dma_aslot)
-        auto half_step = [&](auto dma_tag, const char* srcA, const char* srcW, int off, bool load_next, int dma_k0, char* dma_slot, int dma_ka0, char* dma_aslot) {
-            constexpr bool DMA = decltype(dma_tag)::value;      // compile-time: the loop is peeled, no piece sits behind a run-time test
+        // hook: scalar bookkeeping of the NEXT k-step, run between two MFMA groups (where it is free) instead of between two k-steps (where
+        // ~60 scalar instructions per wave -- k offset with rotation / tap pairing, slot indices -- sat in front of the first MFMA).
+        auto no_hook = []() {};
+        auto half_step = [&](auto dma_tag, const char* srcA, const char* srcW, int off, bool load_next, int dma_k0, char* dma_slot, int dma_ka0, char* dma_aslot,
+                             auto&& hook) {
+            constexpr bool DMA = decltype(dma_tag)::value;      // compile-time: no piece of a copy without refill sits behind a run-time test
             bf16x8_t bn[4];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -414,7 +437,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     if (DMA && ABL != 1) {   // one LDS-DMA instruction per MFMA group instead of a burst behind the barrier
                         if (!RING3) {
                             const int dk = (ABL == 7) ? 0 : dma_k0;   // ABL 7 (timing probe, garbage results): the in-loop DMA always re-reads k-chunk 0 = cache hits
-                            if (i < 4) piece_a(i, dk, dma_slot + (i * 512 + wave * 64) * 16);
+                            if (dk < 0) {}
+                            else if (i < 4) piece_a(i, dk, dma_slot + (i * 512 + wave * 64) * 16);
                             else piece_w(i - 4, dk, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
                         } else {
                             // one piece in MFMA groups 0, 2, 4, 6 of each half-step: the 8 pieces of a k-step spread evenly over its 16 groups
@@ -426,6 +450,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                             }
                         }
                     }
+                    if (i == 5) hook();
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -434,30 +459,45 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 for (int j = 0; j < 4; ++j) bfr[j] = bn[j];
             }
         };
-        auto mid_sync = [&](int kt) {
+        auto mid_sync = [&](int kt, bool refilled) {
             // slot kt is entirely in registers; stage kt+1 must have landed before anyone reads it.  RING3: the newest 4 operations of this
-            // wave are the A pieces of stage kt+2, issued during the half-step that just ended, whenever that stage exists: let them fly.
-            if (RING3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            // wave are the A pieces of stage kt+2 (or of the next tile's stage 0), issued during the half-step that just ended, whenever
+            // that stage exists: let them fly.
+            (void)kt;
+            if (RING3 && refilled) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };
         using T_ = std::integral_constant<bool, true>;
         using F_ = std::integral_constant<bool, false>;
+        // steady state: stage kt + 2 exists, every refill piece is issued behind one uniform test.  RING3: the loop includes k-step nk - 2, whose
+        // "stage nk" does not exist (k2 = -1: nothing is issued; continuing the ring into the next tile's stage 0 there was measured: +0.7 ms per step).
         int kt = 0;
-        for (; kt + 2 < nk; ++kt) {       // steady state: stage kt + 2 exists, every refill piece is issued unconditionally
+        int kc = 2 + rot;                      // chunk of the walk that stage kt + 2 holds
+        kc = kc >= nk ? kc - nk : kc;
+        int k2 = nk > 2 ? kmap(kc) : -1;       // its k offset; -1: no such stage
+        for (; kt + 2 < nk || (RING3 && kt + 1 < nk); ++kt) {
+            int k2n = -1;
+            auto next_k = [&]() {              // stage kt + 3, for the next pass of this loop
+                int c = kc + 1;
+                kc = c >= nk ? c - nk : c;
+                k2n = kt + 3 < nk ? kmap(kc) : -1;
+            };
             // MFMAs of (kt, h0); read (kt, h1); RING3: A pieces of stage kt+2 into the A slot stage kt-1 left free
-            if (!RING3) half_step(F_{}, a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, -1, nullptr);
-            else half_step(T_{}, a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, kofs(kt + 2), a_slot(kt + 2));
-            mid_sync(kt);
+            if (!RING3) half_step(F_{}, sA0, sW0, off_h1, true, -1, nullptr, -1, nullptr, no_hook);
+            else half_step(T_{}, sA0, sW0, off_h1, true, -1, nullptr, k2, sA2, no_hook);
+            mid_sync(kt, k2 >= 0);
             // MFMAs of (kt, h1); read (kt+1, h0); refill: 2-ring = stage kt+2 (A and W) into slot kt; RING3 = W(kt+2) into W slot kt
-            if (!RING3) half_step(T_{}, a_slot(kt + 1), w_slot(kt + 1), off_h0, true, kofs(kt + 2), a_slot(kt), -1, nullptr);
-            else half_step(T_{}, a_slot(kt + 1), w_slot(kt + 1), off_h0, true, kofs(kt + 2), w_slot(kt), -1, nullptr);
+            half_step(T_{}, sA1, sW1, off_h0, true, k2, RING3 ? sW0 : sA0, -1, nullptr, next_k);
+            rotate_ring();
+            k2 = k2n;
         }
-        if (kt + 1 < nk) {                // k-step nk - 2: nothing left to refill
-            half_step(F_{}, a_slot(kt), w_slot(kt), off_h1, true, -1, nullptr, -1, nullptr);
-            mid_sync(kt);
-            half_step(F_{}, a_slot(kt + 1), w_slot(kt + 1), off_h0, true, -1, nullptr, -1, nullptr);
+        if (!RING3 && kt + 1 < nk) {      // 2-ring, k-step nk - 2: nothing left to refill
+            half_step(F_{}, sA0, sW0, off_h1, true, -1, nullptr, -1, nullptr, no_hook);
+            mid_sync(kt, false);
+            half_step(F_{}, sA1, sW1, off_h0, true, -1, nullptr, -1, nullptr, no_hook);
+            rotate_ring();
         }
         // bias for this lane's 4 x 4 output columns: loaded BEFORE the next tile's LDS-DMA is issued (an ordinary load
         // issued behind the DMA would have to drain it first: vmcnt is in-order)
@@ -470,10 +510,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             }
         };
         {   // last k-step (peeled: nothing left to prefetch after its first half)
-            const int kl = nk - 1;
-            half_step(F_{}, a_slot(kl), w_slot(kl), off_h1, true, -1, nullptr, -1, nullptr);
+            half_step(F_{}, sA0, sW0, off_h1, true, -1, nullptr, -1, nullptr, no_hook);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            half_step(F_{}, nullptr, nullptr, 0, false, -1, nullptr, -1, nullptr);
+            half_step(F_{}, nullptr, nullptr, 0, false, -1, nullptr, -1, nullptr, no_hook);
+            rotate_ring();      // sA0 / sW0: where stage nk would go = the next tile's stage 0
         }
         load_bias();    // (measured, round 3: loading them before the last half-step instead -- latency under 32 MFMAs -- costs +1.5 ms per step)
         f32x4_t c4[4];
@@ -494,10 +534,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const int64_t c_off = BATCH ? (int64_t)tz * p.strideC : 0;      // this tile's product (its epilogue runs below, after the next tile is set up)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int nrot = (nhave && p.rot) ? ntm % nk : 0;
         if (nhave) set_tile(A + (BATCH ? (int64_t)ntz * p.strideA : 0) + a_row0(ntm) * p.lda,
                             W + (BATCH ? (int64_t)(ntz % p.w_mod) * p.strideW : 0) + (int64_t)tile_n0(ntn) * p.ldw);
-        rot = nrot;   // the k-loop of THIS tile is over; from here on kofs() addresses the next tile
+        rot = (nhave && p.rot) ? ntm % nk : 0;   // the k-loop of THIS tile is over; from here on kofs() addresses the next tile
         const int emode = (RES ? p.epi_mode_res : p.epi_mode) & 0xff;
         if (nhave && emode == 0) {
 #pragma unroll
@@ -529,8 +568,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             auto issue_fast = [&](int q) {                                // q-th prologue DMA instruction: A(0) x4, W(0) x4, A(1) x4, W(1) x4
                 const int st = q >> 3, g = q & 7;
                 const int k0 = st ? kq1 : kq0;
-                if (g < 4) piece_a(g, k0, a_slot(st) + (g * 512 + wave * 64) * 16);
-                else piece_w(g - 4, k0, w_dst(st) + ((g - 4) * 512 + wave * 64) * 16);
+                if (g < 4) piece_a(g, k0, (st ? sA1 : sA0) + (g * 512 + wave * 64) * 16);
+                else piece_w(g - 4, k0, w_dst(st ? sW1 : sW0) + ((g - 4) * 512 + wave * 64) * 16);
             };
             uint4 res[RES ? 4 : 1][2];
             auto load_res_fast = [&](int i) {
@@ -557,6 +596,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 for (int jp = 0; jp < 2; ++jp) {
                     const auto r0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].x, pk[2 * jp + 1].x, false, false);
                     const auto r1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].y, pk[2 * jp + 1].y, false, false);
+                    if (SC_PROBES && (p.eprobe & 8)) o[jp] = make_uint4(pk[2 * jp].x, pk[2 * jp].y, pk[2 * jp + 1].x, pk[2 * jp + 1].y);
+                    else
                     o[jp] = make_uint4(__builtin_amdgcn_ds_bpermute(bperm, r0[0]), __builtin_amdgcn_ds_bpermute(bperm, r1[0]),
                                        __builtin_amdgcn_ds_bpermute(bperm, r0[1]), __builtin_amdgcn_ds_bpermute(bperm, r1[1]));
                 }
@@ -576,10 +617,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                         o.z = pack2bf(lo2f(o.z) + lo2f(rv.z), hi2f(o.z) + hi2f(rv.z));
                         o.w = pack2bf(lo2f(o.w) + lo2f(rv.w), hi2f(o.w) + hi2f(rv.w));
                     }
-                    *(uint4*)(cptr + i * cstep + jp * 32) = o;
+                    if (SC_PROBES && (p.eprobe & 1)) asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+                    else if (SC_PROBES && (p.eprobe & 4)) *(uint4*)(Cb + ((cptr - Cb + i * cstep + jp * 32) & ((1 << 20) - 8))) = o;
+                    else *(uint4*)(cptr + i * cstep + jp * 32) = o;
                 }
                 if (RES && i + 4 < 8) load_res_fast(i + 4);               // slot i & 3 was consumed just above
-                issue_fast(2 * i); issue_fast(2 * i + 1);       // (all 8 stage-0 pieces before the first store instead: +-0.02 ms per step, round 3)
+                if (SC_PROBES && (p.eprobe & 2)) {}
+                else { issue_fast(2 * i); issue_fast(2 * i + 1); }   // (all 8 stage-0 pieces before the first store instead: +-0.02 ms per step, round 3)
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else if (vec_ok) {
@@ -806,11 +850,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         tm = ntm;
         tn = ntn;
         tz = ntz;
-        if (TRACE && tid == 0) {
+        if (TRACE && lane == 0) {     // per block (wave 0's view) in [0, 8), per wave in [8 + 4 wave, +4): wait / loop / next-tile set-up / epilogue
             unsigned long long t = __builtin_readcyclecounter();
-            unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
-            tr[0] = t_wait; tr[1] = t_loop; tr[2] = t_pre; tr[3] += t - t_begin; tr[4] = it + 1;
-            tr[5] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11));
+            unsigned long long* tr = p.trace + (size_t)blockIdx.x * 40;
+            unsigned long long* tw = tr + 8 + wave * 4;
+            tw[0] = t_wait; tw[1] = t_loop; tw[2] = t_pre; tw[3] += t - t_begin;
+            if (tid == 0) {
+                tr[0] = t_wait; tr[1] = t_loop; tr[2] = t_pre; tr[3] += t - t_begin; tr[4] = it + 1;
+                tr[5] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11));
+            }
             t_begin = t;
         }
     }
@@ -956,6 +1004,9 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     static const int k_epi = SC_TUNE_INT("SC_GEMM_EPI", 2);
     static const int k_epi_res = SC_TUNE_INT("SC_GEMM_EPI_RES", 2);   // 2 since late round 2 (four-ahead residual ring): -0.13 ms per step vs 3 in 7 of 7 A/B passes
     p.rot = k_rot; p.band = k_band; p.epi_mode = k_epi; p.epi_mode_res = k_epi_res;
+    static const int k_stagger = SC_TUNE_INT("SC_GEMM_STAGGER", 0);
+    static const int k_eprobe = SC_TUNE_INT("SC_GEMM_EPROBE", 0);
+    p.stagger = k_stagger; p.eprobe = k_eprobe;
     static const int k_pair = SC_TUNE_SET("SC_GEMM_NOKPAIR") ? 0 : 1;
     if (k_pair && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) p.kpair = (int)(lda / 2 / 64);   // k = 3, stride-2 conv layers of the extractor
     return gemm_dispatch(p, 1, (hipStream_t)stream);

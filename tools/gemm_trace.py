@@ -16,7 +16,7 @@ for name in sys.argv[1:] or list(SH):
     bias = torch.randn(N, device="cuda")
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     ops.gemm(a, w, bias, act, out=out, M=M, K=K, lda=lda)
-    tr = torch.zeros(256, 8, dtype=torch.int64, device="cuda")
+    tr = torch.zeros(256, 40, dtype=torch.int64, device="cuda")
     L.sc_debug_set_gemm_trace(tr.data_ptr())
     ops.gemm(a, w, bias, act, out=out, M=M, K=K, lda=lda)
     torch.cuda.synchronize()
@@ -26,6 +26,9 @@ for name in sys.argv[1:] or list(SH):
     per = t[:, :4] / tiles[:, None]
     m = per.mean(0)
     nk = K // 64
+    pw = t[:, 8:40].reshape(256, 8, 4) / tiles[:, None, None]      # per wave: wait / loop / set-up / epilogue
+    pwm = pw.mean(0)
+    print("   per wave  wait:", [int(v) for v in pwm[:, 0]], " epilogue:", [int(v) for v in pwm[:, 3]], " loop:", [int(v) for v in pwm[:, 1]])
     xcc = tr[:, 5].cpu().tolist()
     print("   XCC id of blocks 0..15:", [int(v) & 15 for v in xcc[:16]], " blocks with xcc == bid%8:", sum(int(v) & 15 == (i % 8) for i, v in enumerate(xcc)), "/ 256")
     print(f"{name:6s} tiles/block={tiles.mean():.2f} per-tile cycles(100MHz ticks?): wait={m[0]:.0f} loop={m[1]:.0f} ({m[1]/nk:.1f}/kstep) prefetch-issue={m[2]:.0f} epilogue={m[3]:.0f}  total={m.sum():.0f}")
