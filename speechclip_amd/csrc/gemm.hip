@@ -39,7 +39,8 @@ struct GemmParams {
     const float* res_gamma; const float* res_beta;   // EPI 2: [N] affine of that LayerNorm
     float* ln_partial;                         // EPI 2: [M, 4*tiles_n, 2] per-(row, 64-column strip) partial (sum, sum of squares) of the OUTPUT rows
     int stagger;                               // PROBES: block group (b >> 3) & 3 sleeps g * stagger * 4096 cycles before its first tile (de-synchronised epilogues)
-    int eprobe;                                // PROBES, fast epilogue only (garbage results): 1 no stores, 2 no next-tile DMA pieces, 4 stores wrap inside 2 MiB of C, 8 no shuffles
+    int eprobe;                                // PROBES, fast epilogue only (garbage results): 1 no stores, 2 no next-tile DMA pieces, 4 stores wrap inside 2 MiB of C, 8 no shuffles;
+                                               // 64 (valid results) streaming stores
     int kpair;                                 // > 0: stride-2 kernel-3 conv as GEMM (K = 3C, lda = 2C), kpair = C / 64: walk K as (tap0 c, tap2 c) pairs, then tap1
 };
 
@@ -619,6 +620,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     }
                     if (SC_PROBES && (p.eprobe & 1)) asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
                     else if (SC_PROBES && (p.eprobe & 4)) *(uint4*)(Cb + ((cptr - Cb + i * cstep + jp * 32) & ((1 << 20) - 8))) = o;
+                    else if (SC_PROBES && (p.eprobe & 64)) {
+                        typedef unsigned u32x4_nt_t __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store((u32x4_nt_t){o.x, o.y, o.z, o.w}, (u32x4_nt_t*)(cptr + i * cstep + jp * 32));
+                    }
                     else *(uint4*)(cptr + i * cstep + jp * 32) = o;
                 }
                 if (RES && i + 4 < 8) load_res_fast(i + 4);               // slot i & 3 was consumed just above
@@ -1006,7 +1011,9 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     p.rot = k_rot; p.band = k_band; p.epi_mode = k_epi; p.epi_mode_res = k_epi_res;
     static const int k_stagger = SC_TUNE_INT("SC_GEMM_STAGGER", 0);
     static const int k_eprobe = SC_TUNE_INT("SC_GEMM_EPROBE", 0);
-    p.stagger = k_stagger; p.eprobe = k_eprobe;
+    static const int k_nt_n = SC_TUNE_INT("SC_GEMM_NT_N", 0);       // PROBES: streaming (nt) stores for the GEMMs with this N and no activation (by consumer)
+    static const int k_nt_act = SC_TUNE_INT("SC_GEMM_NT_ACT", 0);
+    p.stagger = k_stagger; p.eprobe = k_eprobe | ((k_nt_n && N == k_nt_n && (int)(flags & SC_GEMM_ACT_MASK) == k_nt_act && !residual) ? 64 : 0);
     static const int k_pair = SC_TUNE_SET("SC_GEMM_NOKPAIR") ? 0 : 1;
     if (k_pair && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) p.kpair = (int)(lda / 2 / 64);   // k = 3, stride-2 conv layers of the extractor
     return gemm_dispatch(p, 1, (hipStream_t)stream);
