@@ -165,6 +165,56 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const bf16_t* __restr
     }
 }
 
+// Fast path for the pre-LN models' residual streams (HuBERT-large, ViT-L/14: fp32 [rows, 1024] -> bf16, affine; 99 launches per P-large step): a lane owns 8
+// consecutive columns of each 512-column half (two 16-byte loads per half, ONE 16-byte store per half -- the generic kernel's 4-column ownership stores 8
+// bytes per lane), a wave owns two consecutive rows and issues all eight loads up front.
+__global__ __launch_bounds__(256) void layernorm1024f_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             bf16_t* __restrict__ out, int64_t rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= rows) return;
+    const bool two = row0 + 1 < rows;
+    f32x4_t v[2][2][2];                                  // [row][half][quad]
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float* xr = x + (row0 + (two ? r : 0)) * 1024 + lane * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { v[r][h][0] = *(const f32x4_t*)(xr + h * 512); v[r][h][1] = *(const f32x4_t*)(xr + h * 512 + 4); }
+    }
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) s += (v[r][h][q][0] + v[r][h][q][1]) + (v[r][h][q][2] + v[r][h][q][3]);
+        mean[r] = wave_sum(s) * (1.0f / 1024.0f);
+        float qq = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float d = v[r][h][q][i] - mean[r]; qq += d * d; }
+        rstd[r] = rsqrtf(wave_sum(qq) * (1.0f / 1024.0f) + eps);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = h * 512 + lane * 8;
+        const f32x4_t g0 = *(const f32x4_t*)(gamma + col), g1 = *(const f32x4_t*)(gamma + col + 4);
+        const f32x4_t b0 = *(const f32x4_t*)(beta + col), b1 = *(const f32x4_t*)(beta + col + 4);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r && !two) continue;
+            const f32x4_t o0 = (v[r][h][0] - mean[r]) * rstd[r] * g0 + b0, o1 = (v[r][h][1] - mean[r]) * rstd[r] * g1 + b1;
+            uint4 u;
+            u.x = pack2bf(o0[0], o0[1]); u.y = pack2bf(o0[2], o0[3]); u.z = pack2bf(o1[0], o1[1]); u.w = pack2bf(o1[2], o1[3]);
+            *(uint4*)(out + (row0 + r) * 1024 + col) = u;
+        }
+    }
+}
+
 // Fast path for the HuBERT-large feature extractor (extractor_mode = layer_norm: LayerNorm over the 512 channels + GELU after every conv,
 // 8.3 GB per 64-utterance step): D = 512 bf16 -> bf16, a row is exactly one 16-byte chunk per lane; a wave owns four consecutive rows and
 // issues their loads up front.
@@ -390,6 +440,11 @@ extern "C" int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, co
         return 0;
     }
     const bool in32 = flags & SC_LN_IN_F32, out32 = flags & SC_LN_OUT_F32;
+    if (D == 1024 && in32 && !out32 && !gelu && gamma && ld_in == 1024 && ld_out == 1024 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(layernorm1024f_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const float*)x, gamma, beta, (bf16_t*)out, rows, eps);
+        SC_CHECK_LAUNCH();
+        return 0;
+    }
     if (in32 && out32) hipLaunchKernelGGL((layernorm_kernel<true, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
     else if (in32) hipLaunchKernelGGL((layernorm_kernel<true, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
     else if (out32) hipLaunchKernelGGL((layernorm_kernel<false, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);

@@ -56,6 +56,18 @@ def test_layernorm_512_fast_path(gelu):
         torch.testing.assert_close(y.float(), ref, atol=2e-2, rtol=2e-2)
 
 
+def test_layernorm_1024_f32_fast_path():
+    """Pre-LN residual streams (HuBERT-large, ViT-L/14): fp32 [rows, 1024] -> bf16, the 16-byte-store kernel; ragged row counts, odd tails."""
+    from speechclip_amd import ops
+    g = _g(1024)
+    for rows in (1, 2, 7, 8, 9, 4099):
+        x = (torch.randn(rows, 1024, generator=g) * 3 - 1).cuda()
+        gamma, beta = (1 + 0.3 * torch.randn(1024, generator=g)).cuda(), (0.3 * torch.randn(1024, generator=g)).cuda()
+        y = ops.layernorm(x, gamma, beta)
+        assert y.dtype == BF and y.shape == x.shape
+        torch.testing.assert_close(y.float(), F.layer_norm(x, (1024,), gamma, beta, 1e-5), atol=2e-2, rtol=2e-2)
+
+
 def test_layernorm_strided_rows():
     from speechclip_amd import ops
     x = torch.randn(6, 5, 768, generator=_g(1)).cuda()
