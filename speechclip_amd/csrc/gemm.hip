@@ -624,6 +624,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                         typedef unsigned u32x4_nt_t __attribute__((ext_vector_type(4)));
                         __builtin_nontemporal_store((u32x4_nt_t){o.x, o.y, o.z, o.w}, (u32x4_nt_t*)(cptr + i * cstep + jp * 32));
                     }
+                    else if (SC_PROBES && (p.eprobe >> 8)) {      // cache-policy bits of the output stores: (eprobe >> 8) = sc0 | sc1 << 1 | nt << 2
+                        typedef unsigned u32x4_st_t __attribute__((ext_vector_type(4)));
+                        const u32x4_st_t ov = {o.x, o.y, o.z, o.w};
+                        bf16_t* ap = cptr + i * cstep + jp * 32;
+                        switch (p.eprobe >> 8) {
+                            case 1: asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(ap), "v"(ov) : "memory"); break;
+                            case 2: asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(ap), "v"(ov) : "memory"); break;
+                            case 3: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(ap), "v"(ov) : "memory"); break;
+                            case 4: asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(ap), "v"(ov) : "memory"); break;
+                            case 5: asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(ap), "v"(ov) : "memory"); break;
+                            case 6: asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(ap), "v"(ov) : "memory"); break;
+                            default: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(ap), "v"(ov) : "memory"); break;
+                        }
+                    }
                     else *(uint4*)(cptr + i * cstep + jp * 32) = o;
                 }
                 if (RES && i + 4 < 8) load_res_fast(i + 4);               // slot i & 3 was consumed just above
@@ -1013,7 +1027,8 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     static const int k_eprobe = SC_TUNE_INT("SC_GEMM_EPROBE", 0);
     static const int k_nt_n = SC_TUNE_INT("SC_GEMM_NT_N", 0);       // PROBES: streaming (nt) stores for the GEMMs with this N and no activation (by consumer)
     static const int k_nt_act = SC_TUNE_INT("SC_GEMM_NT_ACT", 0);
-    p.stagger = k_stagger; p.eprobe = k_eprobe | ((k_nt_n && N == k_nt_n && (int)(flags & SC_GEMM_ACT_MASK) == k_nt_act && !residual) ? 64 : 0);
+    static const int k_st_policy = SC_TUNE_INT("SC_GEMM_ST_POLICY", 0);   // PROBES: sc0 | sc1 << 1 | nt << 2 on the fast epilogue's output stores
+    p.stagger = k_stagger; p.eprobe = k_eprobe | (k_st_policy << 8) | ((k_nt_n && N == k_nt_n && (int)(flags & SC_GEMM_ACT_MASK) == k_nt_act && !residual) ? 64 : 0);
     static const int k_pair = SC_TUNE_SET("SC_GEMM_NOKPAIR") ? 0 : 1;
     if (k_pair && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) p.kpair = (int)(lda / 2 / 64);   // k = 3, stride-2 conv layers of the extractor
     return gemm_dispatch(p, 1, (hipStream_t)stream);
