@@ -58,6 +58,10 @@ int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
  * the hot path runs on gemm256_kernel / gemm_bf16_kernel.  Caller-owned device scratch, 64 MiB is plenty; NULL switches the comparator off. */
 int sc_set_gemm_workspace(void* workspace, int64_t bytes);
 int sc_gemm_last_path(void);   /* instrumentation: 1 if the last sc_gemm_bf16 call ran on the vendor library, 0 on the hand-written kernels */
+/* instrumentation (comparator only): which half of the comparator workspace `stream` owns: 0 / 1, -1 none yet, -2 both halves belong to other
+ * streams (that stream's GEMMs run on the hand-written kernels), -3 comparator library not loaded.  The comparator ABI itself is declared once,
+ * in speechclip_amd/csrc/vendor/vendor_abi.h, for both libraries. */
+int sc_debug_vendor_stream_slot(void* stream);
 
 int sc_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw,
                          int64_t strideW, int w_mod, void* C, int64_t ldc, int64_t strideC,

@@ -7,11 +7,13 @@
 #include <string.h>
 #include <string>
 #include "common.h"
+#include "vendor/vendor_abi.h"
 #include "../../include/speechclip_hip.h"
 
 namespace {
-typedef int (*set_ws_fn)(void*, int64_t);
-typedef int (*try_fn)(const void*, int64_t, const void*, int64_t, void*, int64_t, const float*, const void*, int64_t, int64_t, int, int, int, int, hipStream_t, int*);
+typedef scv_set_gemm_workspace_fn set_ws_fn;      // vendor/vendor_abi.h: the ONE declaration both libraries are compiled against
+typedef scv_gemm_try_fn try_fn;
+scv_stream_slot_fn g_slot = nullptr;
 void* g_cmp = nullptr;
 set_ws_fn g_set_ws = nullptr;
 try_fn g_try = nullptr;
@@ -31,7 +33,8 @@ bool load_comparator() {
     if (!g_cmp) { sc_set_error("sc_set_gemm_workspace: the vendor comparator library is not built (%s: %s); run `make -C speechclip_amd/csrc vendor`", path.c_str(), dlerror()); return false; }
     g_set_ws = (set_ws_fn)dlsym(g_cmp, "scv_set_gemm_workspace");
     g_try = (try_fn)dlsym(g_cmp, "scv_gemm_try");
-    if (!g_set_ws || !g_try) { sc_set_error("sc_set_gemm_workspace: %s lacks the comparator entry points", path.c_str()); dlclose(g_cmp); g_cmp = nullptr; return false; }
+    g_slot = (scv_stream_slot_fn)dlsym(g_cmp, "scv_stream_slot");
+    if (!g_set_ws || !g_try || !g_slot) { sc_set_error("sc_set_gemm_workspace: %s lacks the comparator entry points", path.c_str()); dlclose(g_cmp); g_cmp = nullptr; return false; }
     return true;
 }
 }  // namespace
@@ -53,7 +56,10 @@ int sc_vendor_gemm_try(const void* A, int64_t lda, const void* W, int64_t ldw, v
                        int64_t ldr, int64_t M, int N, int K, int out_f32, hipStream_t s) {
     if (!g_enabled) return 1;
     int st = 0;
-    const int rc = g_try(A, lda, W, ldw, C, ldc, bias, residual, ldr, M, N, K, out_f32, 0, s, &st);
+    const int rc = g_try(A, lda, W, ldw, C, ldc, bias, residual, ldr, M, N, K, out_f32, s, &st);
     if (rc < 0) sc_set_error("sc_gemm_bf16: hipblasLtMatmul failed (%d)", st);
     return rc;
 }
+
+// Test hook (tests/test_gemm_gpu.py): the comparator workspace half stream `s` owns: 0 / 1, -1 none yet, -2 both taken, -3 comparator not loaded.
+extern "C" int sc_debug_vendor_stream_slot(hipStream_t s) { return (g_cmp && g_slot) ? g_slot(s) : -3; }

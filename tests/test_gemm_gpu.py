@@ -96,8 +96,10 @@ def test_plain_gemms_run_on_the_hand_written_kernel_by_default():
 
 def test_vendor_comparator_path_correct_on_three_streams():
     """The comparator (ops.set_vendor_gemm(True): hipBLASLt behind the same entry, used only by bench.py's `vendor_comparator` leg) hands one
-    workspace half to each of two streams and sends a third stream to the hand-written kernels: the same plain GEMM issued on three streams
-    gives the same, correct result; switching it off restores the hand-written path."""
+    workspace half to each of two streams and sends a third stream to the hand-written kernels: paths == [1, 1, 0], the two library streams own
+    DIFFERENT workspace halves, and every result is correct when checked IN STREAM ORDER on the stream that issued it (no device-wide
+    synchronize before the comparison: a GEMM launched on the null stream instead of the caller's would race the check -- ADVICE r3, the loader's
+    typedef once carried an extra int that did exactly that).  Switching the comparator off restores the hand-written path."""
     from speechclip_amd import ops
     from speechclip_amd._lib import lib
     g = torch.Generator().manual_seed(0)
@@ -106,24 +108,35 @@ def test_vendor_comparator_path_correct_on_three_streams():
     w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16)
     bias = torch.randn(N, generator=g).cuda()
     ref = a.float() @ w.float().t() + bias
-    outs = []
+    torch.cuda.synchronize()
     ops.set_vendor_gemm(True)
     try:
         streams = [torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()]
-        paths = []
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(st):
-                outs.append(ops.gemm(a, w, bias))
-                paths.append(lib().sc_gemm_last_path())
-        torch.cuda.synchronize()
-        assert paths[0] == 1                                     # the library took it on the first stream
+        paths, slots, errs = [], [], []
+        for rep in range(3):                                     # several rounds: an ordering bug needs a chance to show
+            for st in streams:
+                with torch.cuda.stream(st):
+                    # a long kernel first, so that the GEMM is queued BEHIND work on its own stream: on the wrong stream it would start early and
+                    # the stream-ordered comparison below would read a half-written / stale `y`
+                    y = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+                    busy = torch.randn(4096, 4096, device="cuda") @ torch.randn(4096, 4096, device="cuda")
+                    ops.gemm(a, w, bias, out=y)
+                    if rep == 0:
+                        paths.append(lib().sc_gemm_last_path())
+                        slots.append(lib().sc_debug_vendor_stream_slot(st.cuda_stream))
+                    errs.append((st, (y.float() - ref).abs().max()))       # same stream: ordered after the GEMM, no synchronize
+                    del busy
+        assert paths == [1, 1, 0], paths                         # two streams get the library, the third the hand-written kernel
+        assert slots[:2] == [0, 1] and slots[2] == -2, slots     # ... on different workspace halves
+        for st, e in errs:
+            st.synchronize()
+            assert e.item() < 0.15, e.item()
     finally:
         ops.set_vendor_gemm(False)
-    outs.append(ops.gemm(a, w, bias))
+    assert lib().sc_debug_vendor_stream_slot(torch.cuda.current_stream().cuda_stream) in (-1, -3)
+    out = ops.gemm(a, w, bias)
     assert lib().sc_gemm_last_path() == 0
-    for o in outs:
-        torch.testing.assert_close(o.float(), ref, atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(out.float(), ref, atol=3e-2, rtol=2e-2)
 
 
 @pytest.mark.parametrize("M,N,K,res,f32", [(70000, 768, 128, False, False), (70000, 768, 128, True, False), (66000, 512, 192, False, True),
