@@ -62,4 +62,4 @@ int sc_vendor_gemm_try(const void* A, int64_t lda, const void* W, int64_t ldw, v
 }
 
 // Test hook (tests/test_gemm_gpu.py): the comparator workspace half stream `s` owns: 0 / 1, -1 none yet, -2 both taken, -3 comparator not loaded.
-extern "C" int sc_debug_vendor_stream_slot(hipStream_t s) { return (g_cmp && g_slot) ? g_slot(s) : -3; }
+extern "C" int sc_debug_vendor_stream_slot(void* stream) { return (g_cmp && g_slot) ? g_slot((hipStream_t)stream) : -3; }
