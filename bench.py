@@ -65,6 +65,12 @@ def algorithmic_gflop_per_pair(L=160000, d=768, ffn=3072, layers=12, vit_w=768, 
 LARGE = dict(d=1024, ffn=4096, layers=24, vit_w=1024, vit_layers=24, patch=14, E=768)   # HuBERT-large + ViT-L/14 (BASELINE configs[4])
 
 
+def bench_vocab_ids(vocab=8112, seed=7122):
+    """The synthetic reduced sub-word vocabulary of --model cascaded (original CLIP ids; rows 0/2/3 = pad / SOT / EOT as my_vector_quantizer.py:64 assumes)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.cat([torch.tensor([0, 320, 49406, 49407]), torch.randperm(49000, generator=g)[:vocab - 4] + 321])
+
+
 def build_model(seed=7122, large=False, cascaded=False, vocab=8112, finetune_layers=(), finetune_all=False):
     from speechclip_amd.util.shipped_configs import make_config
     from speechclip_amd.model import KWClip_GeneralTransformer
@@ -75,8 +81,7 @@ def build_model(seed=7122, large=False, cascaded=False, vocab=8112, finetune_lay
         if vocab and vocab < 49408:
             import tempfile
             import numpy as np
-            g = torch.Generator().manual_seed(seed)
-            ids = torch.cat([torch.tensor([0, 320, 49406, 49407]), torch.randperm(49000, generator=g)[:vocab - 4] + 321]).numpy()
+            ids = bench_vocab_ids(vocab, seed).numpy()
             vp = os.path.join(tempfile.gettempdir(), f"bench_vocab_{vocab}_{os.getpid()}.npy")
             np.save(vp, np.stack([ids, np.arange(len(ids))[::-1] + 1], axis=1))
         cfg = make_config(parallel=False, cascaded=True, reduce_vocab=vp)
@@ -91,6 +96,22 @@ def build_model(seed=7122, large=False, cascaded=False, vocab=8112, finetune_lay
         cfg.audio_encoder.trainable = True
         cfg.audio_encoder.unfreeze_layers = [int(i) for i in finetune_layers]
     return KWClip_GeneralTransformer(cfg).eval()
+
+
+def make_batch(B, L, rank=0, dev="cuda", varlen=False):
+    """The synthetic batch of the timed region: seed 7122 + rank, waves 0.1 * randn (every wave L samples, or
+    L_i ~ U{32000..L} zero-padded to the batch maximum as collate_general hands it over), images randn [B, 3, 224, 224], unique ids.
+    tests/test_headline_parity_gpu.py checks the HIP path against the fp32 oracle on THIS batch."""
+    g = torch.Generator(device="cpu").manual_seed(7122 + rank)
+    wav = (0.1 * torch.randn(B, L, generator=g)).to(dev)
+    lens = [L] * B
+    if varlen:
+        lens = [int(x) for x in torch.randint(min(32000, L), L + 1, (B,), generator=g)]
+        wav = wav[:, :max(lens)].contiguous()
+        wav *= (torch.arange(wav.shape[1], device=dev)[None, :] < torch.tensor(lens, device=dev)[:, None])
+    batch = {"wav": wav, "wav_len": torch.tensor(lens, dtype=torch.long), "image": torch.randn(B, 3, 224, 224, generator=g).to(dev),
+             "id": (torch.arange(B) + rank * B).to(dev)}
+    return batch, lens
 
 
 def _cpu_model():
@@ -371,15 +392,7 @@ def main():
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_pairs > 0 and world == 1 and not args.train and not large and not casc) else None
     model = model.to(dev)
     B, L = args.batch, args.audio_len
-    g = torch.Generator(device="cpu").manual_seed(7122 + rank)
-    wav = (0.1 * torch.randn(B, L, generator=g)).to(dev)
-    lens = [L] * B
-    if args.varlen:          # L_i ~ U{32000..160000}; zero right-padding to the batch maximum, as collate_general hands it over
-        lens = [int(x) for x in torch.randint(min(32000, L), L + 1, (B,), generator=g)]
-        wav = wav[:, :max(lens)].contiguous()
-        wav *= (torch.arange(wav.shape[1], device=dev)[None, :] < torch.tensor(lens, device=dev)[:, None])
-    batch = {"wav": wav, "wav_len": torch.tensor(lens, dtype=torch.long), "image": torch.randn(B, 3, 224, 224, generator=g).to(dev),
-             "id": (torch.arange(B) + rank * B).to(dev)}
+    batch, lens = make_batch(B, L, rank, dev, args.varlen)
 
     if args.train:
         model.train()

@@ -232,3 +232,57 @@ def test_gemm_large_full_tile_shapes(M, N, K, lda, act, use_res):
     y0 = ops.gemm(flat, w, None, act, res, M=M, K=K, lda=ld)
     ref0 = _ref(a[:4096], w, None, act, res[:4096] if use_res else None)
     torch.testing.assert_close(y0[:4096].float(), ref0, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K,lda,act", [(4096000, 512, 1536, 1024, 1),      # conv layer 1 of the B = 256 step: the A operand spans 4.19e9 bf16 elements
+                                           (4352000, 512, 1536, 1024, 1),      # ... and one past 2^32 ELEMENTS (4.46e9), A = 8.9 GB
+                                           (2250000, 2304, 768, None, 0)])     # plain GEMM whose OUTPUT passes 2^32 elements (5.18e9 bf16 = 10.4 GB)
+def test_gemm_operands_beyond_32bit_offsets(M, N, K, lda, act):
+    """at B = 256 the conv1 A operand is 4 096 000 rows x lda 1024 = 4.19e9 bf16 elements (8.4 GB: byte offsets pass 2^32 and
+    2^33, element offsets pass 2^31), and the largest operand any earlier GEMM test compared with a reference was 1e8 elements -- a 32-bit offset
+    anywhere in the tile addressing would pass every one of them and bench.py.  Overlapping rows (lda < K) exactly as the conv stack uses them
+    (module/hubert.py), operands filled from a position-dependent pattern (so a row read from the WRONG place cannot match), checked against fp32
+    torch on row blocks at the start, the end, and on both sides of the rows whose element / byte offsets cross 2^31, 2^32 (elements) and 2^32,
+    2^33 (bytes) in A and in C."""
+    from speechclip_amd import ops
+    ld = lda or K
+    n_el = M * ld + K + 8
+    g = torch.Generator(device="cuda").manual_seed(M % 1000 + N + K)
+    flat = torch.empty(n_el, device="cuda", dtype=torch.bfloat16)
+    CH = 1 << 28
+    for s0 in range(0, n_el, CH):                                   # fill in chunks (no 17 GB fp32 temporary)
+        n = min(CH, n_el - s0)
+        flat[s0:s0 + n] = (torch.randn(n, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device="cuda")
+    y = ops.gemm(flat, w, bias, act, None, M=M, K=K, lda=ld)
+    assert y.shape == (M, N)
+    a = torch.as_strided(flat, (M, K), (ld, 1))
+    marks = {0, M - 512}
+    for lim in (2 ** 31, 2 ** 32):
+        for per_row in (ld, 2 * ld, N, 2 * N):                      # element and byte offsets of A rows and of C rows
+            r = lim // per_row
+            if 512 <= r < M - 512:
+                marks |= {r - 256}
+    marks |= {(M // 3) // 256 * 256 + 77, (2 * M // 3) // 256 * 256 + 131}
+    worst = 0.0
+    for r0 in sorted(marks):
+        sl = slice(r0, r0 + 512)
+        ref = _ref(a[sl], w, bias, act, None)
+        torch.testing.assert_close(y[sl].float(), ref, atol=2e-2, rtol=2e-2)
+        worst = max(worst, (y[sl].float() - ref).abs().max().item())
+    # every row was written (a wrapped offset would leave part of C untouched and write another part twice): compare a cheap per-row checksum of the
+    # WHOLE output against the fp32 reference of the same checksum, a[M,K] @ (w^T 1) + sum(bias), for the linear case; finite everywhere otherwise
+    if act == 0:
+        got = torch.empty(M, device="cuda")
+        want = torch.empty(M, device="cuda")
+        wsum = w.float().sum(0)
+        for r0 in range(0, M, 1 << 18):
+            sl = slice(r0, min(M, r0 + (1 << 18)))
+            got[sl] = y[sl].float().sum(1)
+            want[sl] = a[sl].float() @ wsum + bias.sum()
+        torch.testing.assert_close(got, want, atol=0.5, rtol=2e-2)
+    else:
+        for r0 in range(0, M, 1 << 20):
+            assert torch.isfinite(y[r0:r0 + (1 << 20)].float().sum()).item()
+    print(f"M={M} N={N} K={K} lda={ld}: A spans {n_el:.3e} elements, C {M * N:.3e}; {len(marks)} row blocks, max abs err {worst:.4f}")
