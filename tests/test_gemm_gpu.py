@@ -281,7 +281,7 @@ def test_gemm_operands_beyond_32bit_offsets(M, N, K, lda, act):
             sl = slice(r0, min(M, r0 + (1 << 18)))
             got[sl] = y[sl].float().sum(1)
             want[sl] = a[sl].float() @ wsum + bias.sum()
-        torch.testing.assert_close(got, want, atol=0.5, rtol=2e-2)
+        torch.testing.assert_close(got, want, atol=1.5, rtol=2e-2)
     else:
         for r0 in range(0, M, 1 << 20):
             assert torch.isfinite(y[r0:r0 + (1 << 20)].float().sum()).item()
