@@ -179,6 +179,12 @@ int sc_topk_rows_f32(const float* x, int64_t ld, int64_t rows, int V, int K, flo
  * out_{q,h} = Wv_h xbar_r + bv_h (sc_gemm_bf16_batched). */
 int sc_cls_pool_fwd(const void* x, int64_t ld_x, const void* cls_tok, const float* scores, const float* cls_scores,
                     const int32_t* lens, void* xbar, int B, int T, int NQ, int R, int D, void* stream);
+/* The same pooling with the pooled sums kept to ~16 mantissa bits: xbar_hilo bf16 [B, R, nblk*D] = (hi | lo) or (hi | lo | hi), hi + lo = the fp32
+ * sum -- the A operand of a depth-nblk*D sc_gemm_bf16[_batched] against [Wv_h | Wv_h] or [Wv_hi | Wv_hi | Wv_lo] (sc_split_hilo_bf16's convention).  The eval heads use this form (round 4): on the
+ * benchmark's T = 499 batch the utterances' pooled vectors differ by ~1e-2 of their norm, and ONE bf16 rounding of them (2e-3) is visible in the
+ * centred-cosine parity of the embedding (kwClip.py:1099-1104 runs this in fp32). */
+int sc_cls_pool_fwd_split(const void* x, int64_t ld_x, const void* cls_tok, const float* scores, const float* cls_scores,
+                          const int32_t* lens, void* xbar_hilo, int B, int T, int NQ, int R, int D, int nblk, void* stream);
 
 /* ---- HuBERT conv layer 0 -- fairseq ConvFeatureExtractionModel block 0 (speech_encoder_plus.py:75)
  * wav f32 [B, ld] (zero padded, L valid columns), w f32 [C,10], out bf16 channels-last [B, P, C]
@@ -386,7 +392,9 @@ int sc_cls_pool_dz(const float* pp, const float* ds, const float* dzbar, const f
  *                            (zero samples add nothing to the GroupNorm sums, the divisor stays T0: the reference's statistics exactly)
  *   sc_posconv_conv_packed / sc_posconv_finish_packed   conv slab of utterance b = [G][rows_b][D/G] at element row_off[b] * D
  *   sc_attention_fwd_packed  fairseq MHA with key-padding mask over packed q|k|v rows (drop_p > 0: the train-mode form)
- *   sc_unpack_rows           packed -> the reference's padded [n_layers][B][T_out][row] layout (zeros beyond an utterance's rows) */
+ *   sc_unpack_rows           packed -> the reference's padded [n_layers][B][T_out][row] layout: out[l][b][t] = t < rows_b - halo ? src row : 0.
+ *                            The encoder passes halo = 1: the last row of every utterance is the receptive-field halo (inexact, reads the
+ *                            neighbouring utterance's samples) and is not exposed; frames >= max(valid_b, feat_len_b) are zeros. */
 int sc_conv0_fwd_packed(const float* wav, int64_t ld, int64_t L, const float* w, const float* bias, const float* coef, void* out, int B,
                         int C, int T0, const int32_t* row_off, int row_scale, int Pmax, int mode, void* wfrag_ws, void* stream);
 int sc_posconv_conv_packed(const void* x, const int32_t* valid, const int32_t* row_off, const void* wg, void* conv, int B, int Tmax, int D, int G,
@@ -397,7 +405,7 @@ int sc_attention_fwd_packed(const void* q, const void* k, const void* v, void* o
                             int Tmax, int64_t total_rows, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, float drop_p, uint32_t seed,
                             void* stream);
 int sc_unpack_rows(const void* src, int64_t src_layer_stride_bytes, const int32_t* row_off, void* out, int64_t out_layer_stride_bytes, int n_layers,
-                   int B, int T_out, int row_bytes, void* stream);
+                   int B, int T_out, int row_bytes, int halo, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,7 @@ def _declare(L):
         "sc_conv0_wgrad": ([P, L64, P, P, I, I, I, I, P], c_int),
         "sc_topk_rows_f32": ([P, L64, L64, I, I, P, P, P], c_int),
         "sc_cls_pool_fwd": ([P, L64, P, P, P, P, P, I, I, I, I, I, P], c_int),
+        "sc_cls_pool_fwd_split": ([P, L64, P, P, P, P, P, I, I, I, I, I, I, P], c_int),
         "sc_conv0_stats_workspace_bytes": ([I], c_int64),
         "sc_conv0_gn_coef": ([P, L64, P, P, P, P, P, I, I, I, F, P], c_int),
         "sc_conv0_wfrag_workspace_bytes": ([I], c_int64),
@@ -89,7 +90,7 @@ def _declare(L):
         "sc_posconv_conv_packed": ([P, P, P, P, P, I, I, I, I, I, P], c_int),
         "sc_posconv_finish_packed": ([P, P, P, P, P, P, P, P, I, L64, I, I, I, F, P], c_int),
         "sc_attention_fwd_packed": ([P, P, P, P, P, P, I, I, I, L64, I, L64, L64, F, F, U32, P], c_int),
-        "sc_unpack_rows": ([P, L64, P, P, L64, I, I, I, I, P], c_int),
+        "sc_unpack_rows": ([P, L64, P, P, L64, I, I, I, I, I, P], c_int),
         "sc_image_normalize_u8": ([P, P, I, I, I, P, P, P], c_int),
         "sc_vit_patchify": ([P, P, I, I, I, I, P], c_int),
         "sc_vit_embed": ([P, P, P, P, P, P, I, I, I, F, P], c_int),

@@ -548,10 +548,14 @@ __global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict_
 // x . u_r + beta_r are one skinny GEMM ([B*T, D] x [D, R], done by sc_gemm_bf16 with bias = beta, f32 out); this kernel does the
 // softmax over [NQ CLS tokens ; frames t < lens[b]] and the R probability-weighted frame sums xbar_r in one streaming pass over x.
 // Block per utterance; wave w owns keys kk = w (mod 4) with 4 keys in flight; per-wave partial sums are combined through LDS.
-template <int DCH>   // DCH = ceil(D / 256) chunks of 4 elements per lane
+// SPLIT (nblk = 2 / 3): xbar is written as bf16 [B, R, nblk*D] = (hi | lo [| hi]) with hi + lo = the fp32 sum to ~16 bits, the operand layout of a
+// depth-nblk*D GEMM against [W | W] or [W_hi | W_hi | W_lo] (sc_split_hilo_bf16's convention): the pooled vector keeps fp32-grade precision on
+// the bf16 MFMA GEMM that follows (round 4: one bf16 rounding of the pooled vector costs 0.013 of centred cosine on the T = 499 white-noise
+// batch, where utterances differ by 1e-2 of the norm).
+template <int DCH, bool SPLIT>   // DCH = ceil(D / 256) chunks of 4 elements per lane
 __global__ __launch_bounds__(256) void cls_pool_kernel(const bf16_t* __restrict__ x, int64_t ld_x, const bf16_t* __restrict__ cls_tok,
                                                        const float* __restrict__ scores, const float* __restrict__ cls_scores,
-                                                       const int32_t* __restrict__ lens, bf16_t* __restrict__ xbar, int T, int NQ, int R, int D) {
+                                                       const int32_t* __restrict__ lens, bf16_t* __restrict__ xbar, int T, int NQ, int R, int D, int nblk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = (float*)smem;                 // [R][NQ + T]  probabilities
     float* red = sc + 8 * (NQ + T);           // [4 waves][R][D] partial sums (only rows < R used)
@@ -621,7 +625,15 @@ __global__ __launch_bounds__(256) void cls_pool_kernel(const bf16_t* __restrict_
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { s0 += red[(w * 8 + r) * D + d]; s1 += red[(w * 8 + r) * D + d + 1]; }
-        *(uint32_t*)(xbar + ((int64_t)b * R + r) * D + d) = pack2bf(s0, s1);
+        if (SPLIT) {
+            const uint32_t hi = pack2bf(s0, s1);
+            bf16_t* o = xbar + ((int64_t)b * R + r) * nblk * D + d;
+            *(uint32_t*)o = hi;
+            *(uint32_t*)(o + D) = pack2bf(s0 - lo2f(hi), s1 - hi2f(hi));
+            if (nblk == 3) *(uint32_t*)(o + 2 * D) = hi;
+        } else {
+            *(uint32_t*)(xbar + ((int64_t)b * R + r) * D + d) = pack2bf(s0, s1);
+        }
     }
 }
 
@@ -721,25 +733,44 @@ extern "C" int sc_cls_attention_fwd(const void* cls_qkv, const void* kv_x, int64
     return 0;
 }
 
-extern "C" int sc_cls_pool_fwd(const void* x, int64_t ld_x, const void* cls_tok, const float* scores, const float* cls_scores,
-                               const int32_t* lens, void* xbar, int B, int T, int NQ, int R, int D, void* stream) {
+static int cls_pool_launch(const void* x, int64_t ld_x, const void* cls_tok, const float* scores, const float* cls_scores,
+                           const int32_t* lens, void* xbar, int B, int T, int NQ, int R, int D, int nblk, void* stream) {
+    const bool split = nblk > 1;
+    SC_CHECK_ARG(nblk >= 1 && nblk <= 3, "sc_cls_pool_fwd_split: nblk=%d (2: hi|lo, 3: hi|lo|hi)", nblk);
     SC_CHECK_ARG(NQ >= 1 && R >= NQ && R <= 8, "sc_cls_pool_fwd: need 1 <= NQ <= R <= 8 (NQ=%d R=%d)", NQ, R);
     SC_CHECK_ARG(D > 0 && D <= 1024 && D % 4 == 0 && ld_x % 4 == 0, "sc_cls_pool_fwd: D=%d must be a multiple of 4, <= 1024", D);
     if (B <= 0) return 0;
     const int lds = (8 * (NQ + T) + 4 * 8 * D) * 4;
     SC_CHECK_ARG(lds <= 160 * 1024, "sc_cls_pool_fwd: T=%d / D=%d too large for LDS", T, D);
     hipStream_t s = (hipStream_t)stream;
-#define SC_POOL_LAUNCH(DCH)                                                                                                         \
-    do {                                                                                                                            \
-        (void)hipFuncSetAttribute((const void*)cls_pool_kernel<DCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);              \
-        hipLaunchKernelGGL(cls_pool_kernel<DCH>, dim3(B), dim3(256), lds, s, (const bf16_t*)x, ld_x, (const bf16_t*)cls_tok, scores, \
-                           cls_scores, lens, (bf16_t*)xbar, T, NQ, R, D);                                                           \
+#define SC_POOL_LAUNCH(DCH, SPL)                                                                                                         \
+    do {                                                                                                                                 \
+        (void)hipFuncSetAttribute((const void*)cls_pool_kernel<DCH, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);              \
+        hipLaunchKernelGGL((cls_pool_kernel<DCH, SPL>), dim3(B), dim3(256), lds, s, (const bf16_t*)x, ld_x, (const bf16_t*)cls_tok, scores, \
+                           cls_scores, lens, (bf16_t*)xbar, T, NQ, R, D, nblk);                                                          \
     } while (0)
-    if (D <= 256) SC_POOL_LAUNCH(1);
-    else if (D <= 512) SC_POOL_LAUNCH(2);
-    else if (D <= 768) SC_POOL_LAUNCH(3);
-    else SC_POOL_LAUNCH(4);
+#define SC_POOL_BY_D(SPL)                   \
+    do {                                    \
+        if (D <= 256) SC_POOL_LAUNCH(1, SPL);      \
+        else if (D <= 512) SC_POOL_LAUNCH(2, SPL); \
+        else if (D <= 768) SC_POOL_LAUNCH(3, SPL); \
+        else SC_POOL_LAUNCH(4, SPL);               \
+    } while (0)
+    if (split) SC_POOL_BY_D(true);
+    else SC_POOL_BY_D(false);
+#undef SC_POOL_BY_D
 #undef SC_POOL_LAUNCH
     SC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sc_cls_pool_fwd(const void* x, int64_t ld_x, const void* cls_tok, const float* scores, const float* cls_scores,
+                               const int32_t* lens, void* xbar, int B, int T, int NQ, int R, int D, void* stream) {
+    return cls_pool_launch(x, ld_x, cls_tok, scores, cls_scores, lens, xbar, B, T, NQ, R, D, 1, stream);
+}
+
+extern "C" int sc_cls_pool_fwd_split(const void* x, int64_t ld_x, const void* cls_tok, const float* scores, const float* cls_scores,
+                                     const int32_t* lens, void* xbar_hilo, int B, int T, int NQ, int R, int D, int nblk, void* stream) {
+    SC_CHECK_ARG(nblk == 2 || nblk == 3, "sc_cls_pool_fwd_split: nblk=%d (2: hi|lo, 3: hi|lo|hi)", nblk);
+    return cls_pool_launch(x, ld_x, cls_tok, scores, cls_scores, lens, xbar_hilo, B, T, NQ, R, D, nblk, stream);
 }

@@ -103,8 +103,10 @@ __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
     asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(y[1]) : "v"(h), "v"(phi));
     return y;
 }
-#else
-__device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
+#endif
+// fp32 degree-8 form (max |err| 1.7e-5): what every f32-OUTPUT epilogue uses (the packed-half form above carries ~11 bits and is meant for
+// results that are rounded to bf16 right away), and the bf16 epilogues too with -DSC_GELU_F16=0.
+__device__ __forceinline__ f32x2_t gelu_poly2_f32(f32x2_t x) {
     const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -SC_GELU_P_C, SC_GELU_P_C), __builtin_amdgcn_fmed3f(x[1], -SC_GELU_P_C, SC_GELU_P_C)};
     const f32x2_t t = xc * xc * SC_GELU_P_S - 1.0f;
     f32x2_t g = t * 2.012408951e-03f + -6.027759260e-03f;
@@ -117,6 +119,8 @@ __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
     g = g * t + 1.659348977e-01f;
     return x * (xc * g + 0.5f);
 }
+#if !SC_GELU_F16
+__device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) { return gelu_poly2_f32(x); }
 #endif
 __device__ __forceinline__ float gelu_erf_precise(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
 // Counter-based dropout masks: element idx of a tensor is kept iff hash(seed, idx) >= thresh (thresh = p * 2^32); the backward regenerates the

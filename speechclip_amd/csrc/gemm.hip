@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
             }
             if (p.act == SC_ACT_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v4[r] = gelu_erf(v4[r]);
+                for (int r = 0; r < 4; ++r) v4[r] = p.out_f32 ? gelu_erf_precise(v4[r]) : gelu_erf(v4[r]);   // f32 consumers get the 1.5e-7 erf path
             } else if (p.act == SC_ACT_QUICKGELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
@@ -794,8 +794,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 for (int j = 0; j < 4; ++j) {
                     f32x4_t v4 = acc[i][j];
                     v4 += bias4[j];
-                    if (ACT == SC_ACT_GELU) {
-                        const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
+                    if (ACT == SC_ACT_GELU) {       // f32 output: the fp32 polynomial (the packed-half form carries ~11 bits, meant for bf16 results)
+                        const f32x2_t g0 = gelu_poly2_f32((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2_f32((f32x2_t){v4[2], v4[3]});
                         v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
                     } else if (ACT == SC_ACT_QUICKGELU) {
 #pragma unroll
@@ -826,8 +826,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     f32x4_t v4 = acc[i][j];
                     v4 += bias4[j];
                     if (ACT == SC_ACT_GELU) {
-                        const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
-                        v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+                        if (p.out_f32) {
+                            const f32x2_t g0 = gelu_poly2_f32((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2_f32((f32x2_t){v4[2], v4[3]});
+                            v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+                        } else {
+                            const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
+                            v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+                        }
                     } else if (ACT == SC_ACT_QUICKGELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);

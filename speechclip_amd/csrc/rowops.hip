@@ -482,16 +482,17 @@ extern "C" int sc_weighted_sum_fwd(const void* hidden, int64_t layer_stride, con
     return 0;
 }
 
-// Packed -> padded row layout (the API boundary of the padding-free engine): out[l][b][t][:] = t < rows_b ? src[l][row_off[b] + t][:] : 0,
-// rows of `row_bytes` bytes (a multiple of 16), rows_b = row_off[b + 1] - row_off[b].  One wave per output row.
+// Packed -> padded row layout (the API boundary of the padding-free engine): out[l][b][t][:] = t < rows_b - halo ? src[l][row_off[b] + t][:] : 0,
+// rows of `row_bytes` bytes (a multiple of 16), rows_b = row_off[b + 1] - row_off[b].  One wave per output row.  `halo` trailing rows of every
+// utterance are NOT copied (the packed engine's receptive-field row holds inexact conv features that read the neighbouring utterance: ADVICE r3).
 __global__ __launch_bounds__(256) void unpack_rows_kernel(const char* __restrict__ src, int64_t src_layer_stride, const int32_t* __restrict__ row_off,
-                                                          char* __restrict__ out, int64_t out_layer_stride, int B, int T_out, int row_bytes) {
+                                                          char* __restrict__ out, int64_t out_layer_stride, int B, int T_out, int row_bytes, int halo) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= (int64_t)B * T_out) return;
     const int b = (int)(r / T_out), t = (int)(r - (int64_t)b * T_out);
     const int l = blockIdx.y;
-    const int rows_b = row_off[b + 1] - row_off[b];
+    const int rows_b = row_off[b + 1] - row_off[b] - halo;
     const char* s = src + l * src_layer_stride + ((int64_t)row_off[b] + t) * row_bytes;
     char* o = out + l * out_layer_stride + r * row_bytes;
     for (int c = lane * 16; c < row_bytes; c += 64 * 16) {
@@ -502,12 +503,12 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(const char* __restrict
 }
 
 extern "C" int sc_unpack_rows(const void* src, int64_t src_layer_stride_bytes, const int32_t* row_off, void* out, int64_t out_layer_stride_bytes, int n_layers,
-                              int B, int T_out, int row_bytes, void* stream) {
-    SC_CHECK_ARG(src && row_off && out && n_layers >= 1 && n_layers <= 65535 && row_bytes > 0 && row_bytes % 16 == 0, "sc_unpack_rows: bad arguments (row_bytes must be a multiple of 16)");
+                              int B, int T_out, int row_bytes, int halo, void* stream) {
+    SC_CHECK_ARG(src && row_off && out && n_layers >= 1 && n_layers <= 65535 && row_bytes > 0 && row_bytes % 16 == 0 && halo >= 0, "sc_unpack_rows: bad arguments (row_bytes must be a multiple of 16)");
     if (B <= 0 || T_out <= 0) return 0;
     const int64_t rows = (int64_t)B * T_out;
     hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((rows + 3) / 4), n_layers), dim3(256), 0, (hipStream_t)stream, (const char*)src, src_layer_stride_bytes,
-                       row_off, (char*)out, out_layer_stride_bytes, B, T_out, row_bytes);
+                       row_off, (char*)out, out_layer_stride_bytes, B, T_out, row_bytes, halo);
     SC_CHECK_LAUNCH();
     return 0;
 }

@@ -288,10 +288,13 @@ class KW_ParallelBranch(nn.Module):
     def forward(self, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> torch.Tensor:
         if torch.is_grad_enabled() and self.cls.requires_grad:
             return self._forward_train(audio_feat, audio_len)
-        out = self.self_att.forward_cls(self.cls, audio_feat, audio_len)            # bf16 [B, d]
+        out = self.self_att.forward_cls(self.cls, audio_feat, audio_len)            # f32 [B, d] (bf16 with SC_HEAD_PRECISE=0)
         if hasattr(self, "linear_proj"):
-            out = ops.gemm(out, TransformerModels.cached_cast(self.linear_proj.weight, torch.bfloat16),
-                           TransformerModels.cached_cast(self.linear_proj.bias, torch.float32), out_f32=True)
+            if out.dtype == torch.float32:
+                out = TransformerModels.hp_linear(out, self.linear_proj.weight, self.linear_proj.bias)
+            else:
+                out = ops.gemm(out, TransformerModels.cached_cast(self.linear_proj.weight, torch.bfloat16),
+                               TransformerModels.cached_cast(self.linear_proj.bias, torch.float32), out_f32=True)
         return out
 
 
@@ -395,9 +398,12 @@ class KW_CascadedBranch(nn.Module):
         if self.training and torch.is_grad_enabled() and self.cls.requires_grad:
             return self._forward_train(audio_feat, audio_len)
         B, K = audio_feat.shape[0], self.keyword_num
-        kw = self.self_att.forward_cls(self.cls, audio_feat, audio_len)                       # bf16 [B, K, d]
-        kw = ops.gemm(kw.view(B * K, -1), TransformerModels.cached_cast(self.linear_proj.weight, torch.bfloat16),
-                      TransformerModels.cached_cast(self.linear_proj.bias, torch.float32), out_f32=True).view(B, K, self.text_dim)
+        kw = self.self_att.forward_cls(self.cls, audio_feat, audio_len)                       # f32 [B, K, d] (bf16 with SC_HEAD_PRECISE=0)
+        if kw.dtype == torch.float32:
+            kw = TransformerModels.hp_linear(kw.view(B * K, -1), self.linear_proj.weight, self.linear_proj.bias).view(B, K, self.text_dim)
+        else:
+            kw = ops.gemm(kw.view(B * K, -1), TransformerModels.cached_cast(self.linear_proj.weight, torch.bfloat16),
+                          TransformerModels.cached_cast(self.linear_proj.bias, torch.float32), out_f32=True).view(B, K, self.text_dim)
         if hasattr(self, "bn_layer"):
             kw = self.bn_layer(kw)
         emb = self.clip.model.token_embedding.weight

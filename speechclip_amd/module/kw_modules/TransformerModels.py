@@ -7,6 +7,7 @@
 [CLS ; frames] and then keeps only the CLS rows (kwClip.py:1099, :879); here only the CLS rows are computed
 (`forward_cls`): K/V for all frames, Q / attention / FFN / LayerNorm for the NQ learned tokens only.
 """
+import os
 import weakref
 
 import torch
@@ -52,6 +53,47 @@ def cached_cast(t: torch.Tensor, dtype) -> torch.Tensor:
     return out
 
 
+def _w3(w32: torch.Tensor) -> torch.Tensor:
+    """[W_hi | W_hi | W_lo] bf16 [N, 3K] of an fp32 weight [N, K]: with the activation as (a_hi | a_lo | a_hi) (sc_split_hilo_bf16, nblk = 3) ONE
+    bf16 MFMA GEMM of depth 3K adds a_hi W_hi + a_lo W_hi + a_hi W_lo = a W to ~16 bits on BOTH operands (the a_lo W_lo term is 2^-16 relative)."""
+    hi = w32.to(BF)
+    lo = (w32 - hi.float()).to(BF)
+    return torch.cat([hi, hi, lo], dim=1).contiguous()
+
+
+def cached_w3(t: torch.Tensor) -> torch.Tensor:
+    """_w3 of an nn.Linear weight, cached like cached_cast."""
+    key = (t.data_ptr(), "w3")
+    ver = (t._version, ops.param_epoch(t), t.device, tuple(t.shape))
+    hit = _CAST_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is t:
+        return hit[1]
+    out = _w3(t.detach().float())
+    _CAST_CACHE[key] = (ver, out, weakref.ref(t))
+    return out
+
+
+def hp_linear(a32: torch.Tensor, weight: torch.Tensor, bias, act: int = 0, residual=None) -> torch.Tensor:
+    """f32 [M, N] = act(a32 @ W^T + b) (+ residual) at fp32-grade precision on the bf16 MFMA GEMM: activation and weight are both split into bf16
+    (hi, lo) halves and ONE GEMM of depth 3K adds the three significant products in fp32 (see _w3).  Used for the B x NQ CLS rows of the pooling
+    heads only (< 0.1 % of the step): on the benchmark batch (T = 499, white-noise utterances) the embeddings of different utterances differ by
+    1e-2 of their norm, so both the per-utterance noise of a bf16-rounded activation (2e-3) and the common shift of bf16-rounded weights
+    (2e-3) are visible in the centred-cosine parity of the embedding (tests/test_headline_parity_gpu.py); the reference runs these rows in fp32."""
+    b = None if bias is None else cached_cast(bias, torch.float32)
+    N, K = weight.shape
+    if (3 * K) % 64 or N % 4:        # shapes the MFMA GEMM does not take (reduced test dimensions): the fp32 SIMT product
+        y = ops.sgemm(a32.contiguous(), cached_cast(weight, torch.float32), transb=True, bias=b)
+        if act == ACT_GELU:
+            y = ops.gelu_f32(y)
+        elif act:
+            raise NotImplementedError("hp_linear: activation %d on the sgemm fallback" % act)
+        return y if residual is None else y + residual
+    return ops.gemm(ops.split_hilo(a32, 3), cached_w3(weight), b, act, residual, out_f32=True)
+
+
+HEAD_PRECISE = os.environ.get("SC_HEAD_PRECISE", "1") != "0"      # 0: the round-3 head (bf16 activations between the CLS-row GEMMs), for A/B timing
+
+
 def _pool_operands(cls, in_w, in_b, heads):
     """Parameter-only preprocessing of the algebraic CLS pooling (cached per parameter version, like weight-norm folding):
     u_r = scale * Wk_h^T Q_{q,h},  beta_r = scale * Q_{q,h} . bk_h  for r = (q, h);  Q = Wq cls + bq."""
@@ -69,7 +111,8 @@ def _pool_operands(cls, in_w, in_b, heads):
         u = torch.einsum("qhj,hjd->qhd", q, w[D:2 * D].view(heads, hd, D)).reshape(NQ * heads, D).contiguous()
         beta = (q * b[D:2 * D].view(1, heads, hd)).sum(-1).reshape(NQ * heads).contiguous()
         c16 = c.to(BF)
-        ops_ = dict(u16=u.to(BF).contiguous(), beta=beta, cls16=c16.contiguous(), wv=w[2 * D:].to(BF).contiguous(), bv=b[2 * D:].contiguous(),
+        wv16 = w[2 * D:].to(BF).contiguous()
+        ops_ = dict(u16=u.to(BF).contiguous(), beta=beta, cls16=c16.contiguous(), wv=wv16, wv3=_w3(w[2 * D:]), bv=b[2 * D:].contiguous(),
                     cls_scores=(c16.float() @ u.to(BF).float().t() + beta).contiguous())                    # [NQ, R]
     if len(_POOL_CACHE) > 256:
         _POOL_CACHE.clear()
@@ -77,10 +120,10 @@ def _pool_operands(cls, in_w, in_b, heads):
     return ops_
 
 
-def _cls_attention_block(cls: torch.Tensor, audio_feat: torch.Tensor, audio_len: torch.Tensor, in_w, in_b, heads: int):
+def _cls_attention_block(cls: torch.Tensor, audio_feat: torch.Tensor, audio_len: torch.Tensor, in_w, in_b, heads: int, precise: bool = False):
     """CLS-rows-only attention in its algebraic form (sc_cls_pool_fwd): scores x.u_r + beta_r over [CLS tokens ; valid frames],
     softmax, probability-weighted frame sums, then the per-head value projection as a small batched GEMM.  K/V of the frames
-    are never materialised.  Returns bf16 [B*NQ, D] (the concatenated head outputs, before out_proj)."""
+    are never materialised.  Returns [B*NQ, D] (the concatenated head outputs, before out_proj): f32 when `precise`, else bf16."""
     B = audio_feat.shape[0]
     NQ, D = cls.shape[-2], cls.shape[-1]
     hd, R = D // heads, NQ * heads
@@ -88,6 +131,13 @@ def _cls_attention_block(cls: torch.Tensor, audio_feat: torch.Tensor, audio_len:
     P = _pool_operands(cls, in_w, in_b, heads)
     lens = audio_len.to(device=rows.device, dtype=torch.int32).contiguous()
     scores = ops.gemm(rows, P["u16"], P["beta"], out_f32=True)                              # [B*Tp, R] = x . u_r + beta_r
+    if precise:
+        # pooled sums as (hi | lo | hi) bf16 blocks, value projection as a depth-3D GEMM against [Wv_hi | Wv_hi | Wv_lo], fp32 out: neither the
+        # pooled vector nor the weight is rounded to 8 bits
+        xbar3 = ops.cls_pool(rows, P["cls16"], scores, P["cls_scores"], lens, B, Tp, NQ, R, D, split=3)   # bf16 [B, R, 3D]
+        out = torch.empty(B * NQ, D, device=rows.device, dtype=torch.float32)
+        ops.gemm_batched(xbar3, R * 3 * D, 3 * D, P["wv3"], hd * 3 * D, heads, out, NQ * D, hd, P["bv"], B, hd, 3 * D, R)
+        return out
     xbar = ops.cls_pool(rows, P["cls16"], scores, P["cls_scores"], lens, B, Tp, NQ, R, D)   # bf16 [B, R, D]
     out = torch.empty(B * NQ, D, device=rows.device, dtype=BF)
     ops.gemm_batched(xbar, R * D, D, P["wv"], hd * D, heads, out, NQ * D, hd, P["bv"], B, hd, D, R)
@@ -113,14 +163,24 @@ class TransformerEncoder(nn.Module):
                                         norm_first=norm_first), n_layers, d_model)
 
     def forward_cls(self, cls: torch.Tensor, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> torch.Tensor:
-        """cls [1,1,D]; audio_feat bf16 [B,T,D]; audio_len [B] (valid frames, without the CLS).  -> bf16 [B, D]:
+        """cls [1,1,D]; audio_feat bf16 [B,T,D]; audio_len [B] (valid frames, without the CLS).  -> f32 [B, D] (bf16 with SC_HEAD_PRECISE=0):
         row 0 of norm(layer([CLS; x])) -- what kwClip.py:1097-1099 keeps."""
         L = self.model.layers[0]
         sa = L.self_attn
         D = cls.shape[-1]
-        att = _cls_attention_block(cls, audio_feat, audio_len, sa.in_proj_weight, sa.in_proj_bias, self.nhead)
         f32 = lambda t: cached_cast(t, torch.float32)  # noqa: E731
         w16 = lambda t: cached_cast(t, BF)             # noqa: E731
+        if HEAD_PRECISE:
+            # the CLS row stays fp32 from the pooled sums to the embedding (the reference runs this branch in fp32 / autocast with fp32 LayerNorms):
+            # every Linear is a (hi | lo)-split GEMM (hp_linear), LayerNorms fp32 in / fp32 out.  B rows: < 0.1 % of the step.
+            att = _cls_attention_block(cls, audio_feat, audio_len, sa.in_proj_weight, sa.in_proj_bias, self.nhead, precise=True)
+            y = hp_linear(att, sa.out_proj.weight, sa.out_proj.bias, residual=f32(cls).reshape(1, D).expand(att.shape[0], D))   # x + SA(x), CLS rows
+            x1 = ops.layernorm(y, f32(L.norm1.weight), f32(L.norm1.bias), self.eps, out_f32=True)
+            h = hp_linear(x1, L.linear1.weight, L.linear1.bias, ACT_GELU)
+            y2 = hp_linear(h, L.linear2.weight, L.linear2.bias, residual=x1)
+            x2 = ops.layernorm(y2, f32(L.norm2.weight), f32(L.norm2.bias), self.eps, out_f32=True)
+            return ops.layernorm(x2, f32(self.model.norm.weight), f32(self.model.norm.bias), 1e-5, out_f32=True)
+        att = _cls_attention_block(cls, audio_feat, audio_len, sa.in_proj_weight, sa.in_proj_bias, self.nhead)
         y = ops.gemm(att, w16(sa.out_proj.weight), f32(sa.out_proj.bias), residual=f32(cls).reshape(1, D).expand(att.shape[0], D),
                      out_f32=True)                                                       # x + SA(x), CLS rows
         x1 = ops.layernorm(y, f32(L.norm1.weight), f32(L.norm1.bias), self.eps, out_f32=True)
@@ -179,14 +239,18 @@ class MultiheadAttentionAndNorm(nn.Module):
         self.attentionBlock_Norm = nn.LayerNorm(d_model, eps=layer_norm_eps)
 
     def forward_cls(self, cls: torch.Tensor, audio_feat: torch.Tensor, audio_len: torch.Tensor) -> torch.Tensor:
-        """cls [1,K,D] -> bf16 [B, K, D]: rows 0..K-1 of LN(MHA([CLS;x]) + [CLS;x])  (kwClip.py:877-881)."""
+        """cls [1,K,D] -> f32 [B, K, D] (bf16 with SC_HEAD_PRECISE=0): rows 0..K-1 of LN(MHA([CLS;x]) + [CLS;x])  (kwClip.py:877-881)."""
         m = self.multihead_attn_layer
         NQ, D = cls.shape[-2], cls.shape[-1]
         B = audio_feat.shape[0]
-        att = _cls_attention_block(cls, audio_feat, audio_len, m.in_proj_weight, m.in_proj_bias, self.nhead)
         res = cls.detach().float().reshape(1, NQ, D).expand(B, NQ, D).reshape(B * NQ, D).contiguous()
-        y = ops.gemm(att, cached_cast(m.out_proj.weight, BF), cached_cast(m.out_proj.bias, torch.float32), residual=res, out_f32=True)
         n = self.attentionBlock_Norm
+        if HEAD_PRECISE:          # fp32 keyword rows (see TransformerEncoder.forward_cls)
+            att = _cls_attention_block(cls, audio_feat, audio_len, m.in_proj_weight, m.in_proj_bias, self.nhead, precise=True)
+            y = hp_linear(att, m.out_proj.weight, m.out_proj.bias, residual=res)
+            return ops.layernorm(y, cached_cast(n.weight, torch.float32), cached_cast(n.bias, torch.float32), self.eps, out_f32=True).view(B, NQ, D)
+        att = _cls_attention_block(cls, audio_feat, audio_len, m.in_proj_weight, m.in_proj_bias, self.nhead)
+        y = ops.gemm(att, cached_cast(m.out_proj.weight, BF), cached_cast(m.out_proj.bias, torch.float32), residual=res, out_f32=True)
         return ops.layernorm(y, cached_cast(n.weight, torch.float32), cached_cast(n.bias, torch.float32), self.eps).view(B, NQ, D)
 
     @torch.no_grad()

@@ -230,15 +230,21 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if pack is not None:
             # Padding-free engine (module/hubert.py: packed_geometry): `hidden` is [n, sum_b rows_b, d].  The padded [B, T, d] layout of the
             # reference is restored at this boundary only -- for the mixed frames when nobody needs the states themselves, else for all states.
-            # Rows beyond an utterance's own frames (the reference holds padded-frame outputs there, which the heads mask: :604-611) are zeros.
+            # Rows beyond an utterance's own frames (the reference holds padded-frame outputs there, which the heads mask: :604-611) are zeros,
+            # the engine's halo row (inexact: it reads the neighbouring utterance) included.
             off = ops.dev_ints(pack["row_off"], torch.int32, dev)
             ws = getattr(self, "weightedsum_layer", None)
             if (feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE and not return_hidden_states
                     and not (torch.is_grad_enabled() and ws.weights.requires_grad)):
                 assert hidden.shape[0] == ws.n_weights, hidden.shape[0]
-                mixed = ops.unpack_rows(ops.weighted_sum(hidden, ws.weights.detach().float(), ws.normalize_features), off, padded.shape[0], T)
+                mixed = ops.unpack_rows(ops.weighted_sum(hidden, ws.weights.detach().float(), ws.normalize_features), off, padded.shape[0], T, halo=1)
                 return (mixed, feat_len)
-            hidden = ops.unpack_rows(hidden, off, padded.shape[0], T)                                                  # [n, B, T, d]
+            hidden = ops.unpack_rows(hidden, off, padded.shape[0], T, halo=1)                                                  # [n, B, T, d]
+        escapes = return_hidden_states or feat_select_idx != FEAT_SELECT_IDX_WEIGHTED_SUM_MODE
+        if pack is None and escapes:
+            # the engine's `hidden` is a reused workspace: states handed to the CALLER (hidden_states / last_hidden_state / a layer list) are copied
+            # out, as the reference returns fresh tensors (speech_encoder_plus.py:596-602) -- a second forward would silently rewrite them otherwise
+            hidden = hidden.clone()
         layers = lambda: tuple(hidden[i, :, :T] for i in range(hidden.shape[0]))  # noqa: E731
         out = []
         if feat_select_idx == "all":

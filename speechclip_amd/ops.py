@@ -351,13 +351,19 @@ def cls_attention(cls_qkv, kv_x, lens_i32, B, T, NQ, H, hd):
     return out
 
 
-def cls_pool(x_rows, cls16, scores, cls_scores, lens_i32, B, T, NQ, R, D):
-    """x_rows bf16 [B*T, D]; cls16 bf16 [NQ, D]; scores f32 [B*T, R]; cls_scores f32 [NQ, R] -> xbar bf16 [B, R, D]."""
+def cls_pool(x_rows, cls16, scores, cls_scores, lens_i32, B, T, NQ, R, D, split=0):
+    """x_rows bf16 [B*T, D]; cls16 bf16 [NQ, D]; scores f32 [B*T, R]; cls_scores f32 [NQ, R] -> xbar bf16 [B, R, D], or with split = 2 / 3 the
+    (hi | lo [| hi]) blocks bf16 [B, R, split*D] that keep the fp32 pooled sums to ~16 bits (operand of a depth-split*D GEMM against [W | W] /
+    [W_hi | W_hi | W_lo])."""
     _need_cuda(x_rows, cls16, scores, cls_scores)
     assert x_rows.dtype == bf16 and x_rows.stride(1) == 1 and scores.dtype == torch.float32 and scores.shape == (B * T, R) and scores.is_contiguous()
-    xbar = torch.empty(B, R, D, device=x_rows.device, dtype=bf16)
-    check(lib().sc_cls_pool_fwd(ptr(x_rows), x_rows.stride(0), ptr(cls16), ptr(scores), ptr(cls_scores), ptr(lens_i32), ptr(xbar), B, T, NQ, R, D,
-                                stream()), "sc_cls_pool_fwd")
+    xbar = torch.empty(B, R, (split or 1) * D, device=x_rows.device, dtype=bf16)
+    if split:
+        check(lib().sc_cls_pool_fwd_split(ptr(x_rows), x_rows.stride(0), ptr(cls16), ptr(scores), ptr(cls_scores), ptr(lens_i32), ptr(xbar), B, T, NQ, R, D,
+                                          int(split), stream()), "sc_cls_pool_fwd_split")
+    else:
+        check(lib().sc_cls_pool_fwd(ptr(x_rows), x_rows.stride(0), ptr(cls16), ptr(scores), ptr(cls_scores), ptr(lens_i32), ptr(xbar), B, T, NQ, R, D,
+                                    stream()), "sc_cls_pool_fwd")
     return xbar
 
 
@@ -455,8 +461,9 @@ def attention_packed(qkv, B, rows_max, H, klens_i32, row_off_i32, out=None, drop
     return out
 
 
-def unpack_rows(src, row_off_i32, B, T_out):
-    """src [n, total_rows, D] or [total_rows, D] (packed) -> [n, B, T_out, D] / [B, T_out, D], zeros beyond each utterance's rows."""
+def unpack_rows(src, row_off_i32, B, T_out, halo=0):
+    """src [n, total_rows, D] or [total_rows, D] (packed) -> [n, B, T_out, D] / [B, T_out, D], zeros beyond each utterance's rows; the last `halo`
+    rows of every utterance are not copied (the packed engine's receptive-field row)."""
     _need_cuda(src, row_off_i32)
     three = src.dim() == 3
     s3 = src if three else src.unsqueeze(0)
@@ -464,7 +471,7 @@ def unpack_rows(src, row_off_i32, B, T_out):
     assert s3.is_contiguous() and (D * s3.element_size()) % 16 == 0
     out = torch.empty(n, B, T_out, D, device=src.device, dtype=src.dtype)
     rb = D * s3.element_size()
-    check(lib().sc_unpack_rows(ptr(s3), total * rb, ptr(row_off_i32), ptr(out), B * T_out * rb, n, B, T_out, rb, stream()), "sc_unpack_rows")
+    check(lib().sc_unpack_rows(ptr(s3), total * rb, ptr(row_off_i32), ptr(out), B * T_out * rb, n, B, T_out, rb, int(halo), stream()), "sc_unpack_rows")
     return out if three else out[0]
 
 

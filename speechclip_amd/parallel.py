@@ -74,22 +74,28 @@ def gather_loss_feats(feats: Dict[str, torch.Tensor], force: bool = False) -> Di
     return out
 
 
-def gather_rows_dict(d: dict) -> dict:
-    """Validation outputs (`others`: id, audio_feat, image_feat, text_feat, keywords ...): every tensor whose dim 0 is the local batch is
-    all-gathered rank-major (float tensors of any trailing shape in ONE packed collective with the ids; other integer tensors one collective
-    each), non-tensors are passed through.  The reference's DataParallel hands validation_epoch_end the outputs of ALL replicas
+ROW_KEYS_1D = ("row_score",)      # 1-D float entries of validation outputs that ARE per-row ([B] -> [B, 1]); anything else 1-D is passed through
+
+
+def gather_rows_dict(d: dict, keys_1d=ROW_KEYS_1D) -> dict:
+    """Validation outputs (`others`: id, audio_feat, image_feat, text_feat, keywords ...): every tensor with >= 2 dims whose dim 0 is the local
+    batch is all-gathered rank-major (float tensors of any trailing shape in ONE packed collective with the ids; other integer tensors one
+    collective each), non-tensors are passed through.  1-D float tensors are gathered only when named in `keys_1d` (a [1] scalar-like entry at
+    B == 1 is not a row tensor: ADVICE r3).  The reference's DataParallel hands validation_epoch_end the outputs of ALL replicas
     (kwClip.py:193-275): recall is ranked against the full candidate pool, not a per-rank shard."""
     rank, ws = world()
     if ws == 1:
         return d
     B = d["id"].shape[0]
-    # all_gather_into_tensor needs the same local batch on every rank (the reference's DataParallel splits evenly too): fail loudly otherwise
+    # all_gather_into_tensor needs the same local batch on every rank (the reference's DataParallel splits evenly too): fail loudly otherwise.
+    # ONE small all-reduce and ONE device->host read per call (it must precede the gather: ranks with different B would deadlock inside it).
     bmm = torch.tensor([B, -B], device=d["id"].device, dtype=torch.int64)
     dist.all_reduce(bmm, op=dist.ReduceOp.MAX)
-    if int(bmm[0]) != B or int(-bmm[1]) != B:
-        raise ValueError(f"gather_rows_dict: local batch {B} differs across ranks (max {int(bmm[0])}, min {int(-bmm[1])}); use drop_last / equal shards")
-    # every float tensor whose dim 0 is the local batch is a row tensor, 1-D ones included ([B] -> [B, 1])
-    flt = {k: v for k, v in d.items() if torch.is_tensor(v) and v.is_floating_point() and v.dim() >= 1 and v.shape[0] == B}
+    bmax, nbmin = bmm.tolist()
+    if bmax != B or -nbmin != B:
+        raise ValueError(f"gather_rows_dict: local batch {B} differs across ranks (max {bmax}, min {-nbmin}); use drop_last / equal shards")
+    flt = {k: v for k, v in d.items() if torch.is_tensor(v) and v.is_floating_point() and v.dim() >= 1 and v.shape[0] == B
+           and (v.dim() >= 2 or k in keys_1d)}
     shapes = {k: v.shape[1:] for k, v in flt.items()}
     feats = {k: v.reshape(B, -1) for k, v in flt.items()}
     feats["id"] = d["id"]
@@ -99,7 +105,7 @@ def gather_rows_dict(d: dict) -> dict:
         res[k] = out[k].view(ws * B, *shapes[k]).to(flt[k].dtype)
     res["id"] = out["id"]
     for k, v in d.items():
-        if k != "id" and torch.is_tensor(v) and not v.is_floating_point() and v.dim() >= 1 and v.shape[0] == B:
+        if k != "id" and torch.is_tensor(v) and not v.is_floating_point() and v.dim() >= 2 and v.shape[0] == B:
             g = torch.empty(ws * B, *v.shape[1:], device=v.device, dtype=v.dtype)
             dist.all_gather_into_tensor(g, v.contiguous())
             res[k] = g

@@ -124,7 +124,7 @@ def test_p_base_headline_b256_vs_oracle():
         o_par = l2_normalize(ref.parallel_branch(feat, o_flen))
     ref_loss = ref.compute_loss({"parallel_audio_feat": o_par, "image_feat": o_img, "id": sub["id"]})["loss"].item()
     _check_subset("P-base B=256 T=499", idx, flen, last, lf, "parallel_audio_feat", o_par, o_flen, hidden[-1], o_img, sub["id"].cuda(), 1 / 0.07,
-                  lambda a, i, ids: ops.infonce(a, i, ids).item(), ref_loss)
+                  lambda a, i, ids: ops.infonce(a, i, ids)[0].item(), ref_loss)
     # the FULL-batch loss is the InfoNCE of the full-batch embeddings (fp32 oracle loss on the HIP embeddings), not merely "about ln 256"
     from oracle.speechclip_ref import masked_contrastive_loss
     want = masked_contrastive_loss(lf["parallel_audio_feat"].float().cpu(), lf["image_feat"].float().cpu(), batch["id"].cpu()).item()
@@ -165,7 +165,7 @@ def test_p_large_b64_ragged_vs_oracle():
         o_par = l2_normalize(ref.parallel_branch(feat, o_flen))
     ref_loss = ref.compute_loss({"parallel_audio_feat": o_par, "image_feat": o_img, "id": sub["id"]})["loss"].item()
     _check_subset("P-large B=64 ragged", idx, flen, last, lf, "parallel_audio_feat", o_par, o_flen, hidden[-1], o_img, sub["id"].cuda(), inv_t,
-                  lambda a, i, ids: ops.infonce(a, i, ids, inv_temperature=inv_t).item(), ref_loss)
+                  lambda a, i, ids: ops.infonce(a, i, ids, inv_temperature=inv_t)[0].item(), ref_loss)
 
 
 def test_c_base_b256_vs_oracle():
@@ -223,7 +223,7 @@ def test_c_base_b256_vs_oracle():
     assert raw.min().item() >= 0.999 and cc.min().item() >= 0.98, (raw.tolist(), cc.tolist())
     if len(rows) >= 2:
         ids = sub["id"][rows].cuda()
-        hip_loss = ops.infonce(lf["cascaded_audio_feat"][idx][rows].float().contiguous(), lf["image_feat"][idx][rows].float().contiguous(), ids).item()
+        hip_loss = ops.infonce(lf["cascaded_audio_feat"][idx][rows].float().contiguous(), lf["image_feat"][idx][rows].float().contiguous(), ids)[0].item()
         from oracle.speechclip_ref import masked_contrastive_loss
         ref_loss = masked_contrastive_loss(o["cascaded_audio_feat"][rows], o["image_feat"][rows], sub["id"][rows]).item()
         assert abs(hip_loss - ref_loss) <= 2e-2, (hip_loss, ref_loss)

@@ -337,7 +337,8 @@ def _one_collective_worker(rank, world, port, q):
     calls.clear()
     others = {"id": feats["id"], "audio_feat": feats["parallel_audio_feat"].detach(), "image_feat": feats["image_feat"],
               "keywords": torch.randn(B, 2, 4, generator=g), "gold_text": torch.arange(B * 5).view(B, 1, 5) + 100 * rank, "note": "x",
-              "row_score": torch.randn(B, generator=g)}        # a 1-D per-row float tensor travels in the packed collective too
+              "row_score": torch.randn(B, generator=g),         # a NAMED 1-D per-row float tensor travels in the packed collective too
+              "scalar_like": torch.randn(B, generator=g)}       # ... an unnamed 1-D float of length B does not (a [1] entry at B == 1)
     go = parallel.gather_rows_dict(others)
     q.put((rank, n_train, ok_grad, len(calls), {k: (v.numpy().copy() if torch.is_tensor(v) else v) for k, v in go.items()},
            {k: (v.numpy().copy() if torch.is_tensor(v) else v) for k, v in others.items()},
@@ -368,8 +369,89 @@ def test_train_gather_is_one_collective_and_validation_outputs_are_gathered_gloo
         want = np.concatenate([res[0][5][k], res[1][5][k]], 0)
         for r in res:
             assert r[4][k].dtype == want.dtype and np.array_equal(r[4][k], want), k
+    for r in res:
+        assert np.array_equal(r[4]["scalar_like"], r[5]["scalar_like"])      # passed through, not gathered
     for k in ("id", "image_feat", "parallel_audio_feat", "cascaded_audio_feat"):
         assert np.array_equal(res[0][6][k], res[1][6][k])
+
+
+def _step_end_worker(rank, world, port, q, train):
+    """One rank of the 8-rank global-batch-2048 protocol test: the REAL training_step_end / validation_step_end + compute_loss of the model class
+    on this rank's 256-row shard of the golden B = 2048 fixture.  No GPU here, so the criterion is the fp32 oracle's masked InfoNCE standing in
+    for sc_infonce_fwd (tests/test_kernels_gpu.py::test_infonce_golden pins the kernel on the same fixture at Bg = 2048)."""
+    import types
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from oracle.speechclip_ref import masked_contrastive_loss
+    from speechclip_amd.base import OrderedNamespace
+    from speechclip_amd.model.kwClip import KWClip_GeneralTransformer, KWClipBase
+    g = np.load(os.path.join(GOLD, "loss.npz"))
+    Bg = 2048
+    B = Bg // world
+    sl = slice(rank * B, (rank + 1) * B)
+    a = torch.from_numpy(g["fa_2048"][sl]).clone().requires_grad_(train)
+    feats = {"id": torch.from_numpy(g["ids_2048"][sl]).clone(), "image_feat": torch.from_numpy(g["fb_2048"][sl]).clone(), "parallel_audio_feat": a}
+    m = types.SimpleNamespace()
+    m.config = OrderedNamespace({"model_settings": {"cascaded_objective_weight": 0.0, "parallel_objective_weight": 1.0}})
+    m.criterion = lambda feat_A, feat_B, index: masked_contrastive_loss(feat_A, feat_B, index)
+    m.compute_loss = types.MethodType(KWClip_GeneralTransformer.compute_loss, m)
+    m._reduce_metrics = types.MethodType(KWClipBase._reduce_metrics, m)
+    logged = {}
+    m.log_dict = lambda d, **kw: logged.update({k: float(v) for k, v in d.items()})
+    if train:
+        out = KWClipBase.training_step_end(m, {"loss_feats": feats, "log_metrics": {"cl_temp": 1 / 0.07}})
+        out["loss"].backward()
+        q.put((rank, float(out["loss"]), a.grad.numpy().copy(), logged))
+    else:
+        others = {"id": feats["id"], "audio_feat": feats["parallel_audio_feat"], "image_feat": feats["image_feat"]}
+        got = KWClipBase.validation_step_end(m, {"loss_feats": feats, "log_metrics": {"cl_temp": 1 / 0.07}, "others": others})
+        q.put((rank, logged["val_loss"], {k: v.numpy().copy() for k, v in got.items()}, logged))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_step_end_hooks_gloo_world8_global_batch_2048(train):
+    """BASELINE.json configs[3] protocol without the 8-GPU node: 8 ranks x 256 pairs with DUPLICATE ids run the model's own
+    training_step_end / validation_step_end; every rank must see the loss of the single-process computation on the rank-major concatenation
+    (= nn.DataParallel's dim-0 gather, kwClip.py:147-191), which is the value the REFERENCE's MaskedContrastiveLoss produced for this very
+    batch (tests/golden/loss.npz B = 2048, MAX_EYE patched: losses.py:126,211); in training the local rows' gradient is the rank's slice of the
+    single-process gradient; in validation every rank ends up with all 2048 rows in rank-major order."""
+    import torch.multiprocessing as mp
+    from oracle.speechclip_ref import masked_contrastive_loss
+    g = np.load(os.path.join(GOLD, "loss.npz"))
+    golden = [c[8] for c in g["cases"] if int(c[0]) == 2048 and c[2] == 0 and c[3] == 0 and c[4] == 1 and c[5] == 1 and abs(c[6] - 1 / 0.07) < 1e-6 and c[7] == 1]
+    assert len(golden) == 1
+    ids = g["ids_2048"]
+    assert len(np.unique(ids)) < len(ids)                      # duplicate ids: the false-negative mask matters
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_step_end_worker, args=(r, world, port, q, train)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    A = torch.from_numpy(g["fa_2048"]).clone().requires_grad_(True)
+    Bm, idt = torch.from_numpy(g["fb_2048"]), torch.from_numpy(ids)
+    single = masked_contrastive_loss(A, Bm, idt)
+    assert abs(single.item() - golden[0]) < 2e-5 * max(1.0, abs(golden[0]))
+    for r in res:
+        assert abs(r[1] - golden[0]) < 2e-5 * max(1.0, abs(golden[0])), (r[0], r[1], golden[0])      # every rank: the reference's global-batch loss
+        assert abs(r[3]["train_loss" if train else "val_loss"] - r[1]) < 1e-6 and abs(r[3][("train" if train else "val") + "_cl_temp"] - 1 / 0.07) < 1e-4
+    if train:
+        single.backward()
+        got = torch.cat([torch.from_numpy(r[2]) for r in res])
+        # every rank differentiates the SAME global loss; the optimizer sums the ranks' parameter gradients (FusedAdam all-reduce), so a rank's
+        # feature gradient is its row slice of the single-process gradient
+        assert torch.allclose(got, A.grad, atol=1e-7, rtol=1e-5)
+    else:
+        for r in res:
+            assert np.array_equal(r[2]["id"], ids) and np.array_equal(r[2]["audio_feat"], g["fa_2048"]) and np.array_equal(r[2]["image_feat"], g["fb_2048"])
 
 
 def test_pretrained_checkpoint_loaders_from_local_files(tmp_path, monkeypatch):

@@ -169,6 +169,28 @@ def test_unpack_rows_kernel():
         assert out[:, b, n:].abs().max().item() == 0 if n < 7 else True
     one = ops.unpack_rows(src[0].float().contiguous(), torch.tensor(off, dtype=torch.int32).cuda(), 4, 9)
     assert one.shape == (4, 9, 64) and torch.equal(one[2, :9], src[0, off[2]:off[2] + 9].float())
+    # halo = 1 (what the encoder passes): the last row of every utterance -- the packed engine's receptive-field row -- is NOT exposed
+    hal = ops.unpack_rows(src, torch.tensor(off, dtype=torch.int32).cuda(), 4, 7, halo=1)
+    for b, r in enumerate(rows):
+        n = min(r - 1, 7)
+        assert torch.equal(hal[:, b, :n], src[:, off[b]:off[b] + n])
+        assert n == 7 or hal[:, b, n:].abs().max().item() == 0
+
+
+def test_returned_hidden_states_do_not_alias_the_engine_workspace():
+    """The reference returns fresh tensors (speech_encoder_plus.py:596-602): hidden states handed to the caller must survive a second forward on a
+    different batch (the engine's `hidden` buffer is a reused workspace; until round 4 the padded path returned views of it)."""
+    model, _, _ = _tiny(False)
+    g = torch.Generator().manual_seed(3)
+    w1, w2 = (0.1 * torch.randn(3, 6000, generator=g)).cuda(), (0.1 * torch.randn(3, 6000, generator=g)).cuda()
+    ln = torch.tensor([6000, 6000, 6000]).cuda()
+    with torch.no_grad():
+        _, _, hid1 = model.forward_audio(w1, ln, return_hidden_states=True)
+        keep = [h.clone() for h in hid1]
+        _, _, hid2 = model.forward_audio(w2, ln, return_hidden_states=True)
+    for a, b in zip(hid1, keep):
+        assert torch.equal(a, b), "a later forward rewrote hidden states that were already returned"
+    assert not torch.equal(hid1[-1], hid2[-1])
 
 
 def test_workspaces_do_not_multiply_with_the_batch_maximum():
