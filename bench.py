@@ -124,7 +124,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(model_sd, n_pairs, L, iters=3):
+def cpu_baseline(model_sd, n_pairs, L, iters=3, keep=None):
     """fp32 CPU oracle (port of the reference's CPU path) on the host cores, SURVEY.md section 8(d) protocol: 1 warm-up + `iters` timed
     iterations of (a) `n_pairs` fixed-length pairs of the headline workload and (b) the C1 batch (BASELINE configs[0]: 16 pairs, variable
     lengths); os.cpu_count() and the CPU model stated; per-segment split (CNN / transformer / layer mix + branch / ViT / loss) from module
@@ -188,6 +188,8 @@ def cpu_baseline(model_sd, n_pairs, L, iters=3):
                 t1 = time.perf_counter()
                 loss = ref.compute_loss(o)["loss"].item()
                 t2 = time.perf_counter()
+                if keep is not None and n == n_pairs:          # the fixed-length sample: inputs + oracle outputs of the LAST timed iteration (parity_check)
+                    keep.update(batch=b, out={k: o[k] for k in ("parallel_audio_feat", "image_feat")}, loss=loss)
                 times.append(t2 - t0)
                 t_loss += t2 - t1
         tot = sum(times)
@@ -214,6 +216,101 @@ def cpu_baseline(model_sd, n_pairs, L, iters=3):
             "sample": f"{iters} timed iterations (after 1 warm-up) of {n_pairs} pairs (10 s audio + 224^2 image) through oracle/speechclip_ref.py fp32 "
                       f"with {cores} torch threads (best of 8/16/32/64/all on a 2-pair probe; host: {ncpu} hardware threads, {_cpu_model()}), "
                       f"{sum(fixed['iter_s']):.1f} s; plus the C1 batch ({n_c1} pairs, variable lengths) {c1['pairs_per_s']} pairs/s"}
+
+
+def parity_check(model, keep, dev):
+    """The HIP path against the CPU baseline's OWN outputs: the same 32 pairs and the same weights the `cpu_baseline` leg just ran through the fp32
+    oracle go through the GPU model; centred cosine per embedding row (tests/helpers.py: the reference's batch mean removed from both sides; the
+    same rows rotated by one as the negative control), loss difference and the largest logit difference.  Thresholds = the test-suite's
+    (tests/test_headline_parity_gpu.py); `ok` says whether this very run met them."""
+    import torch.nn.functional as F
+    b, o = keep["batch"], keep["out"]
+    with torch.no_grad():
+        lf, _, _ = model({k: v.to(dev) for k, v in b.items()})
+        loss = model.compute_loss(lf)["loss"].item()
+
+    def ccos(got, ref):
+        got, ref = got.float().cpu(), ref.float().cpu()
+        mu = ref.mean(0, keepdim=True)
+        return F.cosine_similarity(got - mu, ref - mu, dim=-1), F.cosine_similarity(torch.roll(got, 1, 0) - mu, ref - mu, dim=-1)
+    ca, wa = ccos(lf["parallel_audio_feat"], o["parallel_audio_feat"])
+    ci, wi = ccos(lf["image_feat"], o["image_feat"])
+    lg = ((lf["parallel_audio_feat"].float().cpu() @ lf["image_feat"].float().cpu().t()) - (o["parallel_audio_feat"] @ o["image_feat"].t())) / 0.07
+    raw = F.cosine_similarity(lf["parallel_audio_feat"].float().cpu(), o["parallel_audio_feat"], dim=-1).min().item()
+    out = {"pairs": int(b["id"].shape[0]), "against": "cpu_baseline's own fp32 oracle outputs on the same inputs and weights (last timed iteration)",
+           "audio_centred_cos_min": round(ca.min().item(), 5), "audio_centred_cos_mean": round(ca.mean().item(), 5),
+           "image_centred_cos_min": round(ci.min().item(), 5), "rotated_rows_centred_cos_max": round(max(wa.max().item(), wi.max().item()), 4),
+           "audio_raw_cos_min": round(raw, 7), "loss_gpu": round(loss, 5), "loss_cpu": round(keep["loss"], 5), "loss_abs_diff": round(abs(loss - keep["loss"]), 6),
+           "logit_max_abs_diff": round(lg.abs().max().item(), 5),
+           "thresholds": {"centred_cos_min": 0.99, "rotated_rows_max": 0.9, "loss_abs_diff": 2e-2, "logit_max_abs_diff": 5e-2}}
+    out["ok"] = bool(out["audio_centred_cos_min"] >= 0.99 and out["image_centred_cos_min"] >= 0.99 and out["rotated_rows_centred_cos_max"] < 0.9
+                     and out["loss_abs_diff"] <= 2e-2 and out["logit_max_abs_diff"] <= 5e-2)
+    return out
+
+
+OTHER_CONFIGS = ("cascaded_v8112", "large_b64", "varlen_packed", "varlen_padded", "train")
+
+
+def other_config(kind, dev, batch=None, steps=5, warmup=2):
+    """One of the NON-headline configurations, timed the same way (fences, wall clock, inputs resident) with a short run, so that the driver's one
+    line carries every BASELINE.json config.  Never part of `value`.
+      cascaded_v8112  configs[2]  Cascaded SpeechCLIP base, reduced vocabulary of 8112 sub-words, B = 256, 10 s
+      large_b64       configs[4]  Parallel SpeechCLIP large (HuBERT-large + ViT-L/14), 64 pairs per GPU (model_large/coco/spchclp_p.yaml:10 over 4 GPUs), 10 s
+      varlen_packed / varlen_padded   configs[1] with L_i ~ U{32000..160000}: padding-free engine vs the reference's padded layout (SC_VARLEN_PACK=0)
+      train           configs[1] training step of the trainable tail (train-mode crop to 102400 samples, loss.backward(), clip, Adam, LR schedule)"""
+    from speechclip_amd import parallel
+    large, casc, train, varlen = kind == "large_b64", kind == "cascaded_v8112", kind == "train", kind.startswith("varlen")
+    model = build_model(large=large, cascaded=casc).to(dev)
+    B = batch or (64 if large else 256)
+    L = 160000
+    b, lens = make_batch(B, L, 0, dev, varlen)
+    old_pack = os.environ.get("SC_VARLEN_PACK")
+    if kind == "varlen_padded":
+        os.environ["SC_VARLEN_PACK"] = "0"
+    try:
+        if train:
+            model.train()
+            (opt,), (sch,) = model.configure_optimizers()
+
+            def step():
+                opt.zero_grad()
+                loss = model.training_step_end(model.training_step(b, 0))["loss"]
+                loss.backward()
+                opt.step()
+                sch["scheduler"].step()
+                return loss.detach()
+        else:
+            def step():
+                with torch.no_grad():
+                    lf, _, _ = model(b)
+                    return model.compute_loss(parallel.gather_loss_feats(lf))["loss"]
+        for _ in range(warmup):
+            loss = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        if kind == "varlen_padded":
+            if old_pack is None:
+                os.environ.pop("SC_VARLEN_PACK", None)
+            else:
+                os.environ["SC_VARLEN_PACK"] = old_pack
+    mal = int(getattr(model.audio_encoder, "max_audio_len", -1))
+    eff = [min(n, mal) if (train and mal > 0) else n for n in lens]
+    cache = {}
+    for n in set(eff):
+        cache[n] = algorithmic_gflop_per_pair(n, **(LARGE if large else {}))[0]
+    gf = sum(cache[n] for n in eff) / B + (0.9 if casc else 0.0)     # cascaded head: + ~2.1 GF instead of the parallel head's 1.19 (BASELINE.md section 2)
+    pps = B * steps / dt
+    out = {"ms_per_step": round(dt / steps * 1e3, 3), "pairs_per_s": round(pps, 2), "pairs_per_gpu": B, "steps": steps, "warmup": warmup,
+           "algorithmic_gflop_per_pair": round(gf, 2), "e2e_tflops": round(gf * pps / 1e3, 1), "e2e_frac": round(gf * pps / 1e3 / PEAK_BF16_TFLOPS, 4),
+           "audio_samples_mean": int(sum(eff) / B), "loss": round(float(loss), 5)}
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def _free_port():
@@ -351,6 +448,14 @@ def main():
                     "spchclp_c.yaml:94; 49408 = the full table)")
     ap.add_argument("--no-vendor-comparator", action="store_true", help="skip the hipBLASLt comparator run beside the headline")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the rocm-smi clock / power reading taken beside the timed region")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the non-headline configurations (cascaded, large, varlen packed / "
+                    "padded, train) that the default N = 1 headline run reports beside `value` as `other_configs`")
+    ap.add_argument("--dump-gemm-launches", default=None, help="write the per-step list of GEMM launches (shape, epilogue, tower) as JSON: "
+                    "tools/make_traffic_json.py aligns the PMC rows of the same command with it, so `roofline.traffic` covers exactly the launches "
+                    "`roofline.launches_per_step` counts")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto", help="replay the local part of the step (both towers + head: everything before "
+                    "the exchange) from a captured HIP graph on the steps that are not instrumented with events.  auto: on for N > 1 (eight Python "
+                    "launchers on one host must not become the bottleneck), off for N = 1 (the eager step is what earlier rounds measured)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of the launcher + exchange protocol (no GPU, no kernels)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST HOOK for 1-GPU boxes: all N ranks run on cuda:0 and exchange over gloo, so the N > 1 code "
                     "path (packed gather, global-batch loss, max-over-ranks timing) executes with the real kernels; the line says so in `data`")
@@ -419,12 +524,48 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     fence()
+    # ---- HIP graph of the LOCAL part of the step (both towers + head, everything ahead of the exchange): N > 1 by default.  The exchange (one
+    # all_gather_into_tensor) and the loss stay eager (3 launches); the steps instrumented with HIP events run eagerly (events need the launches).
+    use_graph = (args.graph == "on" or (args.graph == "auto" and world > 1)) and not args.train
+    graph_note, replay_step = None, None
+    if use_graph:
+        try:
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                with torch.no_grad():
+                    model(batch)                                   # allocations of the capture stream's pool settle before the capture
+            torch.cuda.current_stream().wait_stream(cap)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                with torch.no_grad():
+                    g_lf, _, _ = model(batch)
+
+            def replay_step():
+                graph.replay()
+                with torch.no_grad():
+                    return model.compute_loss(parallel.gather_loss_feats(g_lf))["loss"]
+            l_g = float(replay_step())
+            l_e = float(step())
+            if abs(l_g - l_e) > 1e-5:
+                raise RuntimeError("replayed step loss %.6f != eager %.6f" % (l_g, l_e))
+            graph_note = "hip graph (towers + head captured once, replayed; exchange + loss eager)"
+        except Exception as e:     # noqa: BLE001  -- a capture problem must not cost the measurement: fall back to the eager step and SAY so
+            replay_step, graph_note = None, "eager (graph capture failed: %s)" % (str(e)[:200],)
+            torch.cuda.synchronize()
+    if world > 1:                  # all ranks take the same path (a rank replaying beside a rank launching eagerly would still be correct, only uneven)
+        flag = torch.tensor([1.0 if replay_step is not None else 0.0], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if flag.item() < 1 and replay_step is not None:
+            replay_step, graph_note = None, "eager (another rank could not capture)"
+    fence()
     # roofline instrumentation: HIP events around every GEMM launch of every THIRD timed step (two events per launch, ~220 launches per
     # step: on every step they cost ~1 % of the step time they are meant to explain)
     prof = None if args.no_roofline_events else []
     hbm_prof, xchg_prof = [], []
     ops.PROFILE_SIDE = []
     ev_steps = 0
+    host_s = {"eager": [0.0, 0], "graph": [0.0, 0]}               # host time spent INSIDE the step calls (launching), by launch method
     t0 = time.perf_counter()
     for i in range(args.steps):
         instrumented = prof is not None and (i % 3 == 2 or args.steps < 3)
@@ -432,7 +573,15 @@ def main():
         ops.PROFILE_HBM = hbm_prof if instrumented else None
         parallel.PROFILE_EXCHANGE = xchg_prof if instrumented else None       # the exchange measured INSIDE the step (events around the gather)
         ev_steps += int(instrumented)
-        loss = step()
+        h0 = time.perf_counter()
+        if replay_step is not None and not instrumented:
+            loss = replay_step()
+            how = "graph"
+        else:
+            loss = step()
+            how = "eager"
+        host_s[how][0] += time.perf_counter() - h0
+        host_s[how][1] += 1
     ops.PROFILE = ops.PROFILE_HBM = parallel.PROFILE_EXCHANGE = None
     fence()
     dt = time.perf_counter() - t0
@@ -559,13 +708,14 @@ def main():
             ach = alg / (ms * 1e-3) / 1e12
             # HBM traffic of the kernel cannot be measured from inside this process (PMC counters need rocprofv3 and their own passes):
             # report the committed per-launch figure of the same command, with its source, or null if it is not there / not this workload
-            traffic, tsrc = None, None
+            traffic, tsrc, traffic_launches = None, None, None
             import glob
             import hashlib
             tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_hbm_traffic.json")))      # the newest round's PMC pass
             if tfs and not args.train and not large and not casc and B == 256 and L == 160000 and not args.varlen:
                 tj = json.load(open(tfs[-1]))
                 traffic = tj["gemm_main_stream"]["bytes_per_launch"]
+                traffic_launches = tj["gemm_main_stream"].get("launches_per_step")
                 from speechclip_amd import _lib as _l
                 sha = hashlib.sha256(open(_l.LIB_PATH, "rb").read()).hexdigest()[:16]
                 same = tj.get("lib_sha16") == sha
@@ -582,8 +732,8 @@ def main():
             # launches wait for CUs inside their event window (stretched, overlapping in wall time) and are reported as `side_stream`.
             main_stream = torch.cuda.current_stream().cuda_stream
 
-            def concurrent(e):
-                return e[4] != main_stream
+            def concurrent(e):       # image-tower launches (side stream when the towers overlap; tagged by the model, so SC_OVERLAP_VIT=0 classifies the same)
+                return e[5] == "image" if len(e) > 5 else e[4] != main_stream
             flags_c = [concurrent(e) for e in prof]
             part = {}
             for path, name in ((0, "hand_written"), (1, "vendor")):
@@ -601,10 +751,16 @@ def main():
                     "windows_ms_per_step": round(sum(w0.elapsed_time(w1) for w0, w1 in ops.PROFILE_SIDE) / ev_steps, 3),
                     "note": "image-tower GEMMs on the side stream: they wait for CUs inside their event window (stretched, overlapping the main stream in "
                             "wall time); not counted in achieved.  SC_OVERLAP_VIT=0 serialises the towers"} if csel else None
+            if args.dump_gemm_launches:
+                per = len(prof) // ev_steps
+                json.dump({"launches_per_step": per, "overlap_image_tower": os.environ.get("SC_OVERLAP_VIT", "1") != "0",
+                           "launches": [{"M": e[3][0], "N": e[3][1], "K": e[3][2], "act": e[3][3], "res": bool(e[3][4]), "out_f32": bool(e[3][5]),
+                                         "batch": (e[3][7] if len(e[3]) > 7 else 1), "tower": e[5]} for e in prof[:per]]},
+                          open(args.dump_gemm_launches, "w"), indent=0)
             hw = part["hand_written"]
             roof = {"bound": "mfma", "kernel": "gemm256_kernel family (hand-written HIP: fused-GELU / QuickGELU epilogues, conv-as-GEMM with overlapping rows, small shapes)",
                     "achieved": hw["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(hw["achieved"] / PEAK_BF16_TFLOPS, 4),
-                    "traffic": traffic, "traffic_source": tsrc, "launches_per_step": hw["launches_per_step"], "avg_launch_ms": hw["avg_launch_ms"],
+                    "traffic": traffic, "traffic_source": tsrc, "traffic_launches_per_step": traffic_launches, "launches_per_step": hw["launches_per_step"], "avg_launch_ms": hw["avg_launch_ms"],
                     "ms_per_step": hw["ms_per_step"],
                     "vendor_plain_gemms": dict(part["vendor"], kernel="hipBLASLt (plain QKV / out-proj / fc2 / ViT projections behind the same sc_gemm_bf16 entry)",
                                                frac=round(part["vendor"]["achieved"] / PEAK_BF16_TFLOPS, 4) if part["vendor"]["achieved"] else None),
@@ -650,11 +806,32 @@ def main():
                             "timed beside the step with random payloads; exchange_in_step_ms = the same three operations timed by HIP events INSIDE the instrumented "
                             "steps (includes waiting for the slowest rank's towers); both max over ranks") if world > 1 else None,
                "vendor_comparator": vendor, "varlen_padded_comparator": varlen_cmp, "measured_ceiling_8k_cubed": ceiling, "hbm_segments": hbm, "clock": clock,
-               "loss": round(float(loss), 5), "roofline": roof, "cpu_baseline": None}
+               "loss": round(float(loss), 5), "roofline": roof, "cpu_baseline": None, "parity_check": None, "other_configs": None}
+        out["step_launch"] = {"method": graph_note or "eager (one Python launcher thread per GPU)",
+                              "host_launch_ms_per_step": {k: round(v[0] / v[1] * 1e3, 3) for k, v in host_s.items() if v[1]},
+                              "steps_by_method": {k: v[1] for k, v in host_s.items() if v[1]},
+                              "note": "host time spent inside the step calls (enqueueing); the instrumented steps (HIP events) always launch eagerly"}
+        if clock is not None:
+            clock["joules_per_step"] = round(clock["socket_power_w"] * dt / args.steps, 2)
+            clock["joules_per_pair"] = round(clock["socket_power_w"] * dt / args.steps / (world * B), 4)
+            clock["energy_note"] = "socket power (rocm-smi, polled during the extra untimed steps) x the TIMED region's ms_per_step"
         if sd_cpu is not None:
+            keep = {}
+            out["cpu_baseline"] = cpu_baseline(sd_cpu, args.cpu_pairs, L, keep=keep)
+            if keep:
+                out["parity_check"] = parity_check(model, keep, dev)
+        if world == 1 and not args.no_other_configs and not args.train and not large and not casc and not args.varlen:
             del model
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(sd_cpu, args.cpu_pairs, L)
+            oc = {}
+            for kind in OTHER_CONFIGS:
+                try:
+                    oc[kind] = other_config(kind, dev, batch=args.batch if args.batch != 256 else None, steps=5 if args.steps >= 5 else 2, warmup=2 if args.warmup >= 2 else 1)
+                except Exception as e:     # noqa: BLE001
+                    oc[kind] = {"error": str(e)[:300]}
+            oc["note"] = ("short runs (same fences and clock as the headline, inputs resident) of the other BASELINE.json configurations, one after the other in "
+                          "this process; never part of `value`.  --model / --varlen / --train give each its own full line")
+            out["other_configs"] = oc
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

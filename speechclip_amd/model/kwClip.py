@@ -548,7 +548,9 @@ class KWClip_GeneralTransformer(KWClipBase):
                 if ops.PROFILE is not None:        # bench instrumentation: the window in which two kernels may share the CUs
                     w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     w0.record()
+                ops.PROFILE_TAG = "image"
                 image_feat = self.forward_image(image)
+                ops.PROFILE_TAG = "speech"
                 if ops.PROFILE is not None:
                     w1.record()
                     ops.PROFILE_SIDE.append((w0, w1))
@@ -557,10 +559,14 @@ class KWClip_GeneralTransformer(KWClipBase):
             image_feat.record_stream(cur)
         else:
             audio_feat, audio_len = self.forward_audio(wav, wav_len)
+            ops.PROFILE_TAG = "image"
             image_feat = self.forward_image(image)
+            ops.PROFILE_TAG = "speech"
         if self.img_enc_proj_net is not None:
             image_feat = self.img_enc_proj_net(image_feat)
+        ops.PROFILE_TAG = "head"
         c_feat, p_feat, vq, kw = self._branches(audio_feat, audio_len)
+        ops.PROFILE_TAG = "speech"
         image_feat = ops.l2norm(image_feat)
         loss_feats = {"id": ids, "image_feat": image_feat}
         log_metrics = {}

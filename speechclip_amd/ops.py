@@ -38,6 +38,7 @@ class _HbmSpan:
             e1.record()
             PROFILE_HBM.append((self.e0, e1, float(self.nbytes), self.tag, torch.cuda.current_stream().cuda_stream))
         return False
+PROFILE_TAG = "speech"   # which part of the step is launching ("speech" / "image" / "head"): set by KWClip_GeneralTransformer.forward, stored as entry[5]
 PROFILE_SIDE = []     # (start, end) HIP events of every side-stream window (the image tower running beside the speech tower) while PROFILE is on
 
 _GEMM_WS = {}
@@ -121,7 +122,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, act, residual is not None, out_f32, int(lib().sc_gemm_last_path())),
-                        torch.cuda.current_stream().cuda_stream))
+                        torch.cuda.current_stream().cuda_stream, PROFILE_TAG))
     return out
 
 
@@ -148,7 +149,7 @@ def gemm_ln(a, w, bias, mode, act=ACT_NONE, residual=None, out=None, ln_stats=No
     check(rc, "sc_gemm_bf16_ln")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, act, residual is not None, False, 0), torch.cuda.current_stream().cuda_stream))
+        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, act, residual is not None, False, 0), torch.cuda.current_stream().cuda_stream, PROFILE_TAG))
     return out
 
 
@@ -190,7 +191,7 @@ def gemm_batched(a, lda, stride_a, w, stride_w, w_mod, out, ldc, stride_c, bias,
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, act, False, False, 0, batch),   # tag[6] = path (0 hand-written), tag[7] = batch
-                        torch.cuda.current_stream().cuda_stream))
+                        torch.cuda.current_stream().cuda_stream, PROFILE_TAG))
     return out
 
 

@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8", *extra],
+def _run(*extra, steps=2):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1", "--batch", "8", *extra],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
@@ -45,6 +45,20 @@ def test_bench_json_contract_forward():
     seg = c["fixed_length"]["segments_frac"]
     assert set(seg) == {"cnn", "transformer", "vit", "branch", "loss", "mix_and_glue"} and abs(sum(seg.values()) - 1) < 0.02
     assert c["c1_varlen_b16"]["pairs_per_s"] > 0
+    # round 4: the line carries its own parity check (GPU vs the cpu_baseline leg's oracle outputs on the same pairs and weights) ...
+    pc = d["parity_check"]
+    assert pc["pairs"] == 2 and pc["loss_abs_diff"] <= 2e-2 and pc["audio_raw_cos_min"] > 0.9999 and "ok" in pc and set(pc["thresholds"]) >= {"centred_cos_min", "loss_abs_diff"}
+    # ... every other BASELINE.json configuration as a short run beside the headline ...
+    oc = d["other_configs"]
+    for kind in ("cascaded_v8112", "large_b64", "varlen_packed", "varlen_padded", "train"):
+        assert set(oc[kind]) >= {"ms_per_step", "pairs_per_s", "algorithmic_gflop_per_pair", "e2e_frac", "pairs_per_gpu"}, (kind, oc[kind])
+        assert oc[kind]["pairs_per_s"] > 0 and 0 < oc[kind]["e2e_frac"] < 1
+    assert oc["varlen_packed"]["algorithmic_gflop_per_pair"] < d["config"]["algorithmic_gflop_per_pair"] < oc["large_b64"]["algorithmic_gflop_per_pair"]
+    # ... the launch method with the host's enqueue time, and energy next to the clock
+    sl = d["step_launch"]
+    assert sl["method"].startswith("eager") and sl["host_launch_ms_per_step"]["eager"] > 0
+    assert k is None or (k["joules_per_step"] > 0 and abs(k["joules_per_pair"] * 8 - k["joules_per_step"]) < 0.02 * k["joules_per_step"] + 0.01)
+    assert r["traffic_launches_per_step"] is None or r["traffic_launches_per_step"] == r["launches_per_step"]
 
 
 def test_bench_json_contract_train_and_cascaded():
@@ -64,3 +78,17 @@ def test_bench_two_ranks_on_one_gpu_exercises_the_multi_rank_path():
     assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert d["exchange_ms_per_step"] > 0 and d["value"] > 0 and "share-gpu" in d["data"]
     assert abs(d["loss"] - 2.77) < 0.3                                  # ~ ln(16): the loss saw the GLOBAL batch of 16 pairs
+    # N > 1: the local part of the step replays from a captured HIP graph on the non-instrumented steps
+    assert d["step_launch"]["method"].startswith("hip graph"), d["step_launch"]
+
+
+def test_bench_eight_ranks_on_one_gpu_weak_and_strong():
+    """BASELINE.json configs[3] launch shape on the one GPU this box has: `--gpus 8 --share-gpu` runs EIGHT ranks with the real
+    kernels (each its own process, HIP graph replay, packed gather over gloo, loss on the global batch, max-over-ranks timing, one rank-0 line) --
+    weak scaling (fixed pairs per rank) and strong scaling (`--global-batch`, split over the ranks)."""
+    d = _run("--gpus", "8", "--share-gpu", "--cpu-pairs", "0", "--no-vendor-comparator", "--no-clock-probe", steps=4)
+    assert d["n_gpus"] == 8 and d["rccl_ranks_seen"] == 8 and d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp8" and d["scaling"] == "weak"
+    assert abs(d["loss"] - 4.16) < 0.3                                  # ~ ln(64): the loss saw all 64 pairs
+    assert d["step_launch"]["method"].startswith("hip graph") and d["step_launch"]["host_launch_ms_per_step"]["graph"] > 0
+    s = _run("--gpus", "8", "--share-gpu", "--cpu-pairs", "0", "--no-vendor-comparator", "--no-clock-probe", "--global-batch", "64")
+    assert s["scaling"] == "strong" and s["config"]["pairs_per_gpu"] == 8 and s["config"]["global_batch"] == 64 and s["rccl_ranks_seen"] == 8
