@@ -37,8 +37,13 @@ except Exception:  # noqa: BLE001
 
         @classmethod
         def load_from_checkpoint(cls, path, map_location="cpu", strict=True, **kwargs):
-            ckpt = torch.load(path, map_location=map_location, weights_only=False)
+            # Lightning checkpoints pickle pytorch_lightning classes (`callbacks` is keyed by the ModelCheckpoint CLASS, base_task.py:176-193) next to
+            # the avssl OrderedNamespace in `hyper_parameters`: read with the restricted unpickler (inert stubs for what is not importable here)
+            from ..util.checkpoint_io import load_pickled_checkpoint
+            ckpt, _ = load_pickled_checkpoint(path, map_location=map_location)
             config = ckpt["hyper_parameters"]["config"]
+            if not isinstance(config, OrderedNamespace):
+                raise TypeError(f"{path}: hyper_parameters['config'] is {type(config).__name__}, expected the avssl OrderedNamespace (base_model.py:14)")
             model = cls(config)
             load_checkpoint_state(model, ckpt["state_dict"], strict=strict)
             return model

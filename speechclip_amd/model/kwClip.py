@@ -66,12 +66,14 @@ class KWClipBase(BaseLightningModel):
         raise NotImplementedError("Unknown type:{}".format(self.audio_encoder_type))
 
     def forward_image(self, images: Union[list, torch.Tensor]) -> torch.Tensor:
-        if isinstance(images, list):
-            raise NotImplementedError("image files -> tensors is data-layer work (avssl/data, out of scope); pass a [B,3,H,W] tensor")
-        if not isinstance(images, torch.Tensor):
+        if isinstance(images, list):          # kwClip.py:517-518: paths -> ClipModel.prep_image (PIL + CLIP `_transform`) on the model's device
+            self.clip.update_device(self.device)
+            images = self.clip.prep_image(images)
+        elif isinstance(images, torch.Tensor):
+            if images.dim() != 4 or images.shape[1] != 3:
+                raise ValueError(f"Incorrect image tensor shape {images.shape}")
+        else:
             raise TypeError(f"Unknown image type {type(images)}")
-        if images.dim() != 4 or images.shape[1] != 3:
-            raise ValueError(f"Incorrect image tensor shape {images.shape}")
         return self.clip.encode_image(images)
 
     def forward(self, batch: dict) -> tuple:

@@ -55,12 +55,26 @@ class ClipModel(nn.Module):
         if clip_config is not None and not isinstance(clip_config, ClipConfig):
             clip_config = ClipConfig(**dict(clip_config.to_dict() if hasattr(clip_config, "to_dict") else clip_config))
         cfg = clip_config if clip_config is not None else ClipConfig.from_name(name)
-        self.model = CLIP(cfg)
         ckpt = os.environ.get("SPEECHCLIP_CLIP_CKPT", "")
+        ckpt_sd = None
         if ckpt and os.path.isfile(ckpt):
-            self.model.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=False)
+            # clip_official.py:50 `clip.load(name, device)`: openai's files are TorchScript archives; read without the `clip` package, fp16 -> fp32 as
+            # clip.load does on the CPU, architecture derived from the tensor shapes as clip.model.build_model does -- and it must be the NAMED one
+            from ..util.checkpoint_io import clip_config_from_state_dict, load_clip_state_dict
+            ckpt_sd = load_clip_state_dict(ckpt)
+            file_cfg = clip_config_from_state_dict(ckpt_sd)
+            if file_cfg != cfg:
+                raise ValueError(f"{ckpt} holds {file_cfg}, but clip.name = {name!r} is {cfg}")
+        elif ckpt:
+            raise FileNotFoundError(f"SPEECHCLIP_CLIP_CKPT={ckpt} does not exist")
+        self.model = CLIP(cfg)
+        if ckpt_sd is not None:
+            from ..util.checkpoint_io import CLIP_NON_WEIGHT_KEYS, strict_load
+            strict_load(self.model, ckpt_sd, allow_unexpected=CLIP_NON_WEIGHT_KEYS, what=f"CLIP checkpoint {ckpt}")
         self.image_encoder_trainable, self.text_encoder_trainable = image_encoder_trainable, text_encoder_trainable
         self.out_dim = self.model.transformer.width
+        from ..data.image_transforms import clip_preprocess
+        self.image_preprocess = clip_preprocess(cfg.image_resolution)        # clip_official.py:50: the `preprocess` clip.load returns
         self.tokenizer = _TokenizerIds(cfg.vocab_size)
         for p in self.model.parameters():
             p.requires_grad = False
@@ -91,6 +105,12 @@ class ClipModel(nn.Module):
         super().to(*args, **kwargs)
         self.device = self.model.token_embedding.weight.device
         return self
+
+    def prep_image(self, paths: list) -> torch.Tensor:
+        """clip_official.py:151-164: image files -> pre-processed tensor [B, 3, H, W] on self.device.  PIL open + bicubic resize + centre crop on the
+        host (data/image_transforms.py), then the batch goes to the device as uint8 and is scaled / normalised there (sc_image_normalize_u8)."""
+        from ..data.image_transforms import load_images_u8, normalize_u8
+        return normalize_u8(load_images_u8(paths, self.model.cfg.image_resolution), self.device)
 
     def encode_image(self, image: torch.Tensor) -> torch.Tensor:
         return self.model.encode_image(image)

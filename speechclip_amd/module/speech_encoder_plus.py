@@ -72,17 +72,30 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
                 hc["conv_layers"] = [tuple(c) for c in hc["conv_layers"]]
             hubert_config = HubertConfig(**hc)
         cfg = hubert_config if hubert_config is not None else HubertConfig.from_name(name)
-        self.encoder = HubertModel(cfg)
-        self.encoder_task = type("Task", (), {"cfg": type("Cfg", (), {"normalize": cfg.normalize})()})()
+        ckpt_sd = None
         if pretrained:
             ckpt = _find_local_ckpt(self.MODEL2URL[name])
             if ckpt is None:
                 logger.warning("pretrained=True but no local HuBERT checkpoint (set SPEECHCLIP_HUBERT_CKPT); using random init")
             else:
-                sd = torch.load(ckpt, map_location="cpu")
-                sd = sd.get("model", sd)
-                missing, unexpected = self.encoder.load_state_dict(sd, strict=False)
-                logger.info(f"Loaded {ckpt}: missing={missing} unexpected={unexpected}")
+                # speech_encoder_plus.py:380-398: fairseq.checkpoint_utils.load_model_ensemble_and_task builds the model FROM THE CHECKPOINT'S cfg
+                # (extractor_mode, conv_bias, layer_norm_first ...; task.cfg.normalize decides the wave layer-norm, :507-508), not from its name.
+                # fairseq itself is not needed: util/checkpoint_io.py unpickles the file with inert stubs for fairseq's classes.
+                from ..util.checkpoint_io import load_fairseq_hubert
+                file_cfg, ckpt_sd, stubbed = load_fairseq_hubert(ckpt)
+                if hubert_config is not None and file_cfg != cfg:
+                    raise ValueError(f"{ckpt}: the checkpoint's own configuration {file_cfg} differs from the hubert_config that was passed in {cfg}")
+                if file_cfg != cfg:
+                    logger.info(f"{ckpt}: architecture read from the checkpoint's cfg: {file_cfg} (name `{name}` alone would give {cfg})")
+                cfg = file_cfg
+                logger.info(f"{ckpt}: {len(ckpt_sd)} tensors; {len(stubbed)} pickled classes replaced by inert stubs")
+        self.encoder = HubertModel(cfg)
+        self.encoder_task = type("Task", (), {"cfg": type("Cfg", (), {"normalize": cfg.normalize})()})()
+        if ckpt_sd is not None:
+            from ..util.checkpoint_io import HUBERT_UNUSED_KEYS, strict_load
+            # every weight of the forward must be in the file; the pre-training head (final_proj, label_embs_concat) and mask_emb are never reached
+            # by customHubertForward (speech_encoder_plus.py:67-107) and are the only keys that may be absent on either side
+            strict_load(self.encoder, ckpt_sd, allow_missing=HUBERT_UNUSED_KEYS, allow_unexpected=HUBERT_UNUSED_KEYS, what=f"HuBERT checkpoint {ckpt}")
         if layer_drop != "original":          # speech_encoder_plus.py:405-412: a float overrides the checkpoint's rate, "original" keeps it
             self.encoder.encoder.layerdrop = float(layer_drop)
         for p in self.encoder.parameters():
