@@ -217,10 +217,12 @@ class KWClipBase(BaseLightningModel):
         aud_feats = torch.cat([x["audio_feat"] for x in outputs], dim=0)
         print("Total #{} images, #{} audio".format(len(img_feats), len(aud_feats)))
         dev = self.device
-        if dev.type == "cuda":     # fp32 similarity matrix on the device (kwClip.py:487-491), then the rank kernel
-            score = ops.sgemm(aud_feats.float().to(dev).contiguous(), img_feats.float().to(dev).contiguous(), transb=True)
-        else:
-            score = torch.matmul(aud_feats.float(), img_feats.float().T)
+        if dev.type != "cuda":
+            from .._lib import SpeechClipHipError
+            raise SpeechClipHipError("validation_epoch_end scores and ranks on the MI355X (sc_sgemm + sc_retrieval_ranks): move the model to the GPU; "
+                                     "there is no host fallback")
+        # fp32 similarity matrix on the device (kwClip.py:487-491), then the rank kernel
+        score = ops.sgemm(aud_feats.float().to(dev).contiguous(), img_feats.float().to(dev).contiguous(), transb=True)
         return self.reportRetrieval(score_per_A=score, score_per_B=score.T.contiguous(), AB_answers=all_ids, BA_answers=img_ids)
 
     def reportRetrieval(self, score_per_A, score_per_B, AB_answers, BA_answers,

@@ -8,13 +8,15 @@ import torch
 
 def _recall_one_way(score: torch.Tensor, own_ids: torch.Tensor, cand_ids: torch.Tensor, recall_at: Sequence[int]) -> dict:
     n, m = score.shape
-    if score.is_cuda:       # device path: sc_retrieval_ranks (one pass per row, no sort)
-        from .. import ops
-        rank = ops.retrieval_ranks(score.float().contiguous(), own_ids, cand_ids)
-    else:                   # host tensors (the Lightning hook hands CPU tensors to validation_epoch_end when no GPU is involved)
-        pos = cand_ids.to(score.device)[None, :] == own_ids.to(score.device)[:, None]
-        best = torch.where(pos, score, torch.full_like(score, float("-inf"))).max(dim=1, keepdim=True).values
-        rank = torch.where(pos.any(dim=1), (score > best).sum(dim=1), torch.full((n,), m, device=score.device))
+    # There is ONE implementation: sc_retrieval_ranks on the MI355X.  Host score matrices (the reference's validation_epoch_end hands CPU tensors
+    # to mutualRetrieval, kwClip.py:487-491) are moved to the device; without a GPU / the library this raises -- no host re-implementation.
+    from .. import ops
+    from .._lib import SpeechClipHipError
+    if not score.is_cuda:
+        if not torch.cuda.is_available():
+            raise SpeechClipHipError("mutualRetrieval ranks on the MI355X (sc_retrieval_ranks); no GPU is visible and there is no host fallback")
+        score = score.cuda()
+    rank = ops.retrieval_ranks(score.float().contiguous(), own_ids, cand_ids)
     out = {}
     for k in recall_at:
         if k > m:

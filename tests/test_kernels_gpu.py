@@ -293,6 +293,11 @@ def test_retrieval_ranks_golden_and_random():
     for i, k in enumerate((1, 5, 10)):
         assert abs(ab[f"recall@{k}"] - g["recall_ab"][i]) < 1e-4 and abs(ba[f"recall@{k}"] - g["recall_ba"][i]) < 1e-4
         assert abs(mean[f"recall@{k}"] - g["recall_mean"][i]) < 1e-4
+    # HOST score matrices (what the reference's validation_epoch_end hands over, kwClip.py:487-491) take the same device kernel
+    sh = torch.from_numpy(g["aud"]) @ torch.from_numpy(g["img"]).t()
+    ab_h, ba_h, mean_h = mutualRetrieval(sh, sh.t().contiguous(), torch.from_numpy(g["aud_ids"]), torch.from_numpy(g["img_ids"]), [1, 5, 10])
+    for i, k in enumerate((1, 5, 10)):
+        assert abs(ab_h[f"recall@{k}"] - g["recall_ab"][i]) < 1e-4 and abs(ba_h[f"recall@{k}"] - g["recall_ba"][i]) < 1e-4
     gen = _g(77)
     n_img, cap, E = 1000, 5, 512
     imgf = F.normalize(torch.randn(n_img, E, generator=gen), dim=-1)
