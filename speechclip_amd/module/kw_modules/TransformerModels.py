@@ -81,7 +81,10 @@ def hp_linear(a32: torch.Tensor, weight: torch.Tensor, bias, act: int = 0, resid
     (2e-3) are visible in the centred-cosine parity of the embedding (tests/test_headline_parity_gpu.py); the reference runs these rows in fp32."""
     b = None if bias is None else cached_cast(bias, torch.float32)
     N, K = weight.shape
-    if (3 * K) % 64 or N % 4:        # shapes the MFMA GEMM does not take (reduced test dimensions): the fp32 SIMT product
+    # The fp32 SIMT product instead: shapes the MFMA GEMM does not take (reduced test dimensions), and deep-K products with few rows -- 256 x 768 x
+    # (3 x 3072) is three 256 x 256 tiles walking 144 k-steps each (104 us) where sc_sgemm spreads the same product over the chip (46 us;
+    # tools/head_bench.py)
+    if (3 * K) % 64 or N % 4 or (K >= 2048 and a32.shape[0] <= 1024):
         y = ops.sgemm(a32.contiguous(), cached_cast(weight, torch.float32), transb=True, bias=b)
         if act == ACT_GELU:
             y = ops.gelu_f32(y)
