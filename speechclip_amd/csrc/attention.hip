@@ -45,6 +45,9 @@ constexpr int NSTAGE = 3;
 #ifndef SC_ATTN_PP
 #define SC_ATTN_PP 0
 #endif
+#ifndef SC_ATTN_SCALAR             // bit 0: score offset as single v_fma_f32; bit 1: row sums as single v_add_f32 (instead of the packed-f32 forms)
+#define SC_ATTN_SCALAR 0
+#endif
 #ifndef SC_ATTN_LAZY_LOG2          // rescale threshold of the online softmax in log2 units (0: the textbook form, every rise of the maximum rescales)
 #define SC_ATTN_LAZY_LOG2 8.0f
 #endif
@@ -333,11 +336,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
         const float m_new = m_run[qb];
         f32x2_t psum2 = {0.f, 0.f};
         const float sc = partial ? 1.0f : scale_log2e;               // partial tiles were scaled while masking
+#if SC_ATTN_SCALAR & 1
+        const float neg_m = -m_new;
+#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
+#if SC_ATTN_SCALAR & 1      // the score offset as two single v_fma_f32 (asm: plain -O3 SLP-packs adjacent f32 ops into v_pk_fma_f32, which is priced above two v_fma_f32 beside MFMAs -- MI355X_MICROARCH.md)
+                f32x2_t a2;
+                asm("v_fma_f32 %0, %1, %2, %3" : "=v"(a2[0]) : "v"(s[qb][kb][r]), "v"(sc), "v"(neg_m));
+                asm("v_fma_f32 %0, %1, %2, %3" : "=v"(a2[1]) : "v"(s[qb][kb][r + 1]), "v"(sc), "v"(neg_m));
+#else
                 const f32x2_t a2 = (f32x2_t){s[qb][kb][r], s[qb][kb][r + 1]} * sc - m_new;       // one v_pk_fma_f32 per pair
+#endif
 #if defined(SC_ATTN_ABL) && SC_ATTN_ABL == 1
                 const f32x2_t p2 = a2 * 0.001f;                                            // perf probe: no transcendental
 #else
@@ -353,7 +365,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
                     ppk[qb][kb][r >> 1] = pack2bf(d0, d1);
                 } else
                 ppk[qb][kb][r >> 1] = pack2bf(p2[0], p2[1]);       // P leaves the fp32 registers right here: 16 VGPRs instead of 32 through the PV phase
+#if SC_ATTN_SCALAR & 2      // row sums as single f32 adds (two chains)
+                asm("v_add_f32 %0, %1, %2" : "=v"(psum2[0]) : "v"(psum2[0]), "v"(p2[0]));
+                asm("v_add_f32 %0, %1, %2" : "=v"(psum2[1]) : "v"(psum2[1]), "v"(p2[1]));
+#else
                 psum2 += p2;
+#endif
             }
         l_run[qb] = l_run[qb] * alpha + (psum2[0] + psum2[1]);
         if (alpha != 1.0f) {
