@@ -811,6 +811,10 @@ def main():
                               "host_launch_ms_per_step": {k: round(v[0] / v[1] * 1e3, 3) for k, v in host_s.items() if v[1]},
                               "steps_by_method": {k: v[1] for k, v in host_s.items() if v[1]},
                               "note": "host time spent inside the step calls (enqueueing); the instrumented steps (HIP events) always launch eagerly"}
+        if clock is not None and roof is not None:
+            # the same achieved TF/s against the MFMA peak at the clock the socket actually held under this load (power-capped), beside the
+            # nominal 2.4 GHz figure `frac` is priced against
+            roof["frac_of_clock_adjusted_peak"] = round(roof["achieved"] / clock["mfma_peak_at_this_clock_tflops"], 4)
         if clock is not None:
             clock["joules_per_step"] = round(clock["socket_power_w"] * dt / args.steps, 2)
             clock["joules_per_pair"] = round(clock["socket_power_w"] * dt / args.steps / (world * B), 4)
