@@ -116,6 +116,12 @@ int sc_weighted_sum_ln_fwd(const void* h0, const void* ypre, int64_t layer_strid
 #define SC_L2NORM_CLAMP 0x2
 int sc_l2norm_fwd(const void* x, int64_t ld_in, float* out, int64_t rows, int D, int flags, void* stream);
 
+/* ---- Deterministic split-K finish for few-row, deep-K products (the CLS rows of the pooling heads, kwClip.py:1097-1104: linear2 of the branch's
+ * encoder layer is 256 x 768 x 3072): sc_gemm_bf16_batched writes `nsplit` fp32 partial products [nsplit][M][N] (K chunks as the batch), this
+ * sums them in fixed order and applies bias / erf-GELU / residual: out[m,n] = act(sum_s partials[s][m][n] + bias[n]) + residual[m][n].  No atomics. */
+int sc_splitk_reduce_f32(const float* partials, int nsplit, int64_t M, int N, const float* bias, const float* residual, int64_t ldr, float* out, int act,
+                         void* stream);
+
 /* ---- Per-utterance wave layer-norm -- speech_encoder_plus.py:507-508 (task.cfg.normalize) -----
  * out[b,:len_b] = layer_norm(wav[b,:len_b]); out[b,len_b:] = 0.  wav/out are [B, ld] f32. */
 int sc_wave_layernorm(const float* wav, float* out, const int32_t* lens, int B, int64_t ld, float eps, void* stream);

@@ -533,6 +533,37 @@ extern "C" int sc_ln_stats_finalize(const float* partial, int nparts, float* sta
     return 0;
 }
 
+// Deterministic split-K finish: out[m, n] = act( sum_s part[s][m][n] + bias[n] ) + residual[m][n], partials summed in the fixed order s = 0..S-1
+// (no atomics: the eval path is bitwise run-to-run stable).  act: SC_ACT_NONE / SC_ACT_GELU (erf form).  n_total = M * N, a multiple of 4.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t n_total, int N, const float* __restrict__ bias,
+                                                            const float* __restrict__ residual, int64_t ldr, float* __restrict__ out, int act) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n_total) return;
+    f32x4_t acc = *(const f32x4_t*)(part + i);
+    for (int s = 1; s < S; ++s) acc += *(const f32x4_t*)(part + (int64_t)s * n_total + i);
+    const int64_t m = i / N;
+    const int n = (int)(i - m * N);
+    if (bias) acc += *(const f32x4_t*)(bias + n);
+    if (act == SC_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = gelu_erf_precise(acc[r]);
+    }
+    if (residual) acc += *(const f32x4_t*)(residual + m * ldr + n);
+    *(f32x4_t*)(out + i) = acc;
+}
+
+extern "C" int sc_splitk_reduce_f32(const float* partials, int nsplit, int64_t M, int N, const float* bias, const float* residual, int64_t ldr, float* out,
+                                    int act, void* stream) {
+    SC_CHECK_ARG(partials && out && nsplit >= 1 && N > 0 && N % 4 == 0 && (act == SC_ACT_NONE || act == SC_ACT_GELU) && (!residual || ldr % 4 == 0),
+                 "sc_splitk_reduce_f32: bad arguments (N and ldr multiples of 4, act none / gelu)");
+    if (M <= 0) return 0;
+    const int64_t n_total = M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n_total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, nsplit, n_total, N, bias,
+                       residual, ldr, out, act);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sc_l2norm_fwd(const void* x, int64_t ld_in, float* out, int64_t rows, int D, int flags, void* stream) {
     SC_CHECK_ARG(D > 0 && D <= 1024 && D % 4 == 0, "sc_l2norm: D=%d must be a multiple of 4, <= 1024", D);
     if (rows <= 0) return 0;

@@ -81,16 +81,17 @@ def hp_linear(a32: torch.Tensor, weight: torch.Tensor, bias, act: int = 0, resid
     (2e-3) are visible in the centred-cosine parity of the embedding (tests/test_headline_parity_gpu.py); the reference runs these rows in fp32."""
     b = None if bias is None else cached_cast(bias, torch.float32)
     N, K = weight.shape
-    # The fp32 SIMT product instead: shapes the MFMA GEMM does not take (reduced test dimensions), and deep-K products with few rows -- 256 x 768 x
-    # (3 x 3072) is three 256 x 256 tiles walking 144 k-steps each (104 us) where sc_sgemm spreads the same product over the chip (46 us;
-    # tools/head_bench.py)
-    if (3 * K) % 64 or N % 4 or (K >= 2048 and a32.shape[0] <= 1024):
+    if (3 * K) % 64 or N % 4:        # shapes the MFMA GEMM does not take (reduced test dimensions): the fp32 SIMT product (no split-K at these sizes)
         y = ops.sgemm(a32.contiguous(), cached_cast(weight, torch.float32), transb=True, bias=b)
         if act == ACT_GELU:
             y = ops.gelu_f32(y)
         elif act:
             raise NotImplementedError("hp_linear: activation %d on the sgemm fallback" % act)
         return y if residual is None else y + residual
+    if K >= 2048 and a32.shape[0] <= 1024 and K % 256 == 0 and act in (0, ACT_GELU):
+        # few rows, deep K (linear2 of the branch layer: 256 x 768 x (3 x 3072) is three 256 x 256 tiles walking 144 k-steps each, 104 us): a
+        # DETERMINISTIC split-K -- K chunks as a batched GEMM into fp32 partials, summed in fixed order (sc_sgemm's own split-K uses atomics)
+        return ops.gemm_splitk(ops.split_hilo(a32, 3), cached_w3(weight), 768 if (3 * K) % 768 == 0 else 256, b, act, residual)
     return ops.gemm(ops.split_hilo(a32, 3), cached_w3(weight), b, act, residual, out_f32=True)
 
 

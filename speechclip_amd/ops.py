@@ -230,6 +230,25 @@ def weighted_sum(hidden, weights, normalize=False, eps=1e-5):
     return out
 
 
+def gemm_splitk(a16, w16, K_chunk, bias=None, act=ACT_NONE, residual=None):
+    """f32 [M, N] = act(a16 [M, K] @ w16 [N, K]^T + bias) + residual as a DETERMINISTIC split-K product: the K / K_chunk chunks run as one batched
+    GEMM into fp32 partials [S, M, N] (S x more tiles for few-row, deep-K shapes), sc_splitk_reduce_f32 sums them in fixed order."""
+    _need_cuda(a16, w16)
+    assert a16.dtype == bf16 and w16.dtype == bf16 and a16.dim() == 2 and a16.is_contiguous() and w16.is_contiguous()
+    M, K = a16.shape
+    N = w16.shape[0]
+    assert w16.shape[1] == K and K % K_chunk == 0 and K_chunk % 64 == 0 and N % 4 == 0
+    S = K // K_chunk
+    part = torch.empty(S, M, N, device=a16.device, dtype=torch.float32)
+    gemm_batched(a16, K, K_chunk, w16, K_chunk, S, part, N, M * N, None, M, N, K_chunk, S, ldw=K)
+    out = torch.empty(M, N, device=a16.device, dtype=torch.float32)
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+    check(lib().sc_splitk_reduce_f32(ptr(part), S, M, N, ptr(bias), ptr(residual), residual.stride(-2) if residual is not None else 0, ptr(out), int(act),
+                                     stream()), "sc_splitk_reduce_f32")
+    return out
+
+
 def l2norm(x, clamp=False):
     """x / ||x|| (no eps: kwClip.py:1436); clamp=True: x / max(||x||, 1e-8) (the operand normalisation of F.cosine_similarity)."""
     _need_cuda(x)

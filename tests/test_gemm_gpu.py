@@ -286,3 +286,34 @@ def test_gemm_operands_beyond_32bit_offsets(M, N, K, lda, act):
         for r0 in range(0, M, 1 << 20):
             assert torch.isfinite(y[r0:r0 + (1 << 20)].float().sum()).item()
     print(f"M={M} N={N} K={K} lda={ld}: A spans {n_el:.3e} elements, C {M * N:.3e}; {len(marks)} row blocks, max abs err {worst:.4f}")
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(256, 768, 3072, 0, True), (64, 768, 3072, 0, False), (256, 3072, 2048, 1, False), (40, 512, 4096, 0, True)])
+def test_hp_linear_deterministic_split_k(M, N, K, act, res):
+    """hp_linear on few-row, deep-K shapes (the CLS rows through linear2 of the pooling head): hi/lo-split operands, K chunks as a batched GEMM into fp32
+    partials, sc_splitk_reduce_f32 in fixed order -- fp32-grade result (vs float64), bitwise run-to-run stable (no atomics), bias / GELU / residual
+    applied in the finish kernel."""
+    from speechclip_amd.module.kw_modules.TransformerModels import hp_linear
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    lin = torch.nn.Linear(K, N).cuda()
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(N, K, generator=g) * K ** -0.5)
+        lin.bias.copy_(torch.randn(N, generator=g))
+    r = torch.randn(M, N, generator=g).cuda() if res else None
+    y = hp_linear(a, lin.weight, lin.bias, act, r)
+    y2 = hp_linear(a, lin.weight, lin.bias, act, r)
+    assert y.dtype == torch.float32 and torch.equal(y, y2), "split-K finish is not run-to-run deterministic"
+    ref = a.double() @ lin.weight.double().t() + lin.bias.double()
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + r.double()
+    rel = ((y.double() - ref).norm() / ref.norm()).item()
+    assert rel < 2e-5, rel                      # bf16 operands would give ~2e-3
+    # broadcast residual (ldr = 0: the CLS token added to every row, TransformerModels.forward_cls)
+    if res:
+        row = torch.randn(1, N, generator=g).cuda()
+        yb = hp_linear(a, lin.weight, lin.bias, act, row.expand(M, N))
+        refb = a.double() @ lin.weight.double().t() + lin.bias.double() + row.double()
+        assert ((yb.double() - refb).norm() / refb.norm()).item() < 2e-5
