@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from speechclip_amd import ops
-from speechclip_amd.module.kw_modules.TransformerModels import _w3
+from speechclip_amd.module.kw_modules.TransformerModels import _w3, hp_linear
 B = int(os.environ.get("B", "256"))
 def t(fn, n=50):
     for _ in range(5): fn()
@@ -21,12 +21,15 @@ for name, N, K in (("out_proj", 768, 768), ("linear1", 3072, 768), ("linear2", 7
     b = torch.randn(N, device="cuda")
     w3, w16 = _w3(w), w.to(torch.bfloat16)
     a16 = a.to(torch.bfloat16)
-    t_hp = t(lambda: ops.gemm(ops.split_hilo(a, 3), w3, b, out_f32=True))
+    lin = torch.nn.Linear(K, N).cuda()
+    with torch.no_grad():
+        lin.weight.copy_(w); lin.bias.copy_(b)
+    t_hp = t(lambda: hp_linear(a, lin.weight, lin.bias))          # what the head runs (deep K: deterministic split-K)
     t_split = t(lambda: ops.split_hilo(a, 3))
     t_sg = t(lambda: ops.sgemm(a, w, transb=True, bias=b))
     t_bf = t(lambda: ops.gemm(a16, w16, b, out_f32=True))
     ref = a.double() @ w.double().t() + b.double()
-    e_hp = ((ops.gemm(ops.split_hilo(a, 3), w3, b, out_f32=True).double() - ref).norm() / ref.norm()).item()
+    e_hp = ((hp_linear(a, lin.weight, lin.bias).double() - ref).norm() / ref.norm()).item()
     e_sg = ((ops.sgemm(a, w, transb=True, bias=b).double() - ref).norm() / ref.norm()).item()
     e_bf = ((ops.gemm(a16, w16, b, out_f32=True).double() - ref).norm() / ref.norm()).item()
     print(f"{name:9s} M={B} N={N} K={K}: hp_linear {t_hp:7.1f} us (split alone {t_split:5.1f}) rel err {e_hp:.1e} | sgemm {t_sg:7.1f} us {e_sg:.1e} | bf16 gemm {t_bf:6.1f} us {e_bf:.1e}")
