@@ -278,6 +278,52 @@ def test_cls_pool_algebraic_equals_attention(NQ, H, D, T):
     torch.testing.assert_close(y, ref, atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("NQ,H,D,T", [(1, 8, 768, 500), (8, 1, 768, 130), (1, 8, 1024, 77), (1, 4, 128, 9)])
+def test_cls_pool_precise_head_matches_fp32_attention(NQ, H, D, T):
+    """The PRECISE form of the CLS-row attention (round 4: sc_cls_pool_fwd_split writes the pooled sums as (hi | lo | hi) bf16 blocks, the value
+    projection is a depth-3D GEMM against [Wv_hi | Wv_hi | Wv_lo], fp32 out) against explicit fp32 MHA rows over the same bf16 frames: only the
+    scores' bf16 operands (frames, u_r) round -- the pooled vector and Wv do not; and (hi + lo) of the split output equals the fp32 pooled sums of
+    the training kernel (sc_cls_pool_train_fwd) to 2^-16."""
+    from speechclip_amd import ops
+    from speechclip_amd.module.kw_modules.TransformerModels import _cls_attention_block, _frames_view, _pool_operands
+    g = _g(NQ * 100 + D + T)
+    B, hd = 3, D // H
+    cls = torch.randn(1, NQ, D, generator=g).cuda()
+    in_w = (torch.randn(3 * D, D, generator=g) * D ** -0.5).cuda()
+    in_b = (0.1 * torch.randn(3 * D, generator=g)).cuda()
+    x = torch.randn(B, T, D, generator=g).to("cuda", BF)
+    lens = torch.tensor([T, 1, T // 2], device="cuda")
+    y = _cls_attention_block(cls, x, lens, in_w, in_b, H, precise=True)
+    assert y.dtype == torch.float32
+    y = y.view(B, NQ, D)
+    y2 = _cls_attention_block(cls, x, lens, in_w, in_b, H, precise=True).view(B, NQ, D)
+    assert torch.equal(y, y2), "not run-to-run deterministic"
+    ref = torch.zeros(B, NQ, D, device="cuda", dtype=torch.float64)
+    for b in range(B):
+        c16 = cls[0].to(BF).double()
+        src = torch.cat([c16, x[b, : int(lens[b])].double()], 0)
+        q = (cls[0].double() @ in_w[:D].double().t() + in_b[:D].double()).view(NQ, H, hd)
+        k = (src @ in_w[D:2 * D].double().t() + in_b[D:2 * D].double()).view(-1, H, hd)
+        v = (src @ in_w[2 * D:].double().t() + in_b[2 * D:].double()).view(-1, H, hd)          # fp32 Wv: the precise form does not round it
+        s = torch.einsum("qhd,khd->hqk", q, k) * hd ** -0.5
+        ref[b] = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), v).reshape(NQ, D)
+    # the bf16 rounding of u_r (score operand) perturbs the probabilities by ~1e-3 relative; the result itself carries no 8-bit rounding
+    err = (y.double() - ref).abs().max().item()
+    assert err < 4e-3, err
+    # split output == fp32 pooled sums
+    rows, Tp = _frames_view(x)
+    P = _pool_operands(cls, in_w, in_b, H)
+    li = lens.to(torch.int32)
+    R = NQ * H
+    scores = ops.gemm(rows, P["u16"], P["beta"], out_f32=True)
+    for nb in (2, 3):
+        sp = ops.cls_pool(rows, P["cls16"], scores, P["cls_scores"], li, B, Tp, NQ, R, D, split=nb).float().view(B, R, nb, D)
+        _, zbar = ops.cls_pool_train_fwd(rows, P["cls16"].float().contiguous(), scores, P["cls_scores"], li, B, Tp, NQ, R, D)
+        torch.testing.assert_close(sp[:, :, 0] + sp[:, :, 1], zbar, atol=1e-5, rtol=3e-5)
+        if nb == 3:
+            assert torch.equal(sp[:, :, 2], sp[:, :, 0])
+
+
 def test_retrieval_ranks_golden_and_random():
     """Device recall@K (similarity by sc_sgemm, ranks by sc_retrieval_ranks) against the reference's mutualRetrieval values
     (tests/golden/retrieval.npz) and against the oracle's argsort formulation at the Flickr8k test-set shape (5000 x 1000, 5 captions/image)."""
