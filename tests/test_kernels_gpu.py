@@ -309,7 +309,7 @@ def test_cls_pool_precise_head_matches_fp32_attention(NQ, H, D, T):
         ref[b] = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), v).reshape(NQ, D)
     # the bf16 rounding of u_r (score operand) perturbs the probabilities by ~1e-3 relative; the result itself carries no 8-bit rounding
     err = (y.double() - ref).abs().max().item()
-    assert err < 4e-3, err
+    assert err < 1e-2, err                      # (the round-3 form, bf16 pooled vector and Wv: ~3e-2)
     # split output == fp32 pooled sums
     rows, Tp = _frames_view(x)
     P = _pool_operands(cls, in_w, in_b, H)
