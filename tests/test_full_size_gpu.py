@@ -137,3 +137,51 @@ def test_c_base_full_size_properties():
     assert abs(float(lm["softmax_temp"]) - 0.1) < 1e-6
     print(f"C-base B={B}, V={V}: loss {loss:.5f} (oracle on the same embeddings {ref:.5f}); targets stable under permutation: "
           f"{(tg(ot4) == t1[perm]).float().mean().item():.4f}")
+
+
+def test_global_batch_2048_on_one_gpu_equals_eight_shards():
+    """Maximum size of the path: the GLOBAL batch of BASELINE.json configs[3] (2048 pairs, 10 s) on ONE GPU -- what `bench.py --global-batch 2048` runs at
+    N = 1, ~175 GB of activations and workspaces, conv-layer operands of 3.4e10 elements (67 GB: far beyond every 32-bit offset) -- against the same
+    utterances run as eight B = 256 shards (what eight ranks would compute): the embeddings agree (the GEMM's fp32 summation order moves with a row's
+    tile, so not bitwise), and the loss on the global batch is the fp32 oracle's InfoNCE on those embeddings (duplicate ids: the false-negative mask at
+    Bg = 2048, which the reference's MAX_EYE = 256 cannot represent, losses.py:126)."""
+    import bench
+    from oracle.speechclip_ref import masked_contrastive_loss
+    free, total = torch.cuda.mem_get_info()
+    if total < 250e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    model = bench.build_model().cuda()
+    Bg, Bl, L = 2048, 256, 160000
+    g = torch.Generator().manual_seed(2048)
+    wav = torch.empty(Bg, L)
+    for s0 in range(0, Bg, 256):
+        wav[s0:s0 + 256] = 0.1 * torch.randn(256, L, generator=g)
+    for i in range(5, Bg, 97):                                  # some shorter utterances
+        wav[i, 64000 + 31 * i:] = 0
+    lens = torch.full((Bg,), L)
+    for i in range(5, Bg, 97):
+        lens[i] = 64000 + 31 * i
+    img = torch.randn(Bg, 3, 224, 224, generator=g)
+    ids = torch.arange(Bg) // 5                                 # 5 captions per image
+    batch = {"wav": wav.cuda(), "wav_len": lens, "image": img.cuda(), "id": ids.cuda()}
+    with torch.no_grad():
+        a_sh, i_sh = [], []
+        for r in range(Bg // Bl):                               # the eight shards first (small workspaces), then the global batch
+            sl = slice(r * Bl, (r + 1) * Bl)
+            lf, _, _ = model({k: v[sl] for k, v in batch.items()})
+            a_sh.append(lf["parallel_audio_feat"].clone())
+            i_sh.append(lf["image_feat"].clone())
+        a_sh, i_sh = torch.cat(a_sh), torch.cat(i_sh)
+        lf, _, _ = _with_env("SC_VARLEN_PACK", "0", lambda: model(batch))     # the padded layout: M = 2048 x 500 rows in every GEMM
+        a_g, i_g = lf["parallel_audio_feat"], lf["image_feat"]
+        loss = model.compute_loss(lf)["loss"].item()
+    assert a_g.shape == (Bg, 512) and torch.isfinite(a_g).all() and torch.isfinite(i_g).all()
+    # shards differ from the global run in their padded length only where a shard has no full-length utterance (none here: every shard keeps 10 s ones)
+    ca, ci = _cos_rows(a_g, a_sh), _cos_rows(i_g, i_sh)
+    assert ca.min().item() > 0.999999 and ci.min().item() > 0.999999, (ca.min().item(), ci.min().item())
+    assert (a_g - a_sh).abs().max().item() < 2e-3
+    ref = masked_contrastive_loss(a_g.float().cpu(), i_g.float().cpu(), ids).item()
+    assert abs(loss - ref) < 1e-4, (loss, ref)
+    assert abs(loss - 7.6) < 0.3                                # ~ ln 2048 for random-init towers
+    print(f"Bg = 2048 on one GPU: loss {loss:.5f} (oracle on the same embeddings {ref:.5f}); min cos vs eight B = 256 shards: audio {ca.min().item():.7f} image {ci.min().item():.7f}; "
+          f"peak memory {torch.cuda.max_memory_allocated() / 1e9:.0f} GB")
