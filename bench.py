@@ -529,6 +529,10 @@ def main():
     use_graph = (args.graph == "on" or (args.graph == "auto" and world > 1)) and not args.train
     graph_note, replay_step = None, None
     if use_graph:
+        # Capture is LOCAL (no collective inside); every decision that changes how many collectives a rank issues afterwards is agreed on by all
+        # ranks first (a rank that failed to capture must not skip a gather the others run).
+        cap_ok, why = True, ""
+        graph = g_lf = None
         try:
             cap = torch.cuda.Stream()
             cap.wait_stream(torch.cuda.current_stream())
@@ -540,24 +544,29 @@ def main():
             with torch.cuda.graph(graph):
                 with torch.no_grad():
                     g_lf, _, _ = model(batch)
+        except Exception as e:     # noqa: BLE001  -- a capture problem must not cost the measurement: fall back to the eager step and SAY so
+            cap_ok, why = False, str(e)[:200]
+            torch.cuda.synchronize()
 
+        def all_ranks(flag_):
+            if world == 1:
+                return flag_
+            t_ = torch.tensor([1.0 if flag_ else 0.0], device=dev)
+            torch.distributed.all_reduce(t_, op=torch.distributed.ReduceOp.MIN)
+            return t_.item() >= 1
+        if not all_ranks(cap_ok):
+            graph_note = "eager (graph capture failed%s)" % (": " + why if why else " on another rank")
+        else:
             def replay_step():
                 graph.replay()
                 with torch.no_grad():
                     return model.compute_loss(parallel.gather_loss_feats(g_lf))["loss"]
-            l_g = float(replay_step())
+            l_g = float(replay_step())                             # every rank runs both forms once (the same collectives everywhere) ...
             l_e = float(step())
-            if abs(l_g - l_e) > 1e-5:
-                raise RuntimeError("replayed step loss %.6f != eager %.6f" % (l_g, l_e))
-            graph_note = "hip graph (towers + head captured once, replayed; exchange + loss eager)"
-        except Exception as e:     # noqa: BLE001  -- a capture problem must not cost the measurement: fall back to the eager step and SAY so
-            replay_step, graph_note = None, "eager (graph capture failed: %s)" % (str(e)[:200],)
-            torch.cuda.synchronize()
-    if world > 1:                  # all ranks take the same path (a rank replaying beside a rank launching eagerly would still be correct, only uneven)
-        flag = torch.tensor([1.0 if replay_step is not None else 0.0], device=dev)
-        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        if flag.item() < 1 and replay_step is not None:
-            replay_step, graph_note = None, "eager (another rank could not capture)"
+            if all_ranks(abs(l_g - l_e) <= 1e-5):                  # ... and all of them must agree that the replay reproduces the eager step
+                graph_note = "hip graph (towers + head captured once, replayed; exchange + loss eager)"
+            else:
+                replay_step, graph_note = None, "eager (replayed step loss %.6f != eager %.6f on some rank)" % (l_g, l_e)
     fence()
     # roofline instrumentation: HIP events around every GEMM launch of every THIRD timed step (two events per launch, ~220 launches per
     # step: on every step they cost ~1 % of the step time they are meant to explain)
