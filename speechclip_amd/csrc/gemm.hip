@@ -57,6 +57,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 #ifndef SC_PROBES
 #define SC_PROBES 0
 #endif
+#ifndef SC_GEMM_RES_TOUCH         // 1: the residual variants TOUCH their tile's residual lines (4-byte LDS-DMA loads into the idle A slot) during k-step nk - 2, so that the
+#define SC_GEMM_RES_TOUCH 1       // epilogue's residual loads hit in L2 instead of paying the HBM / MALL latency with the matrix pipe idle (round 4)
+#endif
 #ifndef SC_GEMM_FAST_EPI          // 0: every tile takes the general (predicated) epilogue; 1: fast path for the variants without a residual operand;
 #define SC_GEMM_FAST_EPI 1        // 2: also for the residual variants (A/B builds)
 #endif
@@ -460,12 +463,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 for (int j = 0; j < 4; ++j) bfr[j] = bn[j];
             }
         };
-        auto mid_sync = [&](int kt, bool refilled) {
+        auto mid_sync = [&](int kt, bool refilled, int touched = 0) {
             // slot kt is entirely in registers; stage kt+1 must have landed before anyone reads it.  RING3: the newest 4 operations of this
             // wave are the A pieces of stage kt+2 (or of the next tile's stage 0), issued during the half-step that just ended, whenever
-            // that stage exists: let them fly.
+            // that stage exists: let them fly.  `touched`: the newest 2 / 4 operations are the residual touches of k-step nk - 2 (nothing waits
+            // for their data; the wait in front of the epilogue retires them).
             (void)kt;
             if (RING3 && refilled) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else if (touched == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else if (touched == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -485,10 +491,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 kc = c >= nk ? c - nk : c;
                 k2n = kt + 3 < nk ? kmap(kc) : -1;
             };
+            // Residual variants, k-step nk - 2 (no stage nk to fetch: the A slot sA2 and this half-step's DMA issue slots are idle): touch the lines
+            // of this tile's residual -- one 4-byte LDS-DMA load per 128-byte line, 1024 (bf16) / 2048 (f32) lines per tile = 2 / 4 instructions per
+            // wave, landing as garbage in sA2, which nobody reads before the next tile's stage 0 overwrites it.  The epilogue's residual loads, ~1.5
+            // k-steps later, then come out of L2: in isolation the residual operand cost out-proj +26 % (0.159 -> 0.201 ms) = the HBM time of its
+            // 196 MB, paid as exposed latency while the matrix pipe idles in the epilogue.
+            int touched = 0;
+            if (RES && RING3 && SC_GEMM_RES_TOUCH && EPI == 0 && !BATCH && kt == nk - 2 && k2 < 0 && nk >= 3) {
+                const int esz = p.out_f32 ? 4 : 2;
+                const int lines_per_row = 256 * esz / 128;                       // 4 (bf16) or 8 (f32)
+                const char* rbase = (const char*)p.residual + (m0 * p.ldr + n0) * (int64_t)esz;
+                touched = p.out_f32 ? 4 : 2;
+                for (int j = 0; j < touched; ++j) {
+                    const int idx = (wave * touched + j) * 64 + lane;            // line of the tile: row idx / lines_per_row, line idx % lines_per_row
+                    const int row = idx / lines_per_row, ln = idx - row * lines_per_row;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rbase + ((int64_t)row * p.ldr * esz + ln * 128)),
+                                                     (__attribute__((address_space(3))) void*)(sA2 + (wave * 4 + j) * 256), 4, 0, 0);
+                }
+            }
             // MFMAs of (kt, h0); read (kt, h1); RING3: A pieces of stage kt+2 into the A slot stage kt-1 left free
             if (!RING3) half_step(F_{}, sA0, sW0, off_h1, true, -1, nullptr, -1, nullptr, no_hook);
             else half_step(T_{}, sA0, sW0, off_h1, true, -1, nullptr, k2, sA2, no_hook);
-            mid_sync(kt, k2 >= 0);
+            mid_sync(kt, k2 >= 0, touched);
             // MFMAs of (kt, h1); read (kt+1, h0); refill: 2-ring = stage kt+2 (A and W) into slot kt; RING3 = W(kt+2) into W slot kt
             half_step(T_{}, sA1, sW1, off_h0, true, k2, RING3 ? sW0 : sA0, -1, nullptr, next_k);
             rotate_ring();
