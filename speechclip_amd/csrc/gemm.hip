@@ -497,7 +497,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             // k-steps later, then come out of L2: in isolation the residual operand cost out-proj +26 % (0.159 -> 0.201 ms) = the HBM time of its
             // 196 MB, paid as exposed latency while the matrix pipe idles in the epilogue.
             int touched = 0;
-            if (RES && RING3 && SC_GEMM_RES_TOUCH && EPI == 0 && !BATCH && kt == nk - 2 && k2 < 0 && nk >= 3) {
+            auto touch_residual = [&]() {
                 const int esz = p.out_f32 ? 4 : 2;
                 const int lines_per_row = 256 * esz / 128;                       // 4 (bf16) or 8 (f32)
                 const char* rbase = (const char*)p.residual + (m0 * p.ldr + n0) * (int64_t)esz;
@@ -508,11 +508,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rbase + ((int64_t)row * p.ldr * esz + ln * 128)),
                                                      (__attribute__((address_space(3))) void*)(sA2 + (wave * 4 + j) * 256), 4, 0, 0);
                 }
-            }
+            };
+            const bool touch_here = RES && RING3 && SC_GEMM_RES_TOUCH && EPI == 0 && !BATCH && kt == nk - 2 && k2 < 0 && nk >= 3;
+            if (touch_here && SC_GEMM_RES_TOUCH == 1) touch_residual();
+            else touched = 0;
             // MFMAs of (kt, h0); read (kt, h1); RING3: A pieces of stage kt+2 into the A slot stage kt-1 left free
             if (!RING3) half_step(F_{}, sA0, sW0, off_h1, true, -1, nullptr, -1, nullptr, no_hook);
             else half_step(T_{}, sA0, sW0, off_h1, true, -1, nullptr, k2, sA2, no_hook);
-            mid_sync(kt, k2 >= 0, touched);
+            mid_sync(kt, k2 >= 0, (touch_here && SC_GEMM_RES_TOUCH == 1) ? touched : 0);
+            if (touch_here && SC_GEMM_RES_TOUCH == 2) touch_residual();      // A/B: one half-step later (retired by the wait in front of the epilogue)
             // MFMAs of (kt, h1); read (kt+1, h0); refill: 2-ring = stage kt+2 (A and W) into slot kt; RING3 = W(kt+2) into W slot kt
             half_step(T_{}, sA1, sW1, off_h0, true, k2, RING3 ? sW0 : sA0, -1, nullptr, next_k);
             rotate_ring();
