@@ -341,13 +341,18 @@ class KW_CascadedBranch(nn.Module):
         super().__init__()
         self.audio_dim, self.text_dim, self.clip, self.config = audio_dim, text_dim, clip, config
         cb = config.model_settings.cascaded_branch
-        if cb.keyword.get("kw_projection", None) is not None:
-            raise NotImplementedError("kw_projection MLP is not used by any shipped config")
+        self.kw_projection_config = cb.keyword.get("kw_projection", None)
         self.keyword_num = cb.keyword.number
         self.cls = torch.nn.Parameter(torch.randn([1, self.keyword_num, cb.transformer_args.d_model]))
         assert hasattr(TransformerModels, cb.transformer_type), "transformer structure '{}' not supported".format(cb.transformer_type)
         self.self_att = getattr(TransformerModels, cb.transformer_type)(**cb.transformer_args)
-        self.linear_proj = nn.Linear(cb.transformer_args.d_model, self.text_dim)
+        if self.kw_projection_config is None:                      # kwClip.py:749-756
+            self.linear_proj = nn.Linear(cb.transformer_args.d_model, self.text_dim)
+        else:                                                      # kwClip.py:757-771: an MLP instead of the single Linear (eval path; not trainable here)
+            dims = list(self.kw_projection_config.dimensions)
+            assert dims[0] == cb.transformer_args.d_model, f"first dim({dims[0]}) should match the audio encoder dim({cb.transformer_args.d_model})"
+            assert dims[-1] == self.text_dim, f"last dim({dims[-1]}) should match the text encoder dim({self.text_dim})"
+            self.linear_proj = MLPLayers(units=dims, dropout=self.kw_projection_config.dropout)
         self.vq_type = cb.vq.type
         if not hasattr(vector_quantizers, self.vq_type):
             raise NotImplementedError("Vq ({}) not implemented".format(self.vq_type))
@@ -403,7 +408,9 @@ class KW_CascadedBranch(nn.Module):
             return self._forward_train(audio_feat, audio_len)
         B, K = audio_feat.shape[0], self.keyword_num
         kw = self.self_att.forward_cls(self.cls, audio_feat, audio_len)                       # f32 [B, K, d] (bf16 with SC_HEAD_PRECISE=0)
-        if kw.dtype == torch.float32:
+        if isinstance(self.linear_proj, MLPLayers):
+            kw = self.linear_proj(kw.view(B * K, -1)).view(B, K, self.text_dim)
+        elif kw.dtype == torch.float32:
             kw = TransformerModels.hp_linear(kw.view(B * K, -1), self.linear_proj.weight, self.linear_proj.bias).view(B, K, self.text_dim)
         else:
             kw = ops.gemm(kw.view(B * K, -1), TransformerModels.cached_cast(self.linear_proj.weight, torch.bfloat16),
@@ -423,6 +430,8 @@ def _kw_cascaded_forward_train(self, audio_feat: torch.Tensor, audio_len: torch.
     """Differentiable train-mode path (kwClip.py:868-916 under loss.backward()): train_tail.CascadedPoolTrainFn -> Kw_BatchNorm (batch
     statistics) -> cosine / straight-through VQ (KeywordSTFn) -> frozen CLIP text tower with input gradients (TextTowerTrainFn)."""
     from ..train_tail import CascadedPoolTrainFn, KeywordSTFn
+    if isinstance(self.linear_proj, MLPLayers):
+        raise NotImplementedError("training with a kw_projection MLP is not built (no shipped config has one); the eval forward is")
     B, K = audio_feat.shape[0], self.keyword_num
     mha = self.self_att.multihead_attn_layer
     src = getattr(audio_feat, "_mix_src", None)

@@ -233,3 +233,22 @@ def test_forward_image_accepts_a_list_of_paths(tmp_path):
         torch.testing.assert_close(pix.cpu(), normalize_u8(load_images_u8(paths, 224)), atol=2e-6, rtol=0)     # device normalisation == host arithmetic
         b = model.forward_image(pix)
     assert a.shape == (3, 512) and torch.equal(a, b)
+
+
+
+def test_mlp_projection_heads_eval_forward():
+    """MLPLayers (projections.py:6-29; the optional image / branch / keyword projection heads of kwClip.py:757-771,:1147-1187) on the device: Linear -> ReLU ->
+    (Dropout: identity in eval) ... -> Linear at fp32 grade, any leading shape."""
+    from speechclip_amd.module import MLPLayers
+    torch.manual_seed(4)
+    m = MLPLayers(units=[768, 1024, 512], dropout=0.3).cuda().eval()
+    x = torch.randn(5, 8, 768, device="cuda")
+    with torch.no_grad():
+        y = m(x)
+        ref = m.sequential(x.double().cpu().float()) if False else torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(
+            x.double(), m.sequential[0].weight.double(), m.sequential[0].bias.double())), m.sequential[3].weight.double(), m.sequential[3].bias.double())
+    assert y.shape == (5, 8, 512) and y.dtype == torch.float32
+    assert ((y.double() - ref).norm() / ref.norm()).item() < 2e-5
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(x)

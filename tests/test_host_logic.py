@@ -672,6 +672,26 @@ def test_forward_image_type_errors_without_a_gpu():
         model.forward_image("a.jpg")
 
 
+def test_mlp_layers_state_dict_layout_is_the_references():
+    """avssl/module/projections.py:6-29: nn.Sequential of [Linear, nonlin, Dropout] triples minus the last two modules -> parameters live at
+    `sequential.0`, `sequential.3`, `sequential.6` ...; a checkpoint trained with a projection head loads by key."""
+    from speechclip_amd.module import MLPLayers
+    m = MLPLayers(units=[16, 32, 24, 8], dropout=0.2)
+    assert list(m.state_dict().keys()) == ["sequential.0.weight", "sequential.0.bias", "sequential.3.weight", "sequential.3.bias",
+                                           "sequential.6.weight", "sequential.6.bias"]
+    assert [tuple(v.shape) for v in m.state_dict().values()] == [(32, 16), (32,), (24, 32), (24,), (8, 24), (8,)]
+    assert len(m.sequential) == 7 and isinstance(m.sequential[-1], torch.nn.Linear) and m.sequential[2].p == 0.2
+    # the cascaded branch takes `kw_projection` (kwClip.py:757-771): an MLP in place of the single Linear, same attribute name
+    from speechclip_amd.model.kwClip import KW_CascadedBranch
+    model = _tiny_model()
+    cfg = model.config
+    d = cfg.model_settings.cascaded_branch.transformer_args.d_model
+    from speechclip_amd.base import OrderedNamespace
+    cfg.model_settings.cascaded_branch.keyword["kw_projection"] = OrderedNamespace({"dimensions": [d, 48, model.subword_embd_dim], "dropout": 0.1})
+    br = KW_CascadedBranch(config=cfg, audio_dim=d, text_dim=model.subword_embd_dim, clip=model.clip)
+    assert isinstance(br.linear_proj, MLPLayers) and "linear_proj.sequential.3.weight" in br.state_dict()
+
+
 def test_collate_general_matches_reference_golden():
     """speechclip_amd.data.collate_general vs the reference's collate_general on the same ragged rows (tests/golden/small_ops.npz)."""
     from speechclip_amd.data import collate_general
