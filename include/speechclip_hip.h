@@ -116,6 +116,12 @@ int sc_weighted_sum_ln_fwd(const void* h0, const void* ypre, int64_t layer_strid
 #define SC_L2NORM_CLAMP 0x2
 int sc_l2norm_fwd(const void* x, int64_t ld_in, float* out, int64_t rows, int D, int flags, void* stream);
 
+/* ---- `normalize_hiddenstates: true` with `normalize_type: method1 | method2` (avssl/module/speech_encoder_plus.py:572-592; "s3prl" is the per-feature
+ * layer_norm inside WeightedSumLayer, SC_WS_NORMALIZE): IN PLACE on the stacked hidden states [n_layers][B][Tp][D] (bf16, or f32 when in_f32), as the
+ * reference overwrites layer_results[i] before it mixes / returns them.  method 1: every frame to unit L2 norm, x / (||x|| + 1e-8); method 2: every state
+ * of utterance b divided by the mean frame norm over frames t < T (all frames of the padded batch).  workspace (method 2): n_layers*B*(Tp+1) floats. */
+int sc_hidden_normalize(void* hidden, int in_f32, int n_layers, int B, int Tp, int T, int D, int method, float* workspace, void* stream);
+
 /* ---- Deterministic split-K finish for few-row, deep-K products (the CLS rows of the pooling heads, kwClip.py:1097-1104: linear2 of the branch's
  * encoder layer is 256 x 768 x 3072): sc_gemm_bf16_batched writes `nsplit` fp32 partial products [nsplit][M][N] (K chunks as the batch), this
  * sums them in fixed order and applies bias / erf-GELU / residual: out[m,n] = act(sum_s partials[s][m][n] + bias[n]) + residual[m][n].  No atomics. */

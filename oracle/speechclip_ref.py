@@ -30,6 +30,21 @@ def weighted_sum(hidden: Sequence[torch.Tensor], weights: torch.Tensor, normaliz
     return (w.view(-1, 1, 1, 1) * x).sum(0)
 
 
+def normalize_hidden_states(hidden: Sequence[torch.Tensor], method: str) -> list:
+    """avssl/module/speech_encoder_plus.py:572-592 (`normalize_hiddenstates` with `normalize_type` method1 / method2; "s3prl" is the per-feature
+    layer_norm inside WeightedSumLayer instead): method1 = every frame to unit L2 norm, x / (||x|| + 1e-8); method2 = every hidden state divided by its
+    utterance's mean frame norm over ALL T frames of the padded batch (padded frames included, as the reference does)."""
+    out = []
+    for h in hidden:
+        if method == "method1":
+            out.append(h / (torch.norm(h, dim=-1, keepdim=True) + 1e-8))
+        elif method == "method2":
+            out.append(h / torch.mean(torch.norm(h, dim=-1), dim=-1).view(-1, 1, 1))
+        else:
+            raise ValueError(method)
+    return out
+
+
 def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     """avssl/model/kwClip.py:1436,1444-1454 -- x / ||x||, no eps."""
     return x / x.norm(dim=-1, keepdim=True)

@@ -63,6 +63,7 @@ def _declare(L):
         "sc_weighted_sum_ln_fwd": ([P, P, L64, P, P, P, P, I, L64, I, F, P], c_int),
         "sc_l2norm_fwd": ([P, L64, P, L64, I, I, P], c_int),
         "sc_splitk_reduce_f32": ([P, I, L64, I, P, P, L64, P, I, P], c_int),
+        "sc_hidden_normalize": ([P, I, I, I, I, I, I, I, P, P], c_int),
         "sc_wave_layernorm": ([P, P, P, I, L64, F, P], c_int),
         "sc_attention_fwd": ([P, P, P, P, P, I, I, I, I, L64, L64, F, I, P], c_int),
         "sc_attention_fwd_dropout": ([P, P, P, P, P, I, I, I, I, L64, L64, F, I, F, U32, P], c_int),

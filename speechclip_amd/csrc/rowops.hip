@@ -533,6 +533,70 @@ extern "C" int sc_ln_stats_finalize(const float* partial, int nparts, float* sta
     return 0;
 }
 
+// `normalize_hiddenstates` with `normalize_type` method1 / method2 (speech_encoder_plus.py:572-592), IN PLACE on the stacked hidden states
+// x = [n_layers][B][Tp][D] (bf16 post-LN / f32 pre-LN residual stream), as the reference overwrites `layer_results[i]`:
+//   method1: row /= (||row||_2 + 1e-8)          method2: row /= mean_{t < T} ||x[i, b, t, :]||_2   (ALL T frames of the padded batch, padded frames included)
+// MODE 0: norms[row] = ||row||; MODE 1: method1 in place; MODE 2: row *= inv[row / Tp] in place (inv from hidden_group_inv_mean_kernel).  One wave per row.
+template <bool IN_F32, int MODE>
+__global__ __launch_bounds__(256) void hidden_rownorm_kernel(void* __restrict__ x, int64_t rows, int D, int Tp, float* __restrict__ norms,
+                                                             const float* __restrict__ inv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[MAXC][4];
+    load_row<IN_F32>(x, row * D, D, lane, v);
+    float scale;
+    if (MODE == 2) {
+        scale = inv[row / Tp];
+    } else {
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) q += (v[c][0] * v[c][0] + v[c][1] * v[c][1]) + (v[c][2] * v[c][2] + v[c][3] * v[c][3]);
+        const float nrm = sqrtf(wave_sum(q));
+        if (MODE == 0) { if (lane == 0) norms[row] = nrm; return; }
+        scale = 1.0f / (nrm + 1e-8f);
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int e = c * 256 + lane * 4;
+        if (e < D) {
+            if (IN_F32) *(f32x4_t*)((float*)x + row * D + e) = (f32x4_t){v[c][0] * scale, v[c][1] * scale, v[c][2] * scale, v[c][3] * scale};
+            else { uint2 p_; p_.x = pack2bf(v[c][0] * scale, v[c][1] * scale); p_.y = pack2bf(v[c][2] * scale, v[c][3] * scale); *(uint2*)((bf16_t*)x + row * D + e) = p_; }
+        }
+    }
+}
+
+// inv[g] = T / sum_{t < T} norms[g * Tp + t]   for every (layer, utterance) group g; fixed summation order (one wave per group).
+__global__ __launch_bounds__(64) void hidden_group_inv_mean_kernel(const float* __restrict__ norms, float* __restrict__ inv, int Tp, int T) {
+    const int64_t g = blockIdx.x;
+    float s = 0.f;
+    for (int t = threadIdx.x; t < T; t += 64) s += norms[g * Tp + t];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) inv[g] = (float)T / s;
+}
+
+extern "C" int sc_hidden_normalize(void* hidden, int in_f32, int n_layers, int B, int Tp, int T, int D, int method, float* workspace, void* stream) {
+    SC_CHECK_ARG(hidden && n_layers > 0 && B > 0 && Tp > 0 && T > 0 && T <= Tp && D > 0 && D <= 1024 && D % 4 == 0, "sc_hidden_normalize: bad shape (D a multiple of 4, <= 1024; T <= Tp)");
+    SC_CHECK_ARG(method == 1 || method == 2, "sc_hidden_normalize: method=%d (1: unit frames, 2: utterance-mean frame norm)", method);
+    SC_CHECK_ARG(method == 1 || workspace, "sc_hidden_normalize: method 2 needs a workspace of n_layers * B * (Tp + 1) floats");
+    const int64_t rows = (int64_t)n_layers * B * Tp;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define SC_HN(F32, MODE, NORMS, INV) hipLaunchKernelGGL((hidden_rownorm_kernel<F32, MODE>), grid, block, 0, s, hidden, rows, D, Tp, NORMS, INV)
+    if (method == 1) {
+        if (in_f32) SC_HN(true, 1, nullptr, nullptr); else SC_HN(false, 1, nullptr, nullptr);
+    } else {
+        float* norms = workspace;
+        float* inv = workspace + rows;
+        if (in_f32) SC_HN(true, 0, norms, nullptr); else SC_HN(false, 0, norms, nullptr);
+        hipLaunchKernelGGL(hidden_group_inv_mean_kernel, dim3((unsigned)(n_layers * B)), dim3(64), 0, s, norms, inv, Tp, T);
+        if (in_f32) SC_HN(true, 2, nullptr, inv); else SC_HN(false, 2, nullptr, inv);
+    }
+#undef SC_HN
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
 // Deterministic split-K finish: out[m, n] = act( sum_s part[s][m][n] + bias[n] ) + residual[m][n], partials summed in the fixed order s = 0..S-1
 // (no atomics: the eval path is bitwise run-to-run stable).  act: SC_ACT_NONE / SC_ACT_GELU (erf form).  n_total = M * N, a multiple of 4.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t n_total, int N, const float* __restrict__ bias,

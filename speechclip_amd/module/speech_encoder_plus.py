@@ -202,8 +202,9 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             padded = torch.zeros(len(wavs), max(lens), device=dev, dtype=torch.float32)
             for i, w in enumerate(wavs):
                 padded[i, : lens[i]] = w.to(dev, torch.float32)
-        if self.normalize_hiddenstates and self.normalize_type.startswith("method"):
-            raise NotImplementedError("normalize_type method1/method2 are not used by any shipped config")
+        # speech_encoder_plus.py:572-592: `normalize_type` method1 / method2 overwrite every hidden state before they are mixed / returned ("s3prl" instead
+        # normalises inside WeightedSumLayer).  They need the reference's padded [B, T] layout (method2 averages over ALL T frames of the padded batch).
+        norm_method = self.normalize_type if (self.normalize_hiddenstates and self.normalize_type.startswith("method")) else None
         if feat_select_idx is None:
             feat_select_idx = self.feat_select_idx
         # layerdrop (speech_encoder_plus.py:49-53): ONE np.random.random() per layer per forward, in layer order and in every mode (the
@@ -224,7 +225,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         # are returned, selected by index, or needed by the training tail's layer-mix gradient.
         mix_only = (feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE and not return_hidden_states
                     and not (torch.is_grad_enabled() and self.weightedsum_layer.weights.requires_grad)
-                    and not self.weightedsum_layer.normalize_features)
+                    and not self.weightedsum_layer.normalize_features and norm_method is None)
         if drop and feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             # WeightedSumLayer.forward asserts one weight per hidden state (weighted_sum.py:36): the reference fails here too
             raise AssertionError(self.upstream_model_hiddenstates_len - len(drop))
@@ -235,9 +236,13 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
             feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()
             return (mixed, feat_len)
         if self.train_layers and torch.is_grad_enabled():
+            if norm_method is not None:
+                raise NotImplementedError("fine-tuning the encoder under normalize_type method1 / method2 is not built (no shipped config uses them)")
             return self._forward_finetune(padded, lens, feat_select_idx, return_hidden_states, drop_seed)
-        pack = self._pack_plan(padded, lens)
+        pack = self._pack_plan(padded, lens) if norm_method is None else None
         hidden, T, Tp, _valid = self.encoder.extract_all_layers(padded, lens, drop_layers=drop, dropout_seed=drop_seed, pack=pack)      # [n, B, Tp, d]
+        if norm_method is not None:
+            ops.hidden_normalize_(hidden, T, norm_method)           # in place on this forward's states, as the reference overwrites layer_results[i]
         # speech_encoder_plus.py:604-611: Python round() (banker's) of len / 320, clamped to T
         feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()   # escapes to the caller
         if pack is not None:

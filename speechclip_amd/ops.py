@@ -230,6 +230,17 @@ def weighted_sum(hidden, weights, normalize=False, eps=1e-5):
     return out
 
 
+def hidden_normalize_(hidden, T, method):
+    """In place: hidden [n, B, Tp, D] (bf16 / f32, contiguous) normalised as speech_encoder_plus.py:572-592 does for normalize_type "method1" / "method2"."""
+    _need_cuda(hidden)
+    assert hidden.dim() == 4 and hidden.is_contiguous() and hidden.dtype in (bf16, torch.float32) and method in ("method1", "method2")
+    n, B, Tp, D = hidden.shape
+    m = 1 if method == "method1" else 2
+    ws = torch.empty(n * B * (Tp + 1), device=hidden.device, dtype=torch.float32) if m == 2 else None
+    check(lib().sc_hidden_normalize(ptr(hidden), int(hidden.dtype == torch.float32), n, B, Tp, int(T), D, m, ptr(ws), stream()), "sc_hidden_normalize")
+    return hidden
+
+
 def gemm_splitk(a16, w16, K_chunk, bias=None, act=ACT_NONE, residual=None):
     """f32 [M, N] = act(a16 [M, K] @ w16 [N, K]^T + bias) + residual as a DETERMINISTIC split-K product: the K / K_chunk chunks run as one batched
     GEMM into fp32 partials [S, M, N] (S x more tiles for few-row, deep-K shapes), sc_splitk_reduce_f32 sums them in fixed order."""

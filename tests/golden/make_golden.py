@@ -596,9 +596,52 @@ def gen_feat_len_table(kwclip_mod, OrderedNamespace):
     save("feat_len.npz", table=np.array(rows, dtype=np.int64))
 
 
+def gen_norm_methods():
+    """`normalize_hiddenstates: true` with `normalize_type: method1 / method2` (speech_encoder_plus.py:572-592; no shipped YAML uses them, the shipped large
+    configs use "s3prl" = per-feature layer_norm inside WeightedSumLayer): the reference's OWN FairseqSpeechEncoder_Hubert.forward on the weights and waves of
+    the e2e_tiny_{base,large}_p fixtures.  Stored: the normalised hidden states the reference returns (first / last) and the mixed frames."""
+    from avssl.module.speech_encoder_plus import FairseqSpeechEncoder_Hubert
+    out = {}
+    for tag, large in (("tiny_base_p", False), ("tiny_large_p", True)):
+        g = np.load(os.path.join(HERE, f"e2e_{tag}.npz"))
+        STATE["hubert_cfg"] = hubert_ref.HubertRefConfig.tiny(layer_norm_first=large, extractor_mode="layer_norm" if large else "default", conv_bias=large)
+        STATE["clip_cfg"] = clip_ref.ClipRefConfig.tiny()
+        sd = {k[len("sd/audio_encoder."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/audio_encoder.")}
+        wav, wav_len = torch.from_numpy(g["wav"]), torch.from_numpy(g["wav_len"])
+        for method in ("method1", "method2"):
+            enc = FairseqSpeechEncoder_Hubert("hubert_large_ll60k" if large else "hubert", pretrained=True, feat_select_idx="weighted_sum",
+                                              normalize_hiddenstates=True, normalize_type=method).eval()
+            missing, unexpected = enc.load_state_dict(sd, strict=False)
+            assert not unexpected and all("mask_emb" in k or "final_proj" in k or "label_embs" in k for k in missing), (missing, unexpected)
+            assert enc.weightedsum_layer.normalize_features is False          # only "s3prl" normalises inside the layer mix (:472-476)
+            with torch.no_grad():
+                feat, flen, hidden = enc(wav, wav_len, return_hidden_states=True)
+            # the standalone oracle restatement must agree
+            hs = speechclip_ref.normalize_hidden_states([h.clone() for h in hidden_raw(enc, wav, wav_len)], method)
+            for a, b in zip(hs, hidden):
+                assert torch.allclose(a, b, atol=1e-6), method
+            out[f"{tag}/{method}/feat"] = feat.numpy()
+            out[f"{tag}/{method}/hidden_0"] = hidden[0].numpy()
+            out[f"{tag}/{method}/hidden_last"] = hidden[-1].numpy()
+            out[f"{tag}/{method}/feat_len"] = flen.numpy()
+    save("norm_methods.npz", **out)
+
+
+def hidden_raw(enc, wav, wav_len):
+    """The un-normalised hidden states of the same encoder (normalisation switched off for one call)."""
+    enc.normalize_hiddenstates = False
+    try:
+        with torch.no_grad():
+            return enc(wav, wav_len, return_hidden_states=True)[2]
+    finally:
+        enc.normalize_hiddenstates = True
+
+
 def main():
     only_analysis = "--only-analysis" in sys.argv
     install_stubs()
+    if "--only-norm-methods" in sys.argv:      # adds tests/golden/norm_methods.npz without touching the other fixtures
+        return gen_norm_methods()
     import avssl.module.losses as losses_mod
     import avssl.module.retrieval as retrieval_mod
     import avssl.module.weighted_sum as ws_mod

@@ -69,6 +69,39 @@ def test_tiny_parallel_vs_reference_glue(tag, large):
     assert abs(log_metrics["cl_temp"] - 1 / 0.07) < 1e-4
 
 
+@pytest.mark.parametrize("tag,large", [("tiny_base_p", False), ("tiny_large_p", True)])
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_normalize_type_methods_vs_reference_glue(tag, large, method):
+    """audio_encoder.normalize_hiddenstates: true with normalize_type method1 / method2 (speech_encoder_plus.py:572-592): sc_hidden_normalize overwrites the
+    stacked hidden states in place before they are mixed / returned; against what the reference's own encoder forward returned on the same weights and
+    ragged waves (tests/golden/norm_methods.npz): the normalised states (hidden_0, hidden_last) and the mixed frames, per utterance over its own frames."""
+    from speechclip_amd.model import KWClip_GeneralTransformer
+    g = np.load(os.path.join(GOLD, f"e2e_{tag}.npz"))
+    n = np.load(os.path.join(GOLD, "norm_methods.npz"))
+    hc, cc = _tiny_cfgs(large)
+    cfg = make_config(d_model=128, branch_heads=4, hubert_config=hc, clip_config=cc, hubert_name="hubert_large_ll60k" if large else "hubert",
+                      normalize_hiddenstates=True)
+    cfg.audio_encoder.normalize_type = method
+    model = KWClip_GeneralTransformer(cfg)
+    assert model.audio_encoder.weightedsum_layer.normalize_features is False
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    model.load_state_dict(sd, strict=False)
+    model = model.cuda().eval()
+    wav, wav_len = torch.from_numpy(g["wav"]).cuda(), torch.from_numpy(g["wav_len"]).cuda()
+    with torch.no_grad():
+        feat, flen, hidden = model.forward_audio(wav, wav_len, return_hidden_states=True)
+    assert np.array_equal(flen.cpu().numpy(), n[f"{tag}/{method}/feat_len"])
+    for b, L in enumerate(n[f"{tag}/{method}/feat_len"]):
+        for got, key in ((hidden[0], "hidden_0"), (hidden[-1], "hidden_last"), (feat, "feat")):
+            ref = torch.from_numpy(n[f"{tag}/{method}/{key}"])
+            assert _cos(got[b:b + 1, :L], ref[b:b + 1, :L]).item() > 0.998, (key, b)
+            # the SCALE is what these methods set: unit frames (method1) / unit mean frame norm per utterance (method2)
+            rn, gn = ref[b, :L].norm(dim=-1).mean().item(), got[b, :L].float().norm(dim=-1).mean().item()
+            assert abs(gn - rn) < 2e-2 * rn, (key, b, gn, rn)
+    if method == "method1":
+        torch.testing.assert_close(hidden[-1].float().norm(dim=-1), torch.ones_like(hidden[-1][..., 0]).float(), atol=1e-2, rtol=0)
+
+
 def test_tiny_cascaded_vs_reference_glue(tmp_path):
     vocab = np.array([0, 320, 510, 511] + list(range(5, 300, 3)))
     vp = str(tmp_path / "vocab.npy")

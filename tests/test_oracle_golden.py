@@ -95,6 +95,24 @@ def test_e2e_parallel_golden(tag, large):
     assert abs(m.compute_loss(o)["loss"].item() - float(g["loss"])) < 1e-5
 
 
+@pytest.mark.parametrize("tag,large", [("tiny_base_p", False), ("tiny_large_p", True)])
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_normalize_type_methods_golden(tag, large, method):
+    """`normalize_hiddenstates` with `normalize_type` method1 / method2 (speech_encoder_plus.py:572-592): the oracle's restatement against what the
+    reference's own FairseqSpeechEncoder_Hubert.forward returned on the e2e fixtures' weights and waves (tests/golden/norm_methods.npz)."""
+    cfg = HubertRefConfig.tiny(layer_norm_first=large, extractor_mode="layer_norm" if large else "default", conv_bias=large)
+    g, m, batch = _build(tag, cfg, cascaded=False, parallel=True, norm_hidden=False)
+    n = _load("norm_methods.npz")
+    with torch.no_grad():
+        _, flen, hidden = m.forward_audio(batch["wav"], batch["wav_len"])
+        hs = R.normalize_hidden_states(hidden, method)
+        feat = R.weighted_sum(hs, m.ws_weights, False)
+    assert np.array_equal(flen.numpy(), n[f"{tag}/{method}/feat_len"])
+    np.testing.assert_allclose(hs[0].numpy(), n[f"{tag}/{method}/hidden_0"], atol=2e-6)
+    np.testing.assert_allclose(hs[-1].numpy(), n[f"{tag}/{method}/hidden_last"], atol=2e-6)
+    np.testing.assert_allclose(feat.numpy(), n[f"{tag}/{method}/feat"], atol=2e-6)
+
+
 @pytest.mark.parametrize("tag", ["tiny_base_c", "tiny_base_c2"])
 def test_e2e_cascaded_golden(tag):
     vocab = torch.tensor([0, 320, 510, 511] + list(range(5, 300, 3)))
