@@ -450,8 +450,9 @@ def _kw_cascaded_forward_train(self, audio_feat: torch.Tensor, audio_len: torch.
     assert emb.requires_grad is False
     cos = ops.cosine_scores(kw.detach().reshape(B * K, self.text_dim), emb)                     # fp32 [B*K, V]
     vq_results = self.vector_quantizer(x=cos.view(B, K, emb.shape[0]))
-    keywords = KeywordSTFn.apply(kw.reshape(B * K, self.text_dim), cos, vq_results["targets"].reshape(-1), emb,
-                                 self.vector_quantizer.temperature_value(), (0, 2, 3)).view(B, K, emb.shape[1])
+    vq = self.vector_quantizer      # a learnable temperature (vq.temp: "learnable=...") goes in as the parameter itself: KeywordSTFn returns its gradient
+    temp = vq.curr_temp if getattr(vq, "temp_type", "") == "learnable" else vq.temperature_value()
+    keywords = KeywordSTFn.apply(kw.reshape(B * K, self.text_dim), cos, vq_results["targets"].reshape(-1), emb, temp, (0, 2, 3)).view(B, K, emb.shape[1])
     feat = self.clip.encode_keywords(keywords, K)
     return feat, vq_results, keywords
 

@@ -59,8 +59,7 @@ class SimpleVectorQuantizer(nn.Module):
     def forward(self, x, prob_msk=[0, 2, 3], produce_targets=True):
         # train mode: same statistics and hard targets; the straight-through gradient (softmax(x / temp), :133-141) is applied where the
         # sub-word embeddings are formed (train_tail.KeywordSTFn via KW_CascadedBranch), `subword_prob` stays the hard one-hot value.
-        if self.training and self.temp_type == "learnable":
-            raise NotImplementedError("training a learnable VQ temperature is not supported (no shipped config uses it)")
+        # (a learnable temperature, `temp: "learnable=..."`, gets its gradient there too: d loss / d T = -(1 / T) sum dcos . cos)
         B, K, V = x.shape
         targets, stats, ent = ops.vq_fwd(x.reshape(B * K, V), K, prob_msk)
         res = _LazyOneHot()

@@ -331,7 +331,11 @@ class KeywordSTFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, kb, cos, targets, emb, temp, mask_ids):
+        """temp: a float, or the quantizer's LEARNABLE temperature parameter (`vq.temp: "learnable=..."`, my_vector_quantizer.py:33-38): then its gradient is
+        returned too.  With z = cos / T and soft = softmax(z): d loss / d T = sum_v (d loss / d z_v)(-cos_v / T^2) = -(1 / T) sum_v dcos_v cos_v, and
+        `rowdot` = sum_v dcos_v cos_v is what sc_vq_st_bwd already returns per row for the cosine backward."""
         ctx.save_for_backward(kb.detach().float().contiguous(), cos, emb)
+        ctx.temp_is_param = torch.is_tensor(temp) and temp.requires_grad
         ctx.temp, ctx.mask_ids = float(temp), tuple(int(i) for i in mask_ids)
         return ops.gather_rows(emb, targets.reshape(-1))
 
@@ -342,7 +346,8 @@ class KeywordSTFn(torch.autograd.Function):
         dprob = _mfma_f32(dkw.float().contiguous(), E2)                                       # d loss / d subword_prob = dkw @ emb^T  [R, V]
         rowdot = ops.vq_st_bwd_(cos, dprob, ctx.temp, ctx.mask_ids)                           # dprob is now d loss / d cos
         G = _mfma_f32(dprob, U2)                                                              # dcos @ (emb / |emb|)  [R, E]
-        return ops.cosine_bwd_finish(kb, G, rowdot), None, None, None, None, None
+        dtemp = (rowdot.sum() * (-1.0 / ctx.temp)).reshape(1) if ctx.temp_is_param else None
+        return ops.cosine_bwd_finish(kb, G, rowdot), None, None, None, dtemp, None
 
 
 class TextTowerTrainFn(torch.autograd.Function):

@@ -411,6 +411,20 @@ def test_keyword_st_fn_mfma_path(R, V, E):
     scale = a.grad.abs().max().item()
     err = (a2.grad - a.grad).abs().max().item()
     assert err < 2e-3 * scale, (err, scale)          # bf16 sub-word table inside the two products (hi+lo split on the gradient side)
+    # LEARNABLE temperature (vq.temp: "learnable=0.1", my_vector_quantizer.py:33-38): the parameter goes in, its gradient comes out
+    tp = torch.nn.Parameter(torch.tensor([0.1], device=dev()))
+    a3 = a.detach().clone().requires_grad_(True)
+    cos3 = F.cosine_similarity(a3.unsqueeze(2), emb.t().unsqueeze(0), dim=1)
+    x3 = cos3.clone()
+    x3[:, [0, 2, 3]] = float("-inf")
+    soft3 = torch.softmax(x3 / tp, -1)
+    ((torch.zeros_like(x3).scatter_(-1, tgt[:, None], 1.0) + soft3 - soft3.detach()) @ emb).backward(dkw)
+    tq = torch.nn.Parameter(torch.tensor([0.1], device=dev()))
+    a4 = a.detach().clone().requires_grad_(True)
+    KeywordSTFn.apply(a4, ops.cosine_scores(a4.detach(), emb), tgt, emb, tq, (0, 2, 3)).backward(dkw)
+    assert tq.grad is not None and tq.grad.shape == (1,)
+    assert abs(tq.grad.item() - tp.grad.item()) < 5e-3 * abs(tp.grad.item()) + 1e-6, (tq.grad.item(), tp.grad.item())
+    assert (a4.grad - a3.grad).abs().max().item() < 2e-3 * scale
 
 
 def test_text_tower_input_gradient_vit_b32_dims():
