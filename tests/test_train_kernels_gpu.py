@@ -416,8 +416,8 @@ def test_keyword_st_fn_mfma_path(R, V, E):
     a3 = a.detach().clone().requires_grad_(True)
     cos3 = F.cosine_similarity(a3.unsqueeze(2), emb.t().unsqueeze(0), dim=1)
     x3 = cos3.clone()
-    x3[:, [0, 2, 3]] = float("-inf")
-    soft3 = torch.softmax(x3 / tp, -1)
+    x3[:, [0, 2, 3]] = -1e4      # finite stand-in for the reference's -inf mask: autograd of (-inf / T) w.r.t. T is 0 * inf = NaN (the reference's own learnable
+    soft3 = torch.softmax(x3 / tp, -1)      # temperature gets NaN gradients through its masked columns); exp(-1e5) is exactly 0, so the forward is identical
     ((torch.zeros_like(x3).scatter_(-1, tgt[:, None], 1.0) + soft3 - soft3.detach()) @ emb).backward(dkw)
     tq = torch.nn.Parameter(torch.tensor([0.1], device=dev()))
     a4 = a.detach().clone().requires_grad_(True)
