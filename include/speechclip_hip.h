@@ -57,7 +57,11 @@ int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
  * operands behind the same entry (bench.py `vendor_comparator`, tools/blas_compare.py).  The product path never registers one: every GEMM of
  * the hot path runs on gemm256_kernel / gemm_bf16_kernel.  Caller-owned device scratch, 64 MiB is plenty; NULL switches the comparator off. */
 int sc_set_gemm_workspace(void* workspace, int64_t bytes);
-int sc_gemm_last_path(void);   /* instrumentation: 1 if the last sc_gemm_bf16 call ran on the vendor library, 0 on the hand-written kernels */
+int sc_gemm_last_path(void);   /* instrumentation: which kernel the last sc_gemm_bf16 call ran on: 0 gemm256_kernel / gemm_bf16_kernel, 1 the vendor
+                                * library (comparator), 2 gemm_duet_kernel (the phase-shifted two-group form of the 256-column tile; hand-written too) */
+/* Developer / test switch for the duet kernel: -1 dispatcher's rule (default), 0 never, 4 or 8: whenever the shape allows it, with that many
+ * epilogue steps per half tile. */
+void sc_debug_set_gemm_duet(int mode);
 /* instrumentation (comparator only): which half of the comparator workspace `stream` owns: 0 / 1, -1 none yet, -2 both halves belong to other
  * streams (that stream's GEMMs run on the hand-written kernels), -3 comparator library not loaded.  The comparator ABI itself is declared once,
  * in speechclip_amd/csrc/vendor/vendor_abi.h, for both libraries. */

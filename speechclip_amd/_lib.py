@@ -112,6 +112,7 @@ def _declare(L):
         "sc_layernorm_bwd": ([P, P, P, P, P, P, P, I, I, F, I, P], c_int),
         "sc_gelu_f32": ([P, P, L64, I, P], c_int),
         "sc_gemm_last_path": ([], c_int),
+        "sc_debug_set_gemm_duet": ([I], None),
         "sc_debug_vendor_stream_slot": ([P], c_int),
         "sc_split_hilo_bf16": ([P, L64, P, L64, I, I, P], c_int),
         "sc_cosine_refine": ([P, P, P, I, I, I, F, F, P], c_int),

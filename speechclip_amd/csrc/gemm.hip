@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
+#include "gemm_duet.h"
 #include "../../include/speechclip_hip.h"
 
 namespace {
@@ -1027,8 +1028,14 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
 int sc_vendor_gemm_try(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* residual,
                        int64_t ldr, int64_t M, int N, int K, int out_f32, hipStream_t s);   // vendor_gemm.hip
 
-static int g_last_path = 0;   // 0: hand-written kernels of this file, 1: vendor library (instrumentation: which kernel a bench launch hit)
+static int g_last_path = 0;   // 0: gemm256_kernel / gemm_bf16_kernel, 1: vendor library, 2: gemm_duet_kernel (instrumentation: which kernel a launch hit)
 extern "C" int sc_gemm_last_path(void) { return g_last_path; }
+// Duet kernel (gemm_duet.hip) selection: -1 the dispatcher's rule (default), 0 never, 4 / 8 whenever the shape allows, with that many epilogue steps
+#ifndef SC_GEMM_DUET
+#define SC_GEMM_DUET -1
+#endif
+static int g_duet_mode = SC_GEMM_DUET;
+extern "C" void sc_debug_set_gemm_duet(int mode) { g_duet_mode = mode; }
 static unsigned long long* g_gemm_trace = nullptr;
 // per-phase s_memtime stamps of the 256-tile kernel: effective only in the PROBES build (the product library instantiates no TRACE variant)
 extern "C" void sc_debug_set_gemm_trace(void* dev_buf) { g_gemm_trace = SC_PROBES ? (unsigned long long*)dev_buf : nullptr; }
@@ -1040,6 +1047,19 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         // plain GEMM (+ bias, + residual; bf16 or fp32 out): the vendor library's kernel when a workspace is registered (vendor_gemm.hip)
         const int rc = sc_vendor_gemm_try(A, lda, W, ldw, C, ldc, bias, residual, ldr, M, N, K, (flags & SC_GEMM_OUT_F32) ? 1 : 0, (hipStream_t)stream);
         if (rc <= 0) { g_last_path = 1; return rc; }
+    }
+    if (g_duet_mode != 0 && !(flags & SC_GEMM_OUT_F32) && (!g_gemm_trace || g_duet_mode > 0) && A && W && C && M > 0 && N > 0 && K > 0) {
+        DuetParams d{};
+        d.A = (const bf16_t*)A; d.lda = lda; d.W = (const bf16_t*)W; d.ldw = ldw; d.C = (bf16_t*)C; d.ldc = ldc;
+        d.bias = bias; d.residual = (const bf16_t*)residual; d.ldr = ldr; d.M = M; d.N = N; d.K = K;
+        d.act = flags & SC_GEMM_ACT_MASK;
+        d.kpair = (!SC_TUNE_SET("SC_GEMM_NOKPAIR") && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) ? (int)(lda / 2 / 64) : 0;
+        d.esteps = g_duet_mode == 8 ? 8 : g_duet_mode == 17 ? 1 : 4;      // mode 17: gemm8p, plain per-tile kernel; 16: persistent + rolling epilogue
+        d.trace = g_gemm_trace;
+        if (((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!residual || ((uintptr_t)residual & 15) == 0)) {
+            const int rc = g_duet_mode >= 16 ? sc_gemm8p_try(d, (hipStream_t)stream) : sc_gemm_duet_try(d, (hipStream_t)stream);
+            if (rc <= 0) { g_last_path = g_duet_mode >= 16 ? 3 : 2; return rc; }
+        }
     }
     g_last_path = 0;
     GemmParams p{};

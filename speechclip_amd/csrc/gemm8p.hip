@@ -1,0 +1,535 @@
+// bf16 MFMA GEMM, ping-pong ("8-phase") form for gfx950 (CDNA4):  C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual, bf16 out.
+//
+// 256 x 256 x 64 tiles, 8 waves = 2 groups (waves 0-3 / 4-7: one wave of each group on every SIMD) x 4 column strips; wave tile 128 x 64.
+// Each 64-deep k-step is cut into 4 PHASES per wave: one 64 x 32 quadrant of the wave tile = 16 MFMAs, preceded by the LDS fragment reads it needs
+// and by the LDS-DMA issue of one 16 KiB half tile of a later k-step.  A phase is two barrier intervals -- memory (reads + DMA issue), then matrix
+// (16 back-to-back MFMAs at s_setprio 1) -- and the two groups run ONE INTERVAL APART: while a SIMD's group-0 wave is in its MFMA cluster the
+// group-1 wave issues its reads and DMA, and vice versa.  The matrix pipe always has exactly one wave streaming MFMAs and never waits behind a
+// vector-memory / LDS issue stall of the same wave (gemm256_kernel interleaves 4 MFMA : 1 read : 1 DMA in every wave, all 8 waves in lock step,
+// and measures as if MFMA, DMA issue and LDS reads did not overlap at all: profiles/r05_duet_ablation.txt).
+//
+// LDS: 2 buffers x {A0, A1, B0, B1} half tiles of 128 rows x 128 B (A_g: the 128 rows of group g; B_h: W rows h*128 ..), swizzled on the source
+// side like gemm.hip (chunk position c of row r holds k-chunk c ^ (r & 7)).  Refill: phase (t,0) A0(t+1), (t,1) A1(t+1), (t,2) B0(t+2), (t,3) B1(t+2):
+// every slot is re-staged at least one full phase after the last wave finished reading it (reads are waited for BEFORE the barrier that ends a
+// memory interval), and at least 3.5 phases before its first reader.  One counted wait per k-step (phase 3: vmcnt(4)).
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "gemm_duet.h"
+#include "../../include/speechclip_hip.h"
+
+#ifndef SC_PROBES
+#define SC_PROBES 0
+#endif
+#ifndef SC_8P_PRIO
+#define SC_8P_PRIO 1
+#endif
+
+namespace {
+
+constexpr int HT = 128 * 128;            // one half tile: 128 rows x 128 B = 16 KiB
+constexpr int BUF = 4 * HT;              // A0 A1 B0 B1
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int ACT, bool RES>
+__global__ __launch_bounds__(512) void gemm8p_kernel(DuetParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, w4 = wave & 3;
+    const int nk = p.nk;
+
+    // XCD-aware tile order (bijective): blocks b, b + 8, .. share an XCD and take a contiguous, M-panel-major chunk of the tile space
+    const int tiles_m = (int)(p.M / 256), tiles_n = p.tn;
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tm = v / tiles_n, tn = v - tm * tiles_n;
+    const int64_t m0 = (int64_t)tm * 256;
+    const int n0 = tn * 256;
+    const bf16_t* ta = p.A + m0 * p.lda;
+    const bf16_t* tw = p.W + (int64_t)n0 * p.ldw;
+
+    const int frow = lane & 15, fk = lane >> 4;
+    const int off_h0 = frow * 128 + ((fk ^ (frow & 7)) << 4);
+    const int off_h1 = frow * 128 + (((4 + fk) ^ (frow & 7)) << 4);
+    // fragment bases inside a buffer: A half of my group; my 64-row strip of W inside its half tile
+    const int a_base = g * HT;
+    const int b_base = 2 * HT + (w4 >> 1) * HT + (w4 & 1) * 64 * 128;
+
+    // LDS-DMA: a half tile = 2 instructions per wave: rows q * 64 + wave * 8 + (lane >> 3)
+    const int lr = lane >> 3, lc = lane & 7;
+    const int64_t lane_a = (int64_t)(wave * 8 + lr) * p.lda + ((lc ^ lr) << 3);
+    const int64_t lane_w = (int64_t)(wave * 8 + lr) * p.ldw + ((lc ^ lr) << 3);
+    const int64_t lda64 = 64 * p.lda, ldw64 = 64 * p.ldw;
+    auto stage_a = [&](int h, int kt, char* buf) {     // A half tile h of k-step kt
+        const bf16_t* src = ta + (int64_t)h * 128 * p.lda + (int64_t)kt * 64 + lane_a;
+        char* dst = buf + h * HT + wave * 1024;
+        glds16(src, dst);
+        glds16(src + lda64, dst + 8192);
+    };
+    auto stage_b = [&](int h, int kt, char* buf) {     // W half tile h of k-step kt
+        const bf16_t* src = tw + (int64_t)h * 128 * p.ldw + (int64_t)kt * 64 + lane_w;
+        char* dst = buf + (2 + h) * HT + wave * 1024;
+        glds16(src, dst);
+        glds16(src + ldw64, dst + 8192);
+    };
+
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if (SC_PROBES && p.trace) tr0 = __builtin_readcyclecounter();
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t af[4][2], bf_[2][2][2];          // af[i][h]: row block i of the current A sub tile, k half h; bf_[b][j][h]: column block j of B sub tile b
+
+    // prologue: k-step 0 complete, W of k-step 1
+    {
+        char* b0 = smem; char* b1 = smem + BUF;
+        stage_a(0, 0, b0); stage_a(1, 0, b0); stage_b(0, 0, b0); stage_b(1, 0, b0);
+        if (nk > 1) { stage_b(0, 1, b1); stage_b(1, 1, b1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (g == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // group 1 runs one barrier interval behind group 0
+    if (SC_PROBES && p.trace) tr1 = __builtin_readcyclecounter();
+
+    auto read_a = [&](const char* buf, int a) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const bf16x8_t*)(buf + a_base + (a * 64 + i * 16) * 128 + off_h0);
+            af[i][1] = *(const bf16x8_t*)(buf + a_base + (a * 64 + i * 16) * 128 + off_h1);
+        }
+    };
+    auto read_b = [&](const char* buf, int b) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf_[b][j][0] = *(const bf16x8_t*)(buf + b_base + (b * 32 + j * 16) * 128 + off_h0);
+            bf_[b][j][1] = *(const bf16x8_t*)(buf + b_base + (b * 32 + j * 16) * 128 + off_h1);
+        }
+    };
+    auto quadrant = [&](auto atag, auto btag) {
+        constexpr int a = decltype(atag)::value, b = decltype(btag)::value;
+        if (SC_8P_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[a * 4 + i][b * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[b][j][h], af[i][h], acc[a * 4 + i][b * 2 + j], 0, 0, 0);
+        if (SC_8P_PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+    auto mem_end = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mat_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    char* bx = smem;            // buffer of k-step kt
+    char* by = smem + BUF;      // the other one
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---- phase 0: quadrant (a0, b0); stage A0(kt + 1)
+        read_a(bx, 0); read_b(bx, 0);
+        if (kt + 1 < nk) stage_a(0, kt + 1, by);
+        mem_end();
+        quadrant(I0{}, I0{});
+        mat_end();
+        // ---- phase 1: quadrant (a0, b1); stage A1(kt + 1)
+        read_b(bx, 1);
+        if (kt + 1 < nk) stage_a(1, kt + 1, by);
+        mem_end();
+        quadrant(I0{}, I1{});
+        mat_end();
+        // ---- phase 2: quadrant (a1, b1); stage B0(kt + 2) into the slot B0(kt) left after phase 1
+        read_a(bx, 1);
+        if (kt + 2 < nk) stage_b(0, kt + 2, bx);
+        mem_end();
+        quadrant(I1{}, I1{});
+        mat_end();
+        // ---- phase 3: quadrant (a1, b0); stage B1(kt + 2); everything of k-step kt + 1 must have landed (in-order: all but the newest 4 / 2 / 0)
+        if (kt + 2 < nk) { stage_b(1, kt + 2, bx); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mem_end();
+        quadrant(I1{}, I0{});
+        mat_end();
+        { char* x = bx; bx = by; by = x; }
+    }
+    if (g == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    if (SC_PROBES && p.trace) tr2 = __builtin_readcyclecounter();
+
+    // ---- epilogue (same store shape as gemm.hip's fast path: 16 rows x 64 contiguous bytes per store)
+    f32x4_t bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nn = n0 + w4 * 64 + j * 16 + fk * 4;
+        bias4[j] = p.bias ? *(const f32x4_t*)(p.bias + nn) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const int srow = lane >> 2, schunk = lane & 3;
+    const int src_fk = ((schunk & 1) << 1) | (schunk >> 1);
+    const int bperm = (src_fk * 16 + srow) << 2;
+    const int ncol0 = n0 + w4 * 64 + schunk * 8;
+    const int64_t mrow0 = m0 + g * 128 + srow;
+    bf16_t* cptr = p.C + mrow0 * p.ldc + ncol0;
+    const bf16_t* rptr = RES ? p.residual + mrow0 * p.ldr + ncol0 : nullptr;
+    const int64_t cstep = 16 * p.ldc, rstep = 16 * p.ldr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint4 rv[2];
+        if (RES) {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) rv[jp] = *(const uint4*)(rptr + i * rstep + jp * 32);
+        }
+        uint2 pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4_t v4 = acc[i][j] + bias4[j];
+            if (ACT == SC_ACT_GELU) {
+                const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
+                v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+            } else if (ACT == SC_ACT_QUICKGELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
+            }
+            pk[j].x = pack2bf(v4[0], v4[1]);
+            pk[j].y = pack2bf(v4[2], v4[3]);
+        }
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            const auto r0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].x, pk[2 * jp + 1].x, false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].y, pk[2 * jp + 1].y, false, false);
+            uint4 o = make_uint4(__builtin_amdgcn_ds_bpermute(bperm, r0[0]), __builtin_amdgcn_ds_bpermute(bperm, r1[0]),
+                                 __builtin_amdgcn_ds_bpermute(bperm, r0[1]), __builtin_amdgcn_ds_bpermute(bperm, r1[1]));
+            if (RES) {
+                o.x = pack2bf(lo2f(o.x) + lo2f(rv[jp].x), hi2f(o.x) + hi2f(rv[jp].x));
+                o.y = pack2bf(lo2f(o.y) + lo2f(rv[jp].y), hi2f(o.y) + hi2f(rv[jp].y));
+                o.z = pack2bf(lo2f(o.z) + lo2f(rv[jp].z), hi2f(o.z) + hi2f(rv[jp].z));
+                o.w = pack2bf(lo2f(o.w) + lo2f(rv[jp].w), hi2f(o.w) + hi2f(rv[jp].w));
+            }
+            *(uint4*)(cptr + i * cstep + jp * 32) = o;
+        }
+    }
+    if (SC_PROBES && p.trace && lane == 0) {     // per wave: prologue (launch -> first k-step), k-loop, epilogue issue; absolute start / end stamps
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tr3 = __builtin_readcyclecounter();
+        unsigned long long* tr = p.trace + ((size_t)(blockIdx.x % 4096) * 8 + wave) * 8;
+        tr[0] = tr1 - tr0; tr[1] = tr2 - tr1; tr[2] = tr3 - tr2; tr[3] = tr0; tr[4] = tr3;
+        tr[5] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11));
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Persistent form.  One block per CU walks its tile list; the k-step sequence runs on across tile boundaries: the DMA refill issued from the last
+// two k-steps of a tile already belongs to the next tile (its whole first k-step and the W halves of the second), so that tile starts without a
+// prologue, and its loads land while the epilogue runs.  The accumulators are re-initialised quadrant by quadrant inside the memory intervals of the
+// first k-step (32 moves beside the other group's MFMA cluster instead of 128 in front of the first one).
+// (A ROLLING epilogue -- quadrant Q_p of the finished tile converted and stored inside the memory interval that precedes the first MFMA cluster of
+// quadrant Q_p of the next tile -- was built and measured in round 5: 3-7 % SLOWER than even the per-tile kernel on the K = 768 shapes.  The CU's
+// store path moves 24-36 B/clk; 16 KiB of stores per group and interval stretch each of the 8 intervals of that k-step far beyond the 256 cycles
+// of the MFMA cluster they were meant to hide under.  EXPERIMENTS.md, round 5.)
+template <int ACT, bool RES>
+__global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, w4 = wave & 3;
+    const int nk = p.nk;
+
+    // persistent XCD-aware tile list (as gemm256_kernel): block b lives on XCD b % 8 and takes every nb_xcd-th tile of that XCD's contiguous,
+    // M-panel-major chunk of the tile space
+    const int tiles_m = (int)(p.M / 256), tiles_n = p.tn;
+    const int nwg = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
+    const int nb_xcd = (G - xcd + 7) >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int my_tiles = slot_in_xcd < cnt ? (cnt - slot_in_xcd + nb_xcd - 1) / nb_xcd : 0;
+    if (my_tiles == 0) return;
+    auto tile_mn = [&](int it, int& tm, int& tn) { const int v = begin + it * nb_xcd + slot_in_xcd; tm = v / tiles_n; tn = v - tm * tiles_n; };
+
+    const int frow = lane & 15, fk = lane >> 4;
+    const int off_h0 = frow * 128 + ((fk ^ (frow & 7)) << 4);
+    const int off_h1 = frow * 128 + (((4 + fk) ^ (frow & 7)) << 4);
+    const int a_base = g * HT;
+    const int b_base = 2 * HT + (w4 >> 1) * HT + (w4 & 1) * 64 * 128;
+
+    const int lr = lane >> 3, lc = lane & 7;
+    const int64_t lane_a = (int64_t)(wave * 8 + lr) * p.lda + ((lc ^ lr) << 3);
+    const int64_t lane_w = (int64_t)(wave * 8 + lr) * p.ldw + ((lc ^ lr) << 3);
+    const int64_t lda64 = 64 * p.lda, ldw64 = 64 * p.ldw;
+    auto stage_a = [&](const bf16_t* ta, int h, int kt, char* buf) {
+        const bf16_t* src = ta + (int64_t)h * 128 * p.lda + (int64_t)kt * 64 + lane_a;
+        char* dst = buf + h * HT + wave * 1024;
+        glds16(src, dst);
+        glds16(src + lda64, dst + 8192);
+    };
+    auto stage_b = [&](const bf16_t* tw, int h, int kt, char* buf) {
+        const bf16_t* src = tw + (int64_t)h * 128 * p.ldw + (int64_t)kt * 64 + lane_w;
+        char* dst = buf + (2 + h) * HT + wave * 1024;
+        glds16(src, dst);
+        glds16(src + ldw64, dst + 8192);
+    };
+
+    // bias: the whole vector sits in the 32 KiB of LDS the two operand buffers leave free (N <= 8192, host check) and is read per tile with ds_read
+    // (lgkmcnt): an ordinary global load inside the persistent loop makes hipcc wait vmcnt(0) in front of its first use in EVERY pass of the loop,
+    // which drains the LDS-DMA pipeline
+    for (int n = tid * 4; n < p.N; n += 512 * 4)
+        *(f32x4_t*)(smem + 2 * BUF + n * 4) = p.bias ? *(const f32x4_t*)(p.bias + n) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const char* lds_bias = smem + 2 * BUF;
+
+    f32x4_t acc[8][4];
+    bf16x8_t af[4][2], bf_[2][2][2];
+
+    int tm, tn;
+    tile_mn(0, tm, tn);
+    const bf16_t* ta = p.A + (int64_t)tm * 256 * p.lda;
+    const bf16_t* tw = p.W + (int64_t)tn * 256 * p.ldw;
+    {
+        char* b0 = smem; char* b1 = smem + BUF;
+        stage_a(ta, 0, 0, b0); stage_a(ta, 1, 0, b0); stage_b(tw, 0, 0, b0); stage_b(tw, 1, 0, b0);
+        stage_b(tw, 0, 1, b1); stage_b(tw, 1, 1, b1);          // nk >= 2 (host check)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (g == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // group 1 runs one barrier interval behind group 0
+
+    // epilogue lane mapping (gemm.hip): lane L stores row L >> 2, 16-byte chunk L & 3 of a 32-column half
+    const int srow = lane >> 2, schunk = lane & 3;
+    const int src_fk = ((schunk & 1) << 1) | (schunk >> 1);
+    const int bperm = (src_fk * 16 + srow) << 2;
+    const int64_t cstep = 16 * p.ldc, rstep = 16 * p.ldr;
+
+    auto read_a = [&](const char* buf, int a) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const bf16x8_t*)(buf + a_base + (a * 64 + i * 16) * 128 + off_h0);
+            af[i][1] = *(const bf16x8_t*)(buf + a_base + (a * 64 + i * 16) * 128 + off_h1);
+        }
+    };
+    auto read_b = [&](const char* buf, int b) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf_[b][j][0] = *(const bf16x8_t*)(buf + b_base + (b * 32 + j * 16) * 128 + off_h0);
+            bf_[b][j][1] = *(const bf16x8_t*)(buf + b_base + (b * 32 + j * 16) * 128 + off_h1);
+        }
+    };
+    auto quadrant = [&](auto atag, auto btag) {
+        constexpr int a = decltype(atag)::value, b = decltype(btag)::value;
+        if (SC_8P_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[a * 4 + i][b * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[b][j][h], af[i][h], acc[a * 4 + i][b * 2 + j], 0, 0, 0);
+        if (SC_8P_PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+    auto init_q = [&](auto atag, auto btag) {
+        constexpr int a = decltype(atag)::value, b = decltype(btag)::value;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) acc[a * 4 + ii][b * 2 + jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    };
+    auto mem_end = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mat_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    char* bx = smem;
+    char* by = smem + BUF;
+    for (int it = 0; it < my_tiles; ++it) {
+        const bool have_next = it + 1 < my_tiles;
+        int ntm = tm, ntn = tn;
+        if (have_next) tile_mn(it + 1, ntm, ntn);
+        const bf16_t* ta_n = p.A + (int64_t)ntm * 256 * p.lda;
+        const bf16_t* tw_n = p.W + (int64_t)ntn * 256 * p.ldw;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool first = kt == 0;
+            // staged during this k-step: A of the next k-step, W of the one after it (possibly of the next tile)
+            const bool a_ok = kt + 1 < nk || have_next;
+            const bf16_t* sa = kt + 1 < nk ? ta : ta_n;
+            const int sa_k = kt + 1 < nk ? kt + 1 : 0;
+            const bool b_ok = kt + 2 < nk || have_next;
+            const bf16_t* sb = kt + 2 < nk ? tw : tw_n;
+            const int sb_k = kt + 2 < nk ? kt + 2 : kt + 2 - nk;
+            // ---- phase 0: quadrant (a0, b0)
+            if (first) init_q(I0{}, I0{});
+            read_a(bx, 0); read_b(bx, 0);
+            if (a_ok) stage_a(sa, 0, sa_k, by);
+            mem_end();
+            quadrant(I0{}, I0{});
+            mat_end();
+            // ---- phase 1: quadrant (a0, b1)
+            if (first) init_q(I0{}, I1{});
+            read_b(bx, 1);
+            if (a_ok) stage_a(sa, 1, sa_k, by);
+            mem_end();
+            quadrant(I0{}, I1{});
+            mat_end();
+            // ---- phase 2: quadrant (a1, b1); W half 0 of k-step + 2 into the slot this k-step's left after phase 1
+            if (first) init_q(I1{}, I1{});
+            read_a(bx, 1);
+            if (b_ok) stage_b(sb, 0, sb_k, bx);
+            mem_end();
+            quadrant(I1{}, I1{});
+            mat_end();
+            // ---- phase 3: quadrant (a1, b0); the next k-step's A must have landed: in-order, everything but the 4 W pieces of phases 2, 3
+            if (first) init_q(I1{}, I0{});
+            if (b_ok) { stage_b(sb, 1, sb_k, bx); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            mem_end();
+            quadrant(I1{}, I0{});
+            mat_end();
+            { char* x = bx; bx = by; by = x; }
+        }
+        // ---- epilogue: 16 rows x 64 contiguous bytes per store (gemm.hip's fast path); the next tile's first k-step is landing meanwhile
+        {
+            f32x4_t bias4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias4[j] = *(const f32x4_t*)(lds_bias + (tn * 256 + w4 * 64 + j * 16 + fk * 4) * 4);
+            const int64_t mrow0 = (int64_t)tm * 256 + g * 128 + srow;
+            const int ncol0 = tn * 256 + w4 * 64 + schunk * 8;
+            bf16_t* cptr = p.C + mrow0 * p.ldc + ncol0;
+            const bf16_t* rptr = RES ? p.residual + mrow0 * p.ldr + ncol0 : nullptr;
+            uint4 res[RES ? 4 : 1][2];
+            auto load_res = [&](int i) {
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) res[i & 3][jp] = *(const uint4*)(rptr + i * rstep + jp * 32);
+            };
+            if (RES) { load_res(0); load_res(1); load_res(2); load_res(3); }
+            auto shuffled = [&](int i, uint4 (&o)[2]) {
+                uint2 pk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4_t v4 = acc[i][j] + bias4[j];
+                    if (ACT == SC_ACT_GELU) {
+                        const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
+                        v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+                    } else if (ACT == SC_ACT_QUICKGELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
+                    }
+                    pk[j].x = pack2bf(v4[0], v4[1]);
+                    pk[j].y = pack2bf(v4[2], v4[3]);
+                }
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].x, pk[2 * jp + 1].x, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].y, pk[2 * jp + 1].y, false, false);
+                    o[jp] = make_uint4(__builtin_amdgcn_ds_bpermute(bperm, r0[0]), __builtin_amdgcn_ds_bpermute(bperm, r1[0]),
+                                       __builtin_amdgcn_ds_bpermute(bperm, r0[1]), __builtin_amdgcn_ds_bpermute(bperm, r1[1]));
+                }
+            };
+            uint4 oc[2][2];
+            shuffled(0, oc[0]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i + 1 < 8) shuffled(i + 1, oc[(i + 1) & 1]);          // next block's shuffles fly under this block's stores
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    uint4 o = oc[i & 1][jp];
+                    if (RES) {
+                        const uint4 rv = res[i & 3][jp];
+                        o.x = pack2bf(lo2f(o.x) + lo2f(rv.x), hi2f(o.x) + hi2f(rv.x));
+                        o.y = pack2bf(lo2f(o.y) + lo2f(rv.y), hi2f(o.y) + hi2f(rv.y));
+                        o.z = pack2bf(lo2f(o.z) + lo2f(rv.z), hi2f(o.z) + hi2f(rv.z));
+                        o.w = pack2bf(lo2f(o.w) + lo2f(rv.w), hi2f(o.w) + hi2f(rv.w));
+                    }
+                    *(uint4*)(cptr + i * cstep + jp * 32) = o;
+                }
+                if (RES && i + 4 < 8) load_res(i + 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        tm = ntm; tn = ntn; ta = ta_n; tw = tw_n;
+    }
+    if (g == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+}
+
+template <int ACT, bool RES>
+int launch_pers(const DuetParams& p, int grid, hipStream_t s) {
+    constexpr int lds = 2 * BUF + 32768;   // 128 KiB of operands + the bias vector
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm8p_pers_kernel<ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm8p_pers_kernel<ACT, RES>), dim3(grid), dim3(512), lds, s, p);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int ACT, bool RES>
+int launch_one(const DuetParams& p, int grid, hipStream_t s) {
+    constexpr int lds = 2 * BUF;   // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm8p_kernel<ACT, RES>), dim3(grid), dim3(512), lds, s, p);
+    SC_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+int sc_gemm8p_try(const DuetParams& pin, hipStream_t s) {
+    DuetParams p = pin;
+    if (p.N % 256 || p.K % 64 || p.M < 256 || p.M % 256) return 1;
+    p.tn = p.N / 256; p.nk = p.K / 64;
+    if (p.nk < 2) return 1;
+    if (p.ldc % 8 || (p.residual && p.ldr % 8) || p.lda % 8 || p.ldw % 8) return 1;
+    const int64_t tiles = (p.M / 256) * p.tn;
+    if (tiles > 0x7fffffff) return 1;
+    const int grid = (int)tiles;
+    const bool res = p.residual != nullptr;
+    if (p.esteps != 1 && p.N <= 8192) {       // persistent form (esteps == 1: the plain per-tile kernel, A/B)
+        static int n_cu = 0;
+        if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+        const int pg = grid < n_cu ? grid : n_cu;
+        switch (p.act) {
+            case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false>(p, pg, s);
+            case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false>(p, pg, s);
+            default: return res ? launch_pers<SC_ACT_NONE, true>(p, pg, s) : launch_pers<SC_ACT_NONE, false>(p, pg, s);
+        }
+    }
+    switch (p.act) {
+        case SC_ACT_GELU: return res ? launch_one<SC_ACT_GELU, true>(p, grid, s) : launch_one<SC_ACT_GELU, false>(p, grid, s);
+        case SC_ACT_QUICKGELU: return res ? launch_one<SC_ACT_QUICKGELU, true>(p, grid, s) : launch_one<SC_ACT_QUICKGELU, false>(p, grid, s);
+        default: return res ? launch_one<SC_ACT_NONE, true>(p, grid, s) : launch_one<SC_ACT_NONE, false>(p, grid, s);
+    }
+}

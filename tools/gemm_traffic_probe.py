@@ -5,6 +5,9 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from speechclip_amd import ops
+from speechclip_amd._lib import lib
+if os.environ.get('SC_DUET_MODE'):
+    lib().sc_debug_set_gemm_duet(int(os.environ['SC_DUET_MODE']))
 for spec in sys.argv[1:]:
     name, rest = spec.split(":")
     M, N, K, lda, act = (int(v) for v in rest.split(","))
