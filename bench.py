@@ -746,7 +746,7 @@ def main():
             flags_c = [concurrent(e) for e in prof]
             part = {}
             for path, name in ((0, "hand_written"), (1, "vendor")):
-                sel = [e for e, c in zip(prof, flags_c) if e[3][6] == path and not c]
+                sel = [e for e, c in zip(prof, flags_c) if (e[3][6] == 1) == (path == 1) and not c]      # path 1 = vendor library; 0 / 2 / 3 = hand-written kernels
                 pms = sum(e[0].elapsed_time(e[1]) for e in sel)
                 pfl = sum(e[2] for e in sel) * (alg / exe)     # algorithmic share (executed flops include <0.2 % tile padding)
                 part[name] = {"launches_per_step": len(sel) // ev_steps, "ms_per_step": round(pms / ev_steps, 3),

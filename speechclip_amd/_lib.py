@@ -33,6 +33,10 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.sc_last_error.restype = c_char_p
         _declare(_lib)
+        # SC_GEMM_KERNEL_MODE: developer override of the bf16 GEMM kernel choice (sc_debug_set_gemm_duet: 0 = gemm256_kernel only, 16 = gemm8p wherever
+        # the shape allows, ...), for in-step A/B timing; unset = the dispatcher's rule
+        if os.environ.get("SC_GEMM_KERNEL_MODE"):
+            _lib.sc_debug_set_gemm_duet(int(os.environ["SC_GEMM_KERNEL_MODE"]))
     return _lib
 
 

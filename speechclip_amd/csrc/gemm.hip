@@ -1049,16 +1049,22 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         if (rc <= 0) { g_last_path = 1; return rc; }
     }
     if (g_duet_mode != 0 && !(flags & SC_GEMM_OUT_F32) && (!g_gemm_trace || g_duet_mode > 0) && A && W && C && M > 0 && N > 0 && K > 0) {
+        // bf16-output GEMMs with N % 256 == 0: the ping-pong kernel (gemm8p.hip), persistent form, from 256 tiles up (below that one round of tiles
+        // does not fill the chip and gemm256_kernel's / gemm_bf16_kernel's smaller grids do as well)
         DuetParams d{};
         d.A = (const bf16_t*)A; d.lda = lda; d.W = (const bf16_t*)W; d.ldw = ldw; d.C = (bf16_t*)C; d.ldc = ldc;
         d.bias = bias; d.residual = (const bf16_t*)residual; d.ldr = ldr; d.M = M; d.N = N; d.K = K;
         d.act = flags & SC_GEMM_ACT_MASK;
-        d.kpair = (!SC_TUNE_SET("SC_GEMM_NOKPAIR") && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) ? (int)(lda / 2 / 64) : 0;
-        d.esteps = g_duet_mode == 8 ? 8 : g_duet_mode == 17 ? 1 : 4;      // mode 17: gemm8p, plain per-tile kernel; 16: persistent + rolling epilogue
+        d.kpair = (g_duet_mode == 20 && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) ? (int)(lda / 2 / 64) : 0;      // tap-paired K walk: A/B (mode 20)
+        d.esteps = g_duet_mode == 8 ? 8 : g_duet_mode == 17 ? 1 : g_duet_mode == 18 ? 2 : 4;      // 17: gemm8p per-tile kernel; 18: half-barrier schedule
         d.trace = g_gemm_trace;
-        if (((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!residual || ((uintptr_t)residual & 15) == 0)) {
-            const int rc = g_duet_mode >= 16 ? sc_gemm8p_try(d, (hipStream_t)stream) : sc_gemm_duet_try(d, (hipStream_t)stream);
-            if (rc <= 0) { g_last_path = g_duet_mode >= 16 ? 3 : 2; return rc; }
+        d.rows = g_duet_mode == 19 ? 1 : 0;      // gemm8p: K rotation per M panel (A/B: mode 19)
+        const bool aligned = ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!residual || ((uintptr_t)residual & 15) == 0);
+        const bool dflt_ok = N % 256 == 0 && ((M + 255) / 256) * (int64_t)(N / 256) >= 256;
+        if (aligned && (g_duet_mode > 0 || dflt_ok)) {
+            const bool duet = g_duet_mode == 4 || g_duet_mode == 8;
+            const int rc = duet ? sc_gemm_duet_try(d, (hipStream_t)stream) : sc_gemm8p_try(d, (hipStream_t)stream);
+            if (rc <= 0) { g_last_path = duet ? 2 : 3; return rc; }
         }
     }
     g_last_path = 0;

@@ -24,6 +24,9 @@
 #ifndef SC_8P_PRIO
 #define SC_8P_PRIO 1
 #endif
+#ifndef SC_8P_P0WAIT          // 1: phase 0 waits for all its 12 fragment reads before the barrier (A/B)
+#define SC_8P_P0WAIT 1
+#endif
 
 namespace {
 
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(DuetParams p) {
 // quadrant Q_p of the next tile -- was built and measured in round 5: 3-7 % SLOWER than even the per-tile kernel on the K = 768 shapes.  The CU's
 // store path moves 24-36 B/clk; 16 KiB of stores per group and interval stretch each of the 8 intervals of that k-step far beyond the 256 cycles
 // of the MFMA cluster they were meant to hide under.  EXPERIMENTS.md, round 5.)
-template <int ACT, bool RES>
+template <int ACT, bool RES, bool HB>
 __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
 
     // persistent XCD-aware tile list (as gemm256_kernel): block b lives on XCD b % 8 and takes every nb_xcd-th tile of that XCD's contiguous,
     // M-panel-major chunk of the tile space
-    const int tiles_m = (int)(p.M / 256), tiles_n = p.tn;
+    const int tiles_m = (int)((p.M + 255) / 256), tiles_n = p.tn;
     const int nwg = tiles_m * tiles_n;
     const int G = gridDim.x;
     const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
@@ -277,14 +280,14 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
     const int64_t lane_a = (int64_t)(wave * 8 + lr) * p.lda + ((lc ^ lr) << 3);
     const int64_t lane_w = (int64_t)(wave * 8 + lr) * p.ldw + ((lc ^ lr) << 3);
     const int64_t lda64 = 64 * p.lda, ldw64 = 64 * p.ldw;
-    auto stage_a = [&](const bf16_t* ta, int h, int kt, char* buf) {
-        const bf16_t* src = ta + (int64_t)h * 128 * p.lda + (int64_t)kt * 64 + lane_a;
+    auto stage_a = [&](const bf16_t* ta, int h, int k0, char* buf) {      // k0: element offset of the k-chunk
+        const bf16_t* src = ta + (int64_t)h * 128 * p.lda + k0 + lane_a;
         char* dst = buf + h * HT + wave * 1024;
         glds16(src, dst);
         glds16(src + lda64, dst + 8192);
     };
-    auto stage_b = [&](const bf16_t* tw, int h, int kt, char* buf) {
-        const bf16_t* src = tw + (int64_t)h * 128 * p.ldw + (int64_t)kt * 64 + lane_w;
+    auto stage_b = [&](const bf16_t* tw, int h, int k0, char* buf) {
+        const bf16_t* src = tw + (int64_t)h * 128 * p.ldw + k0 + lane_w;
         char* dst = buf + (2 + h) * HT + wave * 1024;
         glds16(src, dst);
         glds16(src + ldw64, dst + 8192);
@@ -301,19 +304,34 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
     f32x4_t acc[8][4];
     bf16x8_t af[4][2], bf_[2][2][2];
 
+    // k walk of a tile: step j reads chunk (j + rot) mod nk of the walk, rot = M-panel index mod nk (the blocks of an XCD would otherwise all pull the
+    // SAME W rows at the same instant: L2 channel de-correlation, as gemm256_kernel); kpair > 0 (stride-2 kernel-3 conv as GEMM, K = 3C, lda = 2C):
+    // the walk visits (tap 0 chunk c, tap 2 chunk c) pairs, then tap 1 -- tap 2 of row r IS tap 0 of row r + 1, so the two touches of those lines are one
+    // k-step apart (an L2 hit) instead of 2C / 64 k-steps apart.  A sum over K is order-free.
+    const int kpair = p.kpair;
+    auto kofs = [&](int j, int rot) -> int {
+        int c = j + rot; c = c >= nk ? c - nk : c;
+        if (kpair > 0) c = c < 2 * kpair ? (c >> 1) + (c & 1) * 2 * kpair : c - kpair;
+        return c * 64;
+    };
+    // a tile that would cross M is shifted back to END at M (every row in range); its stores skip the rows that belong to the previous tile
+    auto tile_a = [&](int tm_) -> const bf16_t* { const int64_t m = (int64_t)tm_ * 256; return p.A + (m + 256 <= p.M ? m : p.M - 256) * p.lda; };
+
     int tm, tn;
     tile_mn(0, tm, tn);
-    const bf16_t* ta = p.A + (int64_t)tm * 256 * p.lda;
+    const bf16_t* ta = tile_a(tm);
     const bf16_t* tw = p.W + (int64_t)tn * 256 * p.ldw;
+    int rot = p.rows ? tm % nk : 0;          // (p.rows reused as the rotation switch: 0 = off)
     {
         char* b0 = smem; char* b1 = smem + BUF;
-        stage_a(ta, 0, 0, b0); stage_a(ta, 1, 0, b0); stage_b(tw, 0, 0, b0); stage_b(tw, 1, 0, b0);
-        stage_b(tw, 0, 1, b1); stage_b(tw, 1, 1, b1);          // nk >= 2 (host check)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        const int k0 = kofs(0, rot), k1 = kofs(1, rot);
+        stage_a(ta, 0, k0, b0); stage_a(ta, 1, k0, b0); stage_b(tw, 0, k0, b0); stage_b(tw, 1, k0, b0);
+        stage_b(tw, 0, k1, b1); stage_b(tw, 1, k1, b1); stage_a(ta, 0, k1, b1); stage_a(ta, 1, k1, b1);          // nk >= 2 (host check)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    if (g == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // group 1 runs one barrier interval behind group 0
+    if (!HB && g == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // group 1 runs one barrier interval behind group 0
 
     // epilogue lane mapping (gemm.hip): lane L stores row L >> 2, 16-byte chunk L & 3 of a 32-column half
     const int srow = lane >> 2, schunk = lane & 3;
@@ -333,6 +351,18 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
         for (int j = 0; j < 2; ++j) {
             bf_[b][j][0] = *(const bf16x8_t*)(buf + b_base + (b * 32 + j * 16) * 128 + off_h0);
             bf_[b][j][1] = *(const bf16x8_t*)(buf + b_base + (b * 32 + j * 16) * 128 + off_h1);
+        }
+    };
+    // phase 0: k half 0 of both operands first, then k half 1 (the second half's LDS latency may run under the first 8 MFMAs of the cluster)
+    auto read_ab_p0 = [&](const char* buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int off = h ? off_h1 : off_h0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf_[0][j][h] = *(const bf16x8_t*)(buf + b_base + (j * 16) * 128 + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i][h] = *(const bf16x8_t*)(buf + a_base + (i * 16) * 128 + off);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto quadrant = [&](auto atag, auto btag) {
@@ -370,57 +400,138 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
 
     char* bx = smem;
     char* by = smem + BUF;
+    unsigned long long tr_loop = 0, tr_epi = 0, tr_first = 0, tr_t = 0;
+    const bool tracing = SC_PROBES && p.trace;
+    if (tracing) tr_t = __builtin_readcyclecounter();
+    const unsigned long long tr_begin = tr_t;
     for (int it = 0; it < my_tiles; ++it) {
         const bool have_next = it + 1 < my_tiles;
         int ntm = tm, ntn = tn;
         if (have_next) tile_mn(it + 1, ntm, ntn);
-        const bf16_t* ta_n = p.A + (int64_t)ntm * 256 * p.lda;
+        const bf16_t* ta_n = tile_a(ntm);
         const bf16_t* tw_n = p.W + (int64_t)ntn * 256 * p.ldw;
+        const int rot_n = p.rows ? ntm % nk : 0;
+        if (HB) {
+        // ---- ONE barrier per phase.  Inside a barrier interval the LEADER group (g = 0) runs [MFMA cluster of phase p][reads of phase p + 1] and the
+        // FOLLOWER group (g = 1) [reads of phase p][MFMA cluster of phase p]: the two waves of a SIMD take the matrix pipe one after the other without
+        // a barrier in between (the follower's reads take about as long as the leader's cluster), and each wave's LDS latency hides under the other
+        // wave's cluster.  k-step + 2 is requested in intervals 2 (W halves: last read in interval 1) and 3 (A halves: last read in interval 2);
+        // k-step + 1 is waited for at the end of interval 2 (in-order: all but the 4 W pieces just issued), one barrier before its first reader.
+        auto bar = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto lgk0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+        const bool lead = g == 0;
+        if (lead) {          // the leader enters the tile with the fragments of (k-step 0, phase 0) in registers
+            read_a(bx, 0); read_b(bx, 0);
+            lgk0();
+        }
         for (int kt = 0; kt < nk; ++kt) {
             const bool first = kt == 0;
-            // staged during this k-step: A of the next k-step, W of the one after it (possibly of the next tile)
-            const bool a_ok = kt + 1 < nk || have_next;
-            const bf16_t* sa = kt + 1 < nk ? ta : ta_n;
-            const int sa_k = kt + 1 < nk ? kt + 1 : 0;
-            const bool b_ok = kt + 2 < nk || have_next;
+            if (tracing && kt == 1) { const unsigned long long c = __builtin_readcyclecounter(); tr_first += c - tr_t; tr_t = c; }
+            const bool s_ok = kt + 2 < nk || have_next;
+            const bf16_t* sa = kt + 2 < nk ? ta : ta_n;
             const bf16_t* sb = kt + 2 < nk ? tw : tw_n;
-            const int sb_k = kt + 2 < nk ? kt + 2 : kt + 2 - nk;
+            const int s_k = kt + 2 < nk ? kofs(kt + 2, rot) : kofs(kt + 2 - nk, rot_n);
+            // (ONE copy of each MFMA cluster: with separate leader / follower copies the register allocator sends the accumulators through scratch)
+            // ---- interval 0
+            bar();
+            if (!lead) { read_a(bx, 0); read_b(bx, 0); lgk0(); }
+            if (first) init_q(I0{}, I0{});
+            quadrant(I0{}, I0{});
+            if (lead) { read_b(bx, 1); lgk0(); }
+            // ---- interval 1
+            bar();
+            if (!lead) { read_b(bx, 1); lgk0(); }
+            if (first) init_q(I0{}, I1{});
+            quadrant(I0{}, I1{});
+            if (lead) { read_a(bx, 1); lgk0(); }
+            // ---- interval 2: W halves of k-step + 2; k-step + 1 must have landed before the next barrier
+            bar();
+            if (!lead) {
+                read_a(bx, 1);
+                if (s_ok) { stage_b(sb, 0, s_k, bx); stage_b(sb, 1, s_k, bx); }
+                lgk0();
+            }
+            if (first) init_q(I1{}, I1{});
+            quadrant(I1{}, I1{});
+            if (lead && s_ok) { stage_b(sb, 0, s_k, bx); stage_b(sb, 1, s_k, bx); }
+            if (s_ok) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ---- interval 3: A halves of k-step + 2
+            bar();
+            if (!lead && s_ok) { stage_a(sa, 0, s_k, bx); stage_a(sa, 1, s_k, bx); }
+            if (first) init_q(I1{}, I0{});
+            quadrant(I1{}, I0{});
+            if (lead) {
+                if (s_ok) { stage_a(sa, 0, s_k, bx); stage_a(sa, 1, s_k, bx); }
+                if (kt + 1 < nk) { read_a(by, 0); read_b(by, 0); lgk0(); }      // (tile boundary: read after the epilogue, the registers are needed there)
+            }
+            { char* x = bx; bx = by; by = x; }
+        }
+        } else
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool first = kt == 0;
+            if (tracing && kt == 1) { const unsigned long long c = __builtin_readcyclecounter(); tr_first += c - tr_t; tr_t = c; }
+            // Refill: the whole of k-step + 2 (possibly the next tile's) is issued from phases 2 and 3 of this k-step into THIS k-step's buffer: its
+            // W halves are free after phase 1 (every wave holds its W fragments in registers), its A halves after phase 2.  Everything is requested a
+            // full k-step before its first reader, and -- tile boundary -- the next tile's first TWO k-steps are requested before the epilogue's
+            // stores enter the queue, so they do not wait behind them (in-order retirement).
+            const bool s_ok = kt + 2 < nk || have_next;
+            const bf16_t* sa = kt + 2 < nk ? ta : ta_n;
+            const bf16_t* sb = kt + 2 < nk ? tw : tw_n;
+            const int s_k = kt + 2 < nk ? kofs(kt + 2, rot) : kofs(kt + 2 - nk, rot_n);
             // ---- phase 0: quadrant (a0, b0)
             if (first) init_q(I0{}, I0{});
+#if SC_8P_P0WAIT
             read_a(bx, 0); read_b(bx, 0);
-            if (a_ok) stage_a(sa, 0, sa_k, by);
             mem_end();
+#else
+            // (no explicit wait: these slots are not refilled before phase 2; hipcc places counted lgkmcnt waits in front of the MFMAs that need each half)
+            read_ab_p0(bx);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             quadrant(I0{}, I0{});
             mat_end();
             // ---- phase 1: quadrant (a0, b1)
             if (first) init_q(I0{}, I1{});
             read_b(bx, 1);
-            if (a_ok) stage_a(sa, 1, sa_k, by);
             mem_end();
             quadrant(I0{}, I1{});
             mat_end();
-            // ---- phase 2: quadrant (a1, b1); W half 0 of k-step + 2 into the slot this k-step's left after phase 1
+            // ---- phase 2: quadrant (a1, b1); both W halves of k-step + 2
             if (first) init_q(I1{}, I1{});
             read_a(bx, 1);
-            if (b_ok) stage_b(sb, 0, sb_k, bx);
+            if (s_ok) { stage_b(sb, 0, s_k, bx); stage_b(sb, 1, s_k, bx); }
             mem_end();
             quadrant(I1{}, I1{});
             mat_end();
-            // ---- phase 3: quadrant (a1, b0); the next k-step's A must have landed: in-order, everything but the 4 W pieces of phases 2, 3
+            // ---- phase 3: quadrant (a1, b0), operands already in registers; both A halves of k-step + 2; k-step + 1 must have landed: in-order,
+            //      everything but the 8 pieces of phases 2 and 3
             if (first) init_q(I1{}, I0{});
-            if (b_ok) { stage_b(sb, 1, sb_k, bx); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            if (s_ok) { stage_a(sa, 0, s_k, bx); stage_a(sa, 1, s_k, bx); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (residual variants: touching the tile's residual lines two k-steps ahead -- 4-byte LDS-DMA loads into a dummy LDS area, gemm256_kernel's trick --
+            //  measured in the step, round 5: out-proj 789 -> 761, fc2 1170 -> 1112 TF/s.  Not kept.)
             mem_end();
             quadrant(I1{}, I0{});
             mat_end();
             { char* x = bx; bx = by; by = x; }
         }
+        if (tracing) { const unsigned long long c = __builtin_readcyclecounter(); tr_loop += c - tr_t; tr_t = c; }
         // ---- epilogue: 16 rows x 64 contiguous bytes per store (gemm.hip's fast path); the next tile's first k-step is landing meanwhile
         {
             f32x4_t bias4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bias4[j] = *(const f32x4_t*)(lds_bias + (tn * 256 + w4 * 64 + j * 16 + fk * 4) * 4);
-            const int64_t mrow0 = (int64_t)tm * 256 + g * 128 + srow;
+            const int64_t m_lo = (int64_t)tm * 256, m0 = m_lo + 256 <= p.M ? m_lo : p.M - 256;
+            const int skip = (int)(m_lo - m0) - g * 128 - srow;            // rows i * 16 + .. below this belong to the previous tile (ragged last M panel)
+            const int64_t mrow0 = m0 + g * 128 + srow;
             const int ncol0 = tn * 256 + w4 * 64 + schunk * 8;
             bf16_t* cptr = p.C + mrow0 * p.ldc + ncol0;
             const bf16_t* rptr = RES ? p.residual + mrow0 * p.ldr + ncol0 : nullptr;
@@ -468,26 +579,31 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
                         o.z = pack2bf(lo2f(o.z) + lo2f(rv.z), hi2f(o.z) + hi2f(rv.z));
                         o.w = pack2bf(lo2f(o.w) + lo2f(rv.w), hi2f(o.w) + hi2f(rv.w));
                     }
-                    *(uint4*)(cptr + i * cstep + jp * 32) = o;
+                    if (i * 16 >= skip) *(uint4*)(cptr + i * cstep + jp * 32) = o;
                 }
                 if (RES && i + 4 < 8) load_res(i + 4);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        tm = ntm; tn = ntn; ta = ta_n; tw = tw_n;
+        if (tracing) { const unsigned long long c = __builtin_readcyclecounter(); tr_epi += c - tr_t; tr_t = c; }
+        tm = ntm; tn = ntn; ta = ta_n; tw = tw_n; rot = rot_n;
     }
-    if (g == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    if (!HB && g == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    if (tracing && lane == 0) {      // per wave: first k-step of every tile / the other k-steps / epilogue issue, block lifetime, tiles
+        unsigned long long* tr = p.trace + ((size_t)blockIdx.x * 8 + wave) * 8;
+        tr[0] = tr_first; tr[1] = tr_loop; tr[2] = tr_epi; tr[3] = __builtin_readcyclecounter() - tr_begin; tr[4] = my_tiles;
+    }
 }
 
-template <int ACT, bool RES>
+template <int ACT, bool RES, bool HB>
 int launch_pers(const DuetParams& p, int grid, hipStream_t s) {
     constexpr int lds = 2 * BUF + 32768;   // 128 KiB of operands + the bias vector
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm8p_pers_kernel<ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm8p_pers_kernel<ACT, RES, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm8p_pers_kernel<ACT, RES>), dim3(grid), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((gemm8p_pers_kernel<ACT, RES, HB>), dim3(grid), dim3(512), lds, s, p);
     SC_CHECK_LAUNCH();
     return 0;
 }
@@ -509,11 +625,12 @@ int launch_one(const DuetParams& p, int grid, hipStream_t s) {
 
 int sc_gemm8p_try(const DuetParams& pin, hipStream_t s) {
     DuetParams p = pin;
-    if (p.N % 256 || p.K % 64 || p.M < 256 || p.M % 256) return 1;
+    if (p.N % 256 || p.K % 64 || p.M < 256) return 1;
+    if (p.M % 256 && (p.esteps == 1 || p.N > 8192)) return 1;      // the per-tile A/B kernel takes full M panels only
     p.tn = p.N / 256; p.nk = p.K / 64;
     if (p.nk < 2) return 1;
     if (p.ldc % 8 || (p.residual && p.ldr % 8) || p.lda % 8 || p.ldw % 8) return 1;
-    const int64_t tiles = (p.M / 256) * p.tn;
+    const int64_t tiles = ((p.M + 255) / 256) * p.tn;
     if (tiles > 0x7fffffff) return 1;
     const int grid = (int)tiles;
     const bool res = p.residual != nullptr;
@@ -521,10 +638,17 @@ int sc_gemm8p_try(const DuetParams& pin, hipStream_t s) {
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
         const int pg = grid < n_cu ? grid : n_cu;
+        if (p.esteps == 2) {      // half-barrier schedule (A/B)
+            switch (p.act) {
+                case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false, true>(p, pg, s);
+                case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true, true>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false, true>(p, pg, s);
+                default: return res ? launch_pers<SC_ACT_NONE, true, true>(p, pg, s) : launch_pers<SC_ACT_NONE, false, true>(p, pg, s);
+            }
+        }
         switch (p.act) {
-            case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false>(p, pg, s);
-            case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false>(p, pg, s);
-            default: return res ? launch_pers<SC_ACT_NONE, true>(p, pg, s) : launch_pers<SC_ACT_NONE, false>(p, pg, s);
+            case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, false>(p, pg, s) : launch_pers<SC_ACT_GELU, false, false>(p, pg, s);
+            case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true, false>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false, false>(p, pg, s);
+            default: return res ? launch_pers<SC_ACT_NONE, true, false>(p, pg, s) : launch_pers<SC_ACT_NONE, false, false>(p, pg, s);
         }
     }
     switch (p.act) {

@@ -153,6 +153,39 @@ def trace8p(only):
         del a, w, out, resid
 
 
+def trace8pp(only):
+    """PROBES library: gemm8p_pers_kernel (mode 16): per tile, cycles in the first k-step (incl. waiting for the partner's epilogue), the others, the epilogue."""
+    import ctypes
+    L = lib()
+    L.sc_debug_set_gemm_trace.argtypes = [ctypes.c_void_p]
+    for name, M, N, K, lda, act, use_res in SHAPES:
+        if only and name not in only:
+            continue
+        ld = lda or K
+        a = (torch.randn(M * ld + K + 64, device="cuda") * 0.5).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device="cuda")
+        resid = torch.randn(M, N, device="cuda").to(torch.bfloat16) if use_res else None
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        L.sc_debug_set_gemm_duet(16)
+        for _ in range(10):
+            ops.gemm(a, w, bias, act, resid, out=out, M=M, K=K, lda=ld)
+        tr = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
+        L.sc_debug_set_gemm_trace(tr.data_ptr())
+        ops.gemm(a, w, bias, act, resid, out=out, M=M, K=K, lda=ld)
+        torch.cuda.synchronize()
+        L.sc_debug_set_gemm_trace(None)
+        t = tr.reshape(256, 8, 8).double()
+        nk = K // 64
+        for grp in (0, 1):
+            x = t[:, 4 * grp:4 * grp + 4, :]
+            tiles = x[:, :, 4].mean()
+            print(f"{name} g{grp}: per tile: first k-step {x[:, :, 0].mean()/tiles:7.0f}  other k-steps {x[:, :, 1].mean()/tiles/(nk-1):6.0f} each  epilogue {x[:, :, 2].mean()/tiles:7.0f}"
+                  f"  | tile {x[:, :, 3].mean()/tiles:7.0f}  tiles/block {tiles:.2f}  lifetime min/max {x[:, :, 3].min():.0f}/{x[:, :, 3].max():.0f}", flush=True)
+        L.sc_debug_set_gemm_duet(-1)
+        del a, w, out, resid
+
+
 def trace(only, modes):
     """PROBES library only (SPEECHCLIP_HIP_LIB=speechclip_amd/libspeechclip_hip_probes.so): per-wave cycles spent in solo / joint / epilogue / null steps."""
     import ctypes
@@ -204,7 +237,7 @@ if __name__ == "__main__":
     while i < len(args):
         if args[i] == "--sustain": sustain = float(args[i + 1]); i += 2
         elif args[i] == "--modes": modes = [int(v) for v in args[i + 1].split(",")]; i += 2
-        elif args[i] in ("check", "time", "trace", "trace8p"): todo.append(args[i]); i += 1
+        elif args[i] in ("check", "time", "trace", "trace8p", "trace8pp"): todo.append(args[i]); i += 1
         else: only.append(args[i]); i += 1
     if not todo: todo = ["check", "time"]
     MODES = modes
@@ -213,4 +246,5 @@ if __name__ == "__main__":
     if "time" in todo: timeit(sustain, modes, only)
     if "trace" in todo: trace(only, modes)
     if "trace8p" in todo: trace8p(only)
+    if "trace8pp" in todo: trace8pp(only)
     sys.exit(0 if ok else 1)
