@@ -1056,7 +1056,7 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         d.bias = bias; d.residual = (const bf16_t*)residual; d.ldr = ldr; d.M = M; d.N = N; d.K = K;
         d.act = flags & SC_GEMM_ACT_MASK;
         d.kpair = (g_duet_mode == 20 && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) ? (int)(lda / 2 / 64) : 0;      // tap-paired K walk: A/B (mode 20)
-        d.esteps = g_duet_mode == 8 ? 8 : g_duet_mode == 17 ? 1 : g_duet_mode == 18 ? 2 : 4;      // 17: gemm8p per-tile kernel; 18: half-barrier schedule
+        d.esteps = g_duet_mode == 8 ? 8 : g_duet_mode == 17 ? 1 : 4;      // 17: gemm8p per-tile kernel
         d.trace = g_gemm_trace;
         d.rows = g_duet_mode == 19 ? 1 : 0;      // gemm8p: K rotation per M panel (A/B: mode 19)
         const bool aligned = ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!residual || ((uintptr_t)residual & 15) == 0);

@@ -24,9 +24,6 @@
 #ifndef SC_8P_PRIO
 #define SC_8P_PRIO 1
 #endif
-#ifndef SC_8P_P0WAIT          // 1: phase 0 waits for all its 12 fragment reads before the barrier (A/B)
-#define SC_8P_P0WAIT 1
-#endif
 
 namespace {
 
@@ -247,7 +244,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(DuetParams p) {
 // quadrant Q_p of the next tile -- was built and measured in round 5: 3-7 % SLOWER than even the per-tile kernel on the K = 768 shapes.  The CU's
 // store path moves 24-36 B/clk; 16 KiB of stores per group and interval stretch each of the 8 intervals of that k-step far beyond the 256 cycles
 // of the MFMA cluster they were meant to hide under.  EXPERIMENTS.md, round 5.)
-template <int ACT, bool RES, bool HB>
+template <int ACT, bool RES>
 __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -331,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    if (!HB && g == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // group 1 runs one barrier interval behind group 0
+    if (g == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // group 1 runs one barrier interval behind group 0
 
     // epilogue lane mapping (gemm.hip): lane L stores row L >> 2, 16-byte chunk L & 3 of a 32-column half
     const int srow = lane >> 2, schunk = lane & 3;
@@ -351,18 +348,6 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
         for (int j = 0; j < 2; ++j) {
             bf_[b][j][0] = *(const bf16x8_t*)(buf + b_base + (b * 32 + j * 16) * 128 + off_h0);
             bf_[b][j][1] = *(const bf16x8_t*)(buf + b_base + (b * 32 + j * 16) * 128 + off_h1);
-        }
-    };
-    // phase 0: k half 0 of both operands first, then k half 1 (the second half's LDS latency may run under the first 8 MFMAs of the cluster)
-    auto read_ab_p0 = [&](const char* buf) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int off = h ? off_h1 : off_h0;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf_[0][j][h] = *(const bf16x8_t*)(buf + b_base + (j * 16) * 128 + off);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i][h] = *(const bf16x8_t*)(buf + a_base + (i * 16) * 128 + off);
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto quadrant = [&](auto atag, auto btag) {
@@ -411,68 +396,9 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
         const bf16_t* ta_n = tile_a(ntm);
         const bf16_t* tw_n = p.W + (int64_t)ntn * 256 * p.ldw;
         const int rot_n = p.rows ? ntm % nk : 0;
-        if (HB) {
-        // ---- ONE barrier per phase.  Inside a barrier interval the LEADER group (g = 0) runs [MFMA cluster of phase p][reads of phase p + 1] and the
-        // FOLLOWER group (g = 1) [reads of phase p][MFMA cluster of phase p]: the two waves of a SIMD take the matrix pipe one after the other without
-        // a barrier in between (the follower's reads take about as long as the leader's cluster), and each wave's LDS latency hides under the other
-        // wave's cluster.  k-step + 2 is requested in intervals 2 (W halves: last read in interval 1) and 3 (A halves: last read in interval 2);
-        // k-step + 1 is waited for at the end of interval 2 (in-order: all but the 4 W pieces just issued), one barrier before its first reader.
-        auto bar = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto lgk0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
-        const bool lead = g == 0;
-        if (lead) {          // the leader enters the tile with the fragments of (k-step 0, phase 0) in registers
-            read_a(bx, 0); read_b(bx, 0);
-            lgk0();
-        }
-        for (int kt = 0; kt < nk; ++kt) {
-            const bool first = kt == 0;
-            if (tracing && kt == 1) { const unsigned long long c = __builtin_readcyclecounter(); tr_first += c - tr_t; tr_t = c; }
-            const bool s_ok = kt + 2 < nk || have_next;
-            const bf16_t* sa = kt + 2 < nk ? ta : ta_n;
-            const bf16_t* sb = kt + 2 < nk ? tw : tw_n;
-            const int s_k = kt + 2 < nk ? kofs(kt + 2, rot) : kofs(kt + 2 - nk, rot_n);
-            // (ONE copy of each MFMA cluster: with separate leader / follower copies the register allocator sends the accumulators through scratch)
-            // ---- interval 0
-            bar();
-            if (!lead) { read_a(bx, 0); read_b(bx, 0); lgk0(); }
-            if (first) init_q(I0{}, I0{});
-            quadrant(I0{}, I0{});
-            if (lead) { read_b(bx, 1); lgk0(); }
-            // ---- interval 1
-            bar();
-            if (!lead) { read_b(bx, 1); lgk0(); }
-            if (first) init_q(I0{}, I1{});
-            quadrant(I0{}, I1{});
-            if (lead) { read_a(bx, 1); lgk0(); }
-            // ---- interval 2: W halves of k-step + 2; k-step + 1 must have landed before the next barrier
-            bar();
-            if (!lead) {
-                read_a(bx, 1);
-                if (s_ok) { stage_b(sb, 0, s_k, bx); stage_b(sb, 1, s_k, bx); }
-                lgk0();
-            }
-            if (first) init_q(I1{}, I1{});
-            quadrant(I1{}, I1{});
-            if (lead && s_ok) { stage_b(sb, 0, s_k, bx); stage_b(sb, 1, s_k, bx); }
-            if (s_ok) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // ---- interval 3: A halves of k-step + 2
-            bar();
-            if (!lead && s_ok) { stage_a(sa, 0, s_k, bx); stage_a(sa, 1, s_k, bx); }
-            if (first) init_q(I1{}, I0{});
-            quadrant(I1{}, I0{});
-            if (lead) {
-                if (s_ok) { stage_a(sa, 0, s_k, bx); stage_a(sa, 1, s_k, bx); }
-                if (kt + 1 < nk) { read_a(by, 0); read_b(by, 0); lgk0(); }      // (tile boundary: read after the epilogue, the registers are needed there)
-            }
-            { char* x = bx; bx = by; by = x; }
-        }
-        } else
+        // (Measured alternatives of this schedule, round 5, same box, TF/s qkv / out / fc2: this one 1128 / 1100 / 1306; TWO phases of 32 MFMAs per k-step --
+        //  half as many barriers -- 1075 / 997 / 1275; ONE barrier per phase with a leader / follower order of the two groups inside the interval
+        //  1100 / 1015 / 1235.  EXPERIMENTS.md.)
         for (int kt = 0; kt < nk; ++kt) {
             const bool first = kt == 0;
             if (tracing && kt == 1) { const unsigned long long c = __builtin_readcyclecounter(); tr_first += c - tr_t; tr_t = c; }
@@ -486,16 +412,8 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
             const int s_k = kt + 2 < nk ? kofs(kt + 2, rot) : kofs(kt + 2 - nk, rot_n);
             // ---- phase 0: quadrant (a0, b0)
             if (first) init_q(I0{}, I0{});
-#if SC_8P_P0WAIT
             read_a(bx, 0); read_b(bx, 0);
-            mem_end();
-#else
-            // (no explicit wait: these slots are not refilled before phase 2; hipcc places counted lgkmcnt waits in front of the MFMAs that need each half)
-            read_ab_p0(bx);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+            mem_end();      // (waiting for phase 0's reads only in front of the MFMAs that need them: +-1 %, round 5)
             quadrant(I0{}, I0{});
             mat_end();
             // ---- phase 1: quadrant (a0, b1)
@@ -588,22 +506,22 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
         if (tracing) { const unsigned long long c = __builtin_readcyclecounter(); tr_epi += c - tr_t; tr_t = c; }
         tm = ntm; tn = ntn; ta = ta_n; tw = tw_n; rot = rot_n;
     }
-    if (!HB && g == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    if (g == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     if (tracing && lane == 0) {      // per wave: first k-step of every tile / the other k-steps / epilogue issue, block lifetime, tiles
         unsigned long long* tr = p.trace + ((size_t)blockIdx.x * 8 + wave) * 8;
         tr[0] = tr_first; tr[1] = tr_loop; tr[2] = tr_epi; tr[3] = __builtin_readcyclecounter() - tr_begin; tr[4] = my_tiles;
     }
 }
 
-template <int ACT, bool RES, bool HB>
+template <int ACT, bool RES>
 int launch_pers(const DuetParams& p, int grid, hipStream_t s) {
     constexpr int lds = 2 * BUF + 32768;   // 128 KiB of operands + the bias vector
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm8p_pers_kernel<ACT, RES, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm8p_pers_kernel<ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm8p_pers_kernel<ACT, RES, HB>), dim3(grid), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((gemm8p_pers_kernel<ACT, RES>), dim3(grid), dim3(512), lds, s, p);
     SC_CHECK_LAUNCH();
     return 0;
 }
@@ -638,17 +556,10 @@ int sc_gemm8p_try(const DuetParams& pin, hipStream_t s) {
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
         const int pg = grid < n_cu ? grid : n_cu;
-        if (p.esteps == 2) {      // half-barrier schedule (A/B)
-            switch (p.act) {
-                case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false, true>(p, pg, s);
-                case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true, true>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false, true>(p, pg, s);
-                default: return res ? launch_pers<SC_ACT_NONE, true, true>(p, pg, s) : launch_pers<SC_ACT_NONE, false, true>(p, pg, s);
-            }
-        }
         switch (p.act) {
-            case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, false>(p, pg, s) : launch_pers<SC_ACT_GELU, false, false>(p, pg, s);
-            case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true, false>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false, false>(p, pg, s);
-            default: return res ? launch_pers<SC_ACT_NONE, true, false>(p, pg, s) : launch_pers<SC_ACT_NONE, false, false>(p, pg, s);
+            case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false>(p, pg, s);
+            case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false>(p, pg, s);
+            default: return res ? launch_pers<SC_ACT_NONE, true>(p, pg, s) : launch_pers<SC_ACT_NONE, false>(p, pg, s);
         }
     }
     switch (p.act) {

@@ -90,7 +90,7 @@ def test_plain_gemms_run_on_the_hand_written_kernel_by_default():
         w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16)
         bias = torch.randn(N, generator=g).cuda()
         y = ops.gemm(a, w, bias)
-        assert lib().sc_gemm_last_path() in (0, 2)
+        assert lib().sc_gemm_last_path() in (0, 2, 3)      # 1 would be the vendor library
         torch.testing.assert_close(y.float(), a.float() @ w.float().t() + bias, atol=3e-2, rtol=2e-2)
 
 
@@ -135,7 +135,7 @@ def test_vendor_comparator_path_correct_on_three_streams():
         ops.set_vendor_gemm(False)
     assert lib().sc_debug_vendor_stream_slot(torch.cuda.current_stream().cuda_stream) in (-1, -3)
     out = ops.gemm(a, w, bias)
-    assert lib().sc_gemm_last_path() in (0, 2)
+    assert lib().sc_gemm_last_path() in (0, 2, 3)      # 1 would be the vendor library
     torch.testing.assert_close(out.float(), ref, atol=3e-2, rtol=2e-2)
 
 
