@@ -103,6 +103,43 @@ __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
     asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(y[1]) : "v"(h), "v"(phi));
     return y;
 }
+// Eight pairs at once, every Horner step issued for all eight before the next step: identical arithmetic to gelu_poly2 per pair (bit-identical results),
+// but the dependent v_pk_fma_f16 chain of one pair (latency + a hazard nop per step) is hidden behind the seven other pairs.  hipcc schedules the per-pair
+// form one or two chains at a time: the GELU epilogue of a 256 x 256 tile was latency-bound (512 v_pk_fma_f16 + 372 s_nop per wave), round 5.
+__device__ __forceinline__ void gelu_poly2_x8(f32x2_t (&x)[8]) {
+    const sc_half2_t one = {(_Float16)1.0f, (_Float16)1.0f}, zero = {(_Float16)0.0f, (_Float16)0.0f};
+    sc_half2_t h[8], t[8], g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = __builtin_bit_cast(sc_half2_t, __builtin_amdgcn_cvt_pkrtz(x[i][0], x[i][1]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = h[i] * h[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = __builtin_elementwise_min(t[i] * (_Float16)0.125f - (_Float16)1.0f, one);
+#if SC_GELU_DEG == 5
+    const float c[6] = {-1.177580447e-02f, 2.993807372e-02f, -3.959858472e-02f, 5.414790186e-02f, -8.377277171e-02f, 1.760021146e-01f};
+    constexpr int NC = 6;
+#else
+    const float c[7] = {5.972025641e-03f, -1.655089296e-02f, 2.409105964e-02f, -3.546234617e-02f, 5.541019052e-02f, -8.442661829e-02f, 1.759702165e-01f};
+    constexpr int NC = 7;
+#endif
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = t[i] * (_Float16)c[0] + (_Float16)c[1];
+#pragma unroll
+    for (int k = 2; k < NC; ++k) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = g[i] * t[i] + (_Float16)c[k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = __builtin_elementwise_min(__builtin_elementwise_max(h[i] * g[i] + (_Float16)0.5f, zero), one);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,1,0]" : "=v"(x[i][0]) : "v"(h[i]), "v"(g[i]));
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(x[i][1]) : "v"(h[i]), "v"(g[i]));
+    }
+}
 #endif
 // fp32 degree-8 form (max |err| 1.7e-5): what every f32-OUTPUT epilogue uses (the packed-half form above carries ~11 bits and is meant for
 // results that are rounded to bf16 right away), and the bf16 epilogues too with -DSC_GELU_F16=0.

@@ -461,18 +461,27 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
             if (RES) { load_res(0); load_res(1); load_res(2); load_res(3); }
             auto shuffled = [&](int i, uint4 (&o)[2]) {
                 uint2 pk[4];
+                if (ACT == SC_ACT_GELU) {          // all 8 value pairs of the row block side by side: gelu_poly2_x8 (common.h)
+                    f32x2_t xs[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4_t v4 = acc[i][j] + bias4[j];
+                        xs[2 * j] = (f32x2_t){v4[0], v4[1]}; xs[2 * j + 1] = (f32x2_t){v4[2], v4[3]};
+                    }
+                    gelu_poly2_x8(xs);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { pk[j].x = pack2bf(xs[2 * j][0], xs[2 * j][1]); pk[j].y = pack2bf(xs[2 * j + 1][0], xs[2 * j + 1][1]); }
+                } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4_t v4 = acc[i][j] + bias4[j];
-                    if (ACT == SC_ACT_GELU) {
-                        const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
-                        v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
-                    } else if (ACT == SC_ACT_QUICKGELU) {
+                    if (ACT == SC_ACT_QUICKGELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
                     }
                     pk[j].x = pack2bf(v4[0], v4[1]);
                     pk[j].y = pack2bf(v4[2], v4[3]);
+                }
                 }
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {

@@ -485,6 +485,13 @@ class KWClip_GeneralTransformer(KWClipBase):
                 self.c_branch_proj_net = MLPLayers(units=p.dimensions, dropout=p.dropout)
 
     def getTrainableParams(self) -> list:
+        # the optional MLP projection heads (image_encoder_projection / parallel_branch_projection / ..., kwClip.py:1161-1190 of the
+        # reference; no shipped YAML has them) are eval-only here: say so when the optimizer is built, not at the first training forward
+        from ..module import MLPLayers
+        heads = [n for n, m in self.named_modules() if isinstance(m, MLPLayers)]
+        if heads:
+            raise NotImplementedError(f"training with the MLP projection heads {heads} is not built on the MI355X path (eval / inference only); "
+                                      "remove the *_projection sections from the config to train (README: gaps)")
         params = super().getTrainableParams()
         for m in (self.cascaded_branch, self.parallel_branch, self.img_enc_proj_net, self.p_branch_proj_net):
             if m is not None:

@@ -15,7 +15,10 @@ def _recall_one_way(score: torch.Tensor, own_ids: torch.Tensor, cand_ids: torch.
     if not score.is_cuda:
         if not torch.cuda.is_available():
             raise SpeechClipHipError("mutualRetrieval ranks on the MI355X (sc_retrieval_ranks); no GPU is visible and there is no host fallback")
-        score = score.cuda()
+        # the device the answer ids live on if they are device tensors (a multi-rank run's model device), else this process's CURRENT device --
+        # never a bare .cuda() (device 0 of whatever is visible)
+        dev = next((t.device for t in (own_ids, cand_ids) if torch.is_tensor(t) and t.is_cuda), torch.device("cuda", torch.cuda.current_device()))
+        score = score.to(dev)
     rank = ops.retrieval_ranks(score.float().contiguous(), own_ids, cand_ids)
     out = {}
     for k in recall_at:

@@ -87,26 +87,42 @@ def gather_rows_dict(d: dict, keys_1d=ROW_KEYS_1D) -> dict:
     if ws == 1:
         return d
     B = d["id"].shape[0]
-    # all_gather_into_tensor needs the same local batch on every rank (the reference's DataParallel splits evenly too): fail loudly otherwise.
-    # ONE small all-reduce and ONE device->host read per call (it must precede the gather: ranks with different B would deadlock inside it).
-    bmm = torch.tensor([B, -B], device=d["id"].device, dtype=torch.int64)
-    dist.all_reduce(bmm, op=dist.ReduceOp.MAX)
-    bmax, nbmin = bmm.tolist()
-    if bmax != B or -nbmin != B:
-        raise ValueError(f"gather_rows_dict: local batch {B} differs across ranks (max {bmax}, min {-nbmin}); use drop_last / equal shards")
+    dev = d["id"].device
+    # all_gather_into_tensor needs the same row count on every rank.  A ragged last validation batch (the reference's DataParallel scatter hands the
+    # first replicas one row more, kwClip.py:193-269; a Flickr8k validation epoch of 5 000 captions does not divide by 8 B) is padded to the largest
+    # local batch and the pad rows are dropped after the gather: ONE small collective (the local row counts) and ONE device->host read per call
+    # (it must precede the gather: ranks with different B would otherwise deadlock inside it).
+    sizes_t = torch.empty(ws, device=dev, dtype=torch.int64)
+    dist.all_gather_into_tensor(sizes_t, torch.tensor([B], device=dev, dtype=torch.int64))
+    sizes = [int(v) for v in sizes_t.tolist()]
+    bmax = max(sizes)
+    ragged = any(v != bmax for v in sizes)
+
+    def pad(v):
+        if v.shape[0] == bmax:
+            return v.contiguous()
+        return torch.cat([v, v.new_zeros((bmax - v.shape[0],) + tuple(v.shape[1:]))], dim=0)
+
+    keep = None
+    if ragged:
+        keep = torch.cat([torch.arange(r * bmax, r * bmax + n, device=dev) for r, n in enumerate(sizes)])      # valid rows, rank-major
+
+    def trim(g):
+        return g if keep is None else g.index_select(0, keep)
+
     flt = {k: v for k, v in d.items() if torch.is_tensor(v) and v.is_floating_point() and v.dim() >= 1 and v.shape[0] == B
            and (v.dim() >= 2 or k in keys_1d)}
     shapes = {k: v.shape[1:] for k, v in flt.items()}
-    feats = {k: v.reshape(B, -1) for k, v in flt.items()}
-    feats["id"] = d["id"]
+    feats = {k: pad(v.reshape(B, -1)) for k, v in flt.items()}
+    feats["id"] = pad(d["id"])
     out = gather_loss_feats(feats)
     res = dict(d)
     for k in flt:
-        res[k] = out[k].view(ws * B, *shapes[k]).to(flt[k].dtype)
-    res["id"] = out["id"]
+        res[k] = trim(out[k]).view(-1, *shapes[k]).to(flt[k].dtype)
+    res["id"] = trim(out["id"])
     for k, v in d.items():
         if k != "id" and torch.is_tensor(v) and not v.is_floating_point() and v.dim() >= 2 and v.shape[0] == B:
-            g = torch.empty(ws * B, *v.shape[1:], device=v.device, dtype=v.dtype)
-            dist.all_gather_into_tensor(g, v.contiguous())
-            res[k] = g
+            g = torch.empty(ws * bmax, *v.shape[1:], device=v.device, dtype=v.dtype)
+            dist.all_gather_into_tensor(g, pad(v))
+            res[k] = trim(g)
     return res

@@ -30,7 +30,34 @@ _SAFE_GLOBALS = {
     ("argparse", "Namespace"): argparse.Namespace,
     ("_codecs", "encode"): __import__("_codecs").encode,
 }
-_SAFE_MODULE_PREFIXES = ("torch", "numpy")      # tensor / storage / ndarray reconstruction helpers live here
+# Tensor / storage / ndarray reconstruction helpers: an explicit (module, name) list.  (a `torch.*` / `numpy.*` PREFIX rule lets protocol-4
+# dotted names through -- ("torch.serialization", "os.system") resolved to os.system -- and exposes torch.hub.load, numpy.testing runstring, ...)
+_TORCH_STORAGES = ("FloatStorage", "HalfStorage", "BFloat16Storage", "DoubleStorage", "LongStorage", "IntStorage", "ShortStorage", "CharStorage",
+                   "ByteStorage", "BoolStorage", "ComplexFloatStorage", "ComplexDoubleStorage")
+_SAFE_HELPERS = {
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._utils", "_rebuild_device_tensor_from_numpy"),
+    ("torch._tensor", "_rebuild_from_type_v2"), ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
+    ("torch.nn.parameter", "Parameter"), ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "scalar"), ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.numeric", "_frombuffer"),
+    ("numpy._core.numeric", "_frombuffer"),
+} | {("torch", n) for n in _TORCH_STORAGES}
+
+
+def _safe_helper(module: str, name: str):
+    """The real object for an allow-listed reconstruction helper, else None.  `torch.<dtype>` globals (torch.float32, ...) are allowed by TYPE."""
+    if "." in name:
+        return None
+    import importlib
+    if (module, name) in _SAFE_HELPERS:
+        try:
+            return getattr(importlib.import_module(module), name)
+        except (ImportError, AttributeError):
+            return None
+    if module == "torch" and isinstance(getattr(torch, name, None), torch.dtype):
+        return getattr(torch, name)
+    return None
 
 
 class StubObject:
@@ -69,8 +96,12 @@ def _stub_class(module: str, name: str):
 
 
 class RestrictedUnpickler(pickle.Unpickler):
-    """find_class: allow-listed globals are real, `torch.*` / `numpy.*` helpers are imported, everything else is a stub class."""
-    stubbed = None          # set of "module.name" seen (per load), for logging / tests
+    """find_class: allow-listed globals and the explicit list of tensor / ndarray reconstruction helpers are real, everything else is a stub class.
+    `self.stubbed`: the "module.name" globals this load replaced by stubs (per instance: concurrent / nested loads do not share it)."""
+
+    def __init__(self, *args, stubbed=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.stubbed = stubbed if stubbed is not None else set()
 
     def find_class(self, module, name):
         if (module, name) in _SAFE_GLOBALS:
@@ -83,37 +114,40 @@ class RestrictedUnpickler(pickle.Unpickler):
         if (module, name) in (("speechclip_amd.module.hubert", "HubertConfig"), ("speechclip_amd.module.clip_model", "ClipConfig")):
             import importlib                      # this package's own plain dataclasses (test-size architectures stored in a config)
             return getattr(importlib.import_module(module), name)
-        root = module.split(".")[0]
-        if root in _SAFE_MODULE_PREFIXES:
-            return super().find_class(module, name)
-        if RestrictedUnpickler.stubbed is not None:
-            RestrictedUnpickler.stubbed.add(f"{module}.{name}")
-        return _stub_class(module, name)
+        helper = _safe_helper(module, name)
+        if helper is not None:
+            return helper
+        self.stubbed.add(f"{module}.{name}")
+        return _stub_class(module, name.replace(".", "_"))
 
 
-class _RestrictedPickleModule:
-    """The `pickle_module` torch.load expects: `Unpickler`, `load`, and a name."""
-    __name__ = "speechclip_amd.util.checkpoint_io.restricted_pickle"
-    Unpickler = RestrictedUnpickler
-    UnpicklingError = pickle.UnpicklingError
+def _restricted_pickle_module(stubbed: set):
+    """The `pickle_module` torch.load expects (`Unpickler`, `load`, `loads`, a name), bound to ONE load's stub log."""
+    class _Unpickler(RestrictedUnpickler):
+        def __init__(self, *args, **kwargs):
+            super().__init__(*args, stubbed=stubbed, **kwargs)
 
-    @staticmethod
-    def load(f, **kwargs):
-        return RestrictedUnpickler(f, **kwargs).load()
+    class _Module:
+        __name__ = "speechclip_amd.util.checkpoint_io.restricted_pickle"
+        Unpickler = _Unpickler
+        UnpicklingError = pickle.UnpicklingError
 
-    @staticmethod
-    def loads(b, **kwargs):
-        return RestrictedUnpickler(io.BytesIO(b), **kwargs).load()
+        @staticmethod
+        def load(f, **kwargs):
+            return _Unpickler(f, **kwargs).load()
+
+        @staticmethod
+        def loads(b, **kwargs):
+            return _Unpickler(io.BytesIO(b), **kwargs).load()
+
+    return _Module
 
 
 def load_pickled_checkpoint(path: str, map_location="cpu") -> Tuple[dict, set]:
     """torch.load through the restricted unpickler.  -> (checkpoint dict, set of "module.name" globals that were replaced by stubs)."""
-    RestrictedUnpickler.stubbed = set()
-    try:
-        ckpt = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_RestrictedPickleModule)
-        return ckpt, set(RestrictedUnpickler.stubbed)
-    finally:
-        RestrictedUnpickler.stubbed = None
+    stubbed: set = set()
+    ckpt = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_restricted_pickle_module(stubbed))
+    return ckpt, stubbed
 
 
 # ------------------------------------------------------------------------------------------------ fairseq HuBERT
@@ -243,9 +277,14 @@ CLIP_NON_WEIGHT_KEYS = ("input_resolution", "context_length", "vocab_size")     
 def load_clip_state_dict(path: str) -> Dict[str, torch.Tensor]:
     """openai's released files are TorchScript archives: read through torch.jit.load (no `clip` package); a plain state_dict file (what
     `clip.load(jit=False)` users save) is accepted too.  fp16 weights are cast to fp32 as `clip.load(name, "cpu")` does (clip/clip.py: model.float())."""
-    try:
-        sd = torch.jit.load(path, map_location="cpu").state_dict()
-    except RuntimeError:
+    import zipfile
+    is_script = False
+    if zipfile.is_zipfile(path):
+        with zipfile.ZipFile(path) as z:
+            is_script = any(n.endswith("constants.pkl") for n in z.namelist())      # TorchScript archives carry constants.pkl; torch.save zips do not
+    if is_script:
+        sd = torch.jit.load(path, map_location="cpu").state_dict()               # a truncated / corrupt archive raises HERE, with its own message
+    else:
         obj = torch.load(path, map_location="cpu", weights_only=True)
         sd = obj.get("state_dict", obj) if isinstance(obj, dict) else obj
     return {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in sd.items()}

@@ -380,7 +380,7 @@ def test_train_gather_is_one_collective_and_validation_outputs_are_gathered_gloo
     for rank, n_train, ok_grad, n_val, go, loc, out in res:
         assert n_train == 1, n_train                       # one collective for ids + every feature
         assert ok_grad
-        assert n_val == 2, n_val                           # packed floats+ids, and the one integer tensor (gold_text)
+        assert n_val == 3, n_val                           # the local row counts, packed floats+ids, and the one integer tensor (gold_text)
         assert go["note"] == "x"
     for k in ("id", "audio_feat", "image_feat", "keywords", "gold_text", "row_score"):
         want = np.concatenate([res[0][5][k], res[1][5][k]], 0)
@@ -390,6 +390,42 @@ def test_train_gather_is_one_collective_and_validation_outputs_are_gathered_gloo
         assert np.array_equal(r[4]["scalar_like"], r[5]["scalar_like"])      # passed through, not gathered
     for k in ("id", "image_feat", "parallel_audio_feat", "cascaded_audio_feat"):
         assert np.array_equal(res[0][6][k], res[1][6][k])
+
+
+def _ragged_gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from speechclip_amd import parallel
+    g = torch.Generator().manual_seed(11 + rank)
+    B = 3 if rank == 0 else 2                                # DataParallel's scatter of a 5-row last batch over 2 replicas: 3 + 2
+    others = {"id": torch.arange(B) + 10 * rank + 2 ** 33, "audio_feat": torch.randn(B, 6, generator=g), "image_feat": torch.randn(B, 6, generator=g),
+              "keywords": torch.randn(B, 2, 3, generator=g), "gold_text": torch.arange(B * 4).view(B, 1, 4) + 100 * rank, "row_score": torch.randn(B, generator=g)}
+    go = parallel.gather_rows_dict(others)
+    q.put((rank, {k: v.numpy().copy() for k, v in go.items()}, {k: v.numpy().copy() for k, v in others.items()}))
+    dist.destroy_process_group()
+
+
+def test_validation_gather_accepts_a_ragged_last_batch_gloo_world2():
+    """the reference's DataParallel scatter accepts a last validation batch that does not divide by the replica count
+    (kwClip.py:193-269); gather_rows_dict used to raise.  Ranks with 3 and 2 rows: every rank ends up with the 5 rows in rank-major order, pad rows gone,
+    ids bit-exact beyond 2^32."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for k in ("id", "audio_feat", "image_feat", "keywords", "gold_text", "row_score"):
+        want = np.concatenate([res[0][2][k], res[1][2][k]], 0)
+        assert want.shape[0] == 5
+        for r in res:
+            assert r[1][k].dtype == want.dtype and np.array_equal(r[1][k], want), k
 
 
 def _step_end_worker(rank, world, port, q, train):
@@ -897,3 +933,54 @@ def test_product_library_links_no_vendor_blas():
     assert "blas" not in out and "miopen" not in out, out
     syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "hipblas" not in syms.lower()
+
+
+def test_restricted_unpickler_runs_no_foreign_code(tmp_path):
+    """the unpickler used to pass every `torch.*` / `numpy.*` global to pickle's own find_class, which resolves protocol-4 DOTTED
+    names through module attributes -- ("torch.serialization", "os.system") executed os.system.  Now only an explicit list of reconstruction helpers is
+    real; gadgets become inert stubs (calling a stub returns a stub), and ordinary tensor / ndarray payloads still load bit-exact."""
+    import io
+    import pickle
+    import numpy as np
+    from speechclip_amd.util.checkpoint_io import RestrictedUnpickler, StubObject, load_pickled_checkpoint
+    marker = tmp_path / "pwned"
+    gadgets = [
+        b"\x80\x04\x8c\x13torch.serialization\x8c\x09os.system\x93\x8c" + bytes([len(f"touch {marker}")]) + f"touch {marker}".encode() + b"\x85R.",
+        pickle.dumps(("x",), protocol=2).replace(b"\x80\x02", b"\x80\x02", 1),      # harmless control
+    ]
+    u = RestrictedUnpickler(io.BytesIO(gadgets[0]))
+    out = u.load()
+    assert isinstance(out, StubObject) and not marker.exists() and "torch.serialization.os.system" in u.stubbed
+    for mod, name in (("torch.hub", "load"), ("numpy.testing._private.utils", "runstring"), ("torch.utils.cpp_extension", "load_inline"),
+                      ("torch", "load"), ("numpy", "load"), ("os", "system"), ("builtins", "eval"), ("builtins", "exec"), ("torch._utils", "os.system")):
+        cls = RestrictedUnpickler(io.BytesIO(b"")).find_class(mod, name)
+        assert isinstance(cls, type) and issubclass(cls, StubObject), (mod, name, cls)
+    # per-instance stub logs (two loaders do not share state)
+    a, b = RestrictedUnpickler(io.BytesIO(b"")), RestrictedUnpickler(io.BytesIO(b""))
+    a.find_class("foo.bar", "Baz")
+    assert a.stubbed == {"foo.bar.Baz"} and b.stubbed == set()
+    # ordinary payloads are untouched
+    t = {"w": torch.arange(12, dtype=torch.float32).reshape(3, 4), "h": torch.ones(5, dtype=torch.bfloat16), "n": np.arange(6, dtype=np.int64).reshape(2, 3),
+         "s": np.float32(2.5), "p": torch.nn.Parameter(torch.zeros(2))}
+    f = tmp_path / "plain.pt"
+    torch.save(t, f)
+    ck, stubbed = load_pickled_checkpoint(str(f))
+    assert not stubbed and torch.equal(ck["w"], t["w"]) and torch.equal(ck["h"], t["h"]) and (ck["n"] == t["n"]).all() and float(ck["s"]) == 2.5
+    assert isinstance(ck["p"], torch.nn.Parameter)
+
+
+def test_clip_loader_does_not_mask_a_corrupt_torchscript_archive(tmp_path):
+    """a truncated TorchScript archive must surface its own error instead of falling through to torch.load(weights_only=True)."""
+    import zipfile
+    from speechclip_amd.util.checkpoint_io import load_clip_state_dict
+    bad = tmp_path / "ViT-bad.pt"
+    with zipfile.ZipFile(bad, "w") as z:
+        z.writestr("archive/constants.pkl", b"\x80\x02).")
+        z.writestr("archive/version", b"3\n")
+    with pytest.raises(Exception) as ei:
+        load_clip_state_dict(str(bad))
+    assert "weights_only" not in str(ei.value).lower()
+    good = tmp_path / "plain_sd.pt"
+    torch.save({"state_dict": {"a": torch.ones(2, dtype=torch.float16)}}, good)
+    sd = load_clip_state_dict(str(good))
+    assert sd["a"].dtype == torch.float32
