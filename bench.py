@@ -345,7 +345,7 @@ def dry_run(args, world, rank):
         if args.global_batch % world:
             sys.exit(f"bench.py: --global-batch {args.global_batch} is not divisible by {world} ranks")
         args.batch = args.global_batch // world
-    B, E = args.batch or 8, 512
+    B, E = args.batch or 8, (768 if args.model == "large" else 512)      # embedding width of the CLIP tower (ViT-L/14: 768)
     g = torch.Generator().manual_seed(7122 + rank)
 
     def step():
@@ -376,7 +376,8 @@ def dry_run(args, world, rank):
                           "scaling": "strong" if args.global_batch is not None else "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "dry-run: launcher + exchange protocol on CPU/gloo, no kernels, not a measurement",
                           "config": {"workload": "dry run", "pairs_per_gpu": B, "global_batch": int(bg), "parallelism": f"dp{world}"},
-                          "ranks_seen": int(seen.item()), "loss": round(float(loss), 5), "roofline": None, "cpu_baseline": None}), flush=True)
+                          "ranks_seen": int(seen.item()), "backend": str(dist.get_backend()) if world > 1 else "none", "model": args.model,
+                          "loss": round(float(loss), 5), "roofline": None, "cpu_baseline": None}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -482,6 +483,18 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)      # "nccl" = RCCL on ROCm: xGMI between the GPUs of the node
+    backend_name, devices_seen = "none", 1
+    if world > 1:
+        backend_name = str(dist.get_backend())
+        # First-contact check for the 8-GPU node: every rank must sit on its OWN physical GPU.  A launcher that hands each rank
+        # HIP_VISIBLE_DEVICES=<one id> collapses LOCAL_RANK -> cuda:0 legitimately; ranks that share a PCI bus id do not.  (--share-gpu is the
+        # explicit single-GPU test hook and says so in `data`.)
+        bus = torch.cuda.get_device_properties(dev).pci_bus_id if hasattr(torch.cuda.get_device_properties(dev), "pci_bus_id") else local_rank
+        ids = [None] * world
+        dist.all_gather_object(ids, (int(torch.cuda.current_device()), str(bus), os.environ.get("HIP_VISIBLE_DEVICES", "")))
+        devices_seen = len({b for _, b, _ in ids})
+        if not args.share_gpu and devices_seen != world:
+            sys.exit(f"bench.py: {world} ranks but only {devices_seen} distinct GPU(s) behind them {ids}: check HIP_VISIBLE_DEVICES / LOCAL_RANK")
 
     from speechclip_amd import ops, parallel
     large = args.model == "large"
@@ -817,7 +830,8 @@ def main():
                           "algorithmic_gflop_per_pair": round(total_gf, 2), "mode": mode_str},
                "e2e_tflops_per_gpu": round(total_gf * 1e9 * pairs_per_s / world / 1e12, 1),
                "e2e_frac_of_bf16_peak": round(total_gf * 1e9 * pairs_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
-               "rccl_ranks_seen": int(seen.item()), "exchange_ms_per_step": exchange_ms, "exchange_in_step_ms": exchange_in_step_ms,
+               "ranks_seen": int(seen.item()), "backend": backend_name, "rccl_ranks_seen": int(seen.item()) if backend_name == "nccl" else 0,
+               "devices_seen": devices_seen, "exchange_ms_per_step": exchange_ms, "exchange_in_step_ms": exchange_in_step_ms,
                "exchange": ("one packed all_gather_into_tensor over RCCL per step (speechclip_amd/parallel.py); exchange_ms_per_step = pack + collective + unpack, "
                             "timed beside the step with random payloads; exchange_in_step_ms = the same three operations timed by HIP events INSIDE the instrumented "
                             "steps (includes waiting for the slowest rank's towers); both max over ranks") if world > 1 else None,

@@ -778,6 +778,10 @@ def test_bench_gpus2_self_launches_and_runs_under_torchrun_dry_run():
     # strong scaling: the GLOBAL batch is fixed and split over the ranks
     d = _bench_line([sys.executable, bench, "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0", "--global-batch", "12"])
     assert d["scaling"] == "strong" and d["config"]["global_batch"] == 12 and d["config"]["pairs_per_gpu"] == 6 and d["n_gpus"] == 2
+    # BASELINE.json configs[4]: Parallel SpeechCLIP large on 4 ranks, global batch 256 -> 64 pairs per rank, E = 768
+    d = _bench_line([sys.executable, bench, "--gpus", "4", "--dry-run", "--steps", "2", "--warmup", "0", "--model", "large", "--global-batch", "256"])
+    assert d["n_gpus"] == 4 and d["ranks_seen"] == 4 and d["backend"] == "gloo" and d["model"] == "large"
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 256 and d["config"]["pairs_per_gpu"] == 64
     # a launcher that started the wrong number of ranks is reported, not asserted on
     import subprocess
     r = subprocess.run([sys.executable, bench, "--gpus", "4", "--dry-run"], capture_output=True, text=True, cwd=root,
