@@ -35,7 +35,7 @@ def test_bench_json_contract_forward():
     assert r["vendor_plain_gemms"]["launches_per_step"] == 0         # every GEMM of the headline step is the hand-written kernel
     v = d["vendor_comparator"]
     assert v["value"] > 0 and v["unit"] == "pairs/s" and v["ms_per_step"] > 0
-    assert d["rccl_ranks_seen"] == 1 and d["exchange_ms_per_step"] is None
+    assert d["ranks_seen"] == 1 and d["backend"] == "none" and d["rccl_ranks_seen"] == 0 and d["exchange_ms_per_step"] is None
     k = d["clock"]                  # rocm-smi reading beside the timed region (None only where rocm-smi cannot read the device)
     assert k is None or (500 < k["sclk_mhz_under_load"] <= 2500 and k["socket_power_w"] > 100 and
                          abs(k["mfma_peak_at_this_clock_tflops"] - 2500.0 * k["sclk_mhz_under_load"] / 2400) < 0.1)
@@ -74,11 +74,11 @@ def test_bench_two_ranks_on_one_gpu_exercises_the_multi_rank_path():
     """`bench.py --gpus 2` self-launches two ranks; with the --share-gpu test hook both run the REAL kernels on cuda:0 and exchange over
     gloo, so the N > 1 branch (packed gather, loss on the global batch, exchange timing, max-over-ranks, rank-0 line) runs on hardware
     before the driver's multi-GPU node does it over RCCL."""
-    d = _run("--gpus", "2", "--share-gpu", "--cpu-pairs", "0", "--no-vendor-comparator")
-    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    d = _run("--gpus", "2", "--share-gpu", "--graph", "on", "--cpu-pairs", "0", "--no-vendor-comparator")
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["rccl_ranks_seen"] == 0 and d["devices_seen"] == 1 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert d["exchange_ms_per_step"] > 0 and d["value"] > 0 and "share-gpu" in d["data"]
     assert abs(d["loss"] - 2.77) < 0.3                                  # ~ ln(16): the loss saw the GLOBAL batch of 16 pairs
-    # N > 1: the local part of the step replays from a captured HIP graph on the non-instrumented steps
+    # --graph on: the local part of the step replays from a captured HIP graph on the non-instrumented steps (the default is eager at every N)
     assert d["step_launch"]["method"].startswith("hip graph"), d["step_launch"]
 
 
@@ -86,9 +86,10 @@ def test_bench_eight_ranks_on_one_gpu_weak_and_strong():
     """BASELINE.json configs[3] launch shape on the one GPU this box has: `--gpus 8 --share-gpu` runs EIGHT ranks with the real
     kernels (each its own process, HIP graph replay, packed gather over gloo, loss on the global batch, max-over-ranks timing, one rank-0 line) --
     weak scaling (fixed pairs per rank) and strong scaling (`--global-batch`, split over the ranks)."""
-    d = _run("--gpus", "8", "--share-gpu", "--cpu-pairs", "0", "--no-vendor-comparator", "--no-clock-probe", steps=4)
-    assert d["n_gpus"] == 8 and d["rccl_ranks_seen"] == 8 and d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp8" and d["scaling"] == "weak"
+    d = _run("--gpus", "8", "--share-gpu", "--graph", "on", "--cpu-pairs", "0", "--no-vendor-comparator", "--no-clock-probe", steps=4)
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["backend"] == "gloo" and d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp8" and d["scaling"] == "weak"
     assert abs(d["loss"] - 4.16) < 0.3                                  # ~ ln(64): the loss saw all 64 pairs
     assert d["step_launch"]["method"].startswith("hip graph") and d["step_launch"]["host_launch_ms_per_step"]["graph"] > 0
     s = _run("--gpus", "8", "--share-gpu", "--cpu-pairs", "0", "--no-vendor-comparator", "--no-clock-probe", "--global-batch", "64")
-    assert s["scaling"] == "strong" and s["config"]["pairs_per_gpu"] == 8 and s["config"]["global_batch"] == 64 and s["rccl_ranks_seen"] == 8
+    assert s["scaling"] == "strong" and s["config"]["pairs_per_gpu"] == 8 and s["config"]["global_batch"] == 64 and s["ranks_seen"] == 8
+    assert s["step_launch"]["method"].startswith("eager")
