@@ -21,6 +21,12 @@
 #ifndef SC_PROBES
 #define SC_PROBES 0
 #endif
+#ifndef SC_8P_RES_LATE        // 1: residual variants issue the next tile's k-step-1 refill from the epilogue, behind the first residual loads (A/B: in-step -2 %)
+#define SC_8P_RES_LATE 0
+#endif
+#ifndef SC_8P_ABL             // timing ablations of the persistent kernel (garbage results): 1 no fragment reads, 2 no LDS-DMA, 3 no MFMA, 4 no barrier after the MFMA cluster
+#define SC_8P_ABL 0
+#endif
 #ifndef SC_8P_PRIO
 #define SC_8P_PRIO 1
 #endif
@@ -278,12 +284,14 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
     const int64_t lane_w = (int64_t)(wave * 8 + lr) * p.ldw + ((lc ^ lr) << 3);
     const int64_t lda64 = 64 * p.lda, ldw64 = 64 * p.ldw;
     auto stage_a = [&](const bf16_t* ta, int h, int k0, char* buf) {      // k0: element offset of the k-chunk
+        if (SC_8P_ABL == 2) return;
         const bf16_t* src = ta + (int64_t)h * 128 * p.lda + k0 + lane_a;
         char* dst = buf + h * HT + wave * 1024;
         glds16(src, dst);
         glds16(src + lda64, dst + 8192);
     };
     auto stage_b = [&](const bf16_t* tw, int h, int k0, char* buf) {
+        if (SC_8P_ABL == 2) return;
         const bf16_t* src = tw + (int64_t)h * 128 * p.ldw + k0 + lane_w;
         char* dst = buf + (2 + h) * HT + wave * 1024;
         glds16(src, dst);
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
     const int64_t cstep = 16 * p.ldc, rstep = 16 * p.ldr;
 
     auto read_a = [&](const char* buf, int a) {
+        if (SC_8P_ABL == 1) { for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(af[i][0])); asm volatile("" : "+v"(af[i][1])); } return; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             af[i][0] = *(const bf16x8_t*)(buf + a_base + (a * 64 + i * 16) * 128 + off_h0);
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
         }
     };
     auto read_b = [&](const char* buf, int b) {
+        if (SC_8P_ABL == 1) { for (int j = 0; j < 2; ++j) { asm volatile("" : "+v"(bf_[b][j][0])); asm volatile("" : "+v"(bf_[b][j][1])); } return; }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             bf_[b][j][0] = *(const bf16x8_t*)(buf + b_base + (b * 32 + j * 16) * 128 + off_h0);
@@ -358,8 +368,10 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[a * 4 + i][b * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[b][j][h], af[i][h], acc[a * 4 + i][b * 2 + j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    if (SC_8P_ABL != 3) acc[a * 4 + i][b * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[b][j][h], af[i][h], acc[a * 4 + i][b * 2 + j], 0, 0, 0);
+                    else asm volatile("" : "+v"(acc[a * 4 + i][b * 2 + j]) : "v"(bf_[b][j][h]), "v"(af[i][h]));
+                }
         if (SC_8P_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto init_q = [&](auto atag, auto btag) {
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
     };
     auto mat_end = [&]() {
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (SC_8P_ABL != 4) __builtin_amdgcn_s_barrier();      // ABL 4 (timing probe, racy): one barrier per phase only
         asm volatile("" ::: "memory");
     };
     using I0 = std::integral_constant<int, 0>;
@@ -406,10 +418,17 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
             // W halves are free after phase 1 (every wave holds its W fragments in registers), its A halves after phase 2.  Everything is requested a
             // full k-step before its first reader, and -- tile boundary -- the next tile's first TWO k-steps are requested before the epilogue's
             // stores enter the queue, so they do not wait behind them (in-order retirement).
-            const bool s_ok = kt + 2 < nk || have_next;
+            // Residual variants, last k-step of a tile: the refill (the next tile's k-step 1) is issued from the EPILOGUE instead, behind its first residual
+            // loads -- vector-memory results return in order, so residual loads queued behind 8 freshly issued DMA pieces (first-touch A lines from HBM)
+            // cannot be consumed before those have landed, and the epilogue opens with the matrix pipe idle for that long (SC_8P_RES_LATE=0: old order).
+            const bool late = RES && SC_8P_RES_LATE && kt == nk - 1;
+            const bool s_ok = (kt + 2 < nk || have_next) && !late;
             const bf16_t* sa = kt + 2 < nk ? ta : ta_n;
             const bf16_t* sb = kt + 2 < nk ? tw : tw_n;
             const int s_k = kt + 2 < nk ? kofs(kt + 2, rot) : kofs(kt + 2 - nk, rot_n);
+            // (A "balanced" fragment-read schedule -- quadrant order (a0,b0) (a0,b1) (a1,b0) (a1,b1), the next k-step's b0 read in phase 3's memory interval, the
+            //  k-half-1 fragments of a0 requested at the head of phase 0's cluster: 4 / 4 / 8 / 4 reads per memory interval instead of 12 / 4 / 8 / 0 -- measured
+            //  3 % SLOWER on every shape (fc2 1235 vs 1270, conv1 1125 vs 1158 TF/s, same box), round 5.  EXPERIMENTS.md.)
             // ---- phase 0: quadrant (a0, b0)
             if (first) init_q(I0{}, I0{});
             read_a(bx, 0); read_b(bx, 0);
@@ -459,6 +478,10 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
                 for (int jp = 0; jp < 2; ++jp) res[i & 3][jp] = *(const uint4*)(rptr + i * rstep + jp * 32);
             };
             if (RES) { load_res(0); load_res(1); load_res(2); load_res(3); }
+            if (RES && SC_8P_RES_LATE && have_next) {      // the refill the last k-step left out (bx / by are swapped by now: `by` held k-step nk - 1)
+                const int k1 = kofs(1, rot_n);
+                stage_b(tw_n, 0, k1, by); stage_b(tw_n, 1, k1, by); stage_a(ta_n, 0, k1, by); stage_a(ta_n, 1, k1, by);
+            }
             auto shuffled = [&](int i, uint4 (&o)[2]) {
                 uint2 pk[4];
                 if (ACT == SC_ACT_GELU) {          // all 8 value pairs of the row block side by side: gelu_poly2_x8 (common.h)

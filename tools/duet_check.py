@@ -105,7 +105,8 @@ def timeit(sustain, modes, only):
         row = {}
         for rnd in range(3):          # interleaved rounds
             for mode in modes:
-                lib().sc_debug_set_gemm_duet(mode)
+                ops.set_vendor_gemm(mode == 99)            # mode 99: the hipBLASLt comparator (plain shapes only)
+                lib().sc_debug_set_gemm_duet(mode if mode != 99 else -1)
                 run(5)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); run(30); e1.record()
@@ -116,6 +117,7 @@ def timeit(sustain, modes, only):
         print(f"{name:8s} " + "  ".join(f"mode{m}: {v}" for m, v in row.items()), flush=True)
         del a, w, out, resid
     lib().sc_debug_set_gemm_duet(-1)
+    ops.set_vendor_gemm(False)
     print(json.dumps(res))
 
 
