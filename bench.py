@@ -8,7 +8,7 @@ forward of both towers + head + L2 norms + (N > 1: RCCL all-gather of the embedd
 N > 1: one process per GPU, weak scaling (256 pairs per GPU), value = all pairs / max-over-ranks time.  `python bench.py --gpus N` works
 both under an external `python -m torch.distributed.run ...` (RANK / WORLD_SIZE in the environment) and on its own: with --gpus N > 1 and
 no WORLD_SIZE it re-executes itself under torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous) and rank 0 prints the line.
-Every GEMM of the step runs on the hand-written gemm256_kernel; hipBLASLt on the plain shapes is measured BESIDE the headline as
+Every GEMM of the step runs on the hand-written kernels (gemm8p_pers_kernel for the large bf16-output shapes, gemm256_kernel / gemm_bf16_kernel for the rest); hipBLASLt on the plain shapes is measured BESIDE the headline as
 `vendor_comparator` (never part of `value`).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
@@ -748,7 +748,7 @@ def main():
                 from speechclip_amd import _lib as _l
                 sha = hashlib.sha256(open(_l.LIB_PATH, "rb").read()).hexdigest()[:16]
                 same = tj.get("lib_sha16") == sha
-                tsrc = (tj["source"] + " (%s; separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; main-stream gemm256_kernel + gemm_bf16_kernel launches of the "
+                tsrc = (tj["source"] + " (%s; separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; main-stream sc_gemm_bf16 launches (gemm8p_pers_kernel, gemm256_kernel, gemm_bf16_kernel) of the "
                         "same command; NOT measured in this run -- PMC counters need rocprofv3; collected on library %s, this run's library is %s: %s)"
                         % (os.path.basename(tfs[-1]), tj.get("lib_sha16", "unstamped"), sha, "the same build" if same else "a DIFFERENT build"))
             # the entry serves two kernels (vendor_gemm.hip): the hand-written gemm256_kernel family (everything fused / overlapping rows /
@@ -787,7 +787,7 @@ def main():
                                          "batch": (e[3][7] if len(e[3]) > 7 else 1), "tower": e[5]} for e in prof[:per]]},
                           open(args.dump_gemm_launches, "w"), indent=0)
             hw = part["hand_written"]
-            roof = {"bound": "mfma", "kernel": "gemm256_kernel family (hand-written HIP: fused-GELU / QuickGELU epilogues, conv-as-GEMM with overlapping rows, small shapes)",
+            roof = {"bound": "mfma", "kernel": "sc_gemm_bf16 family, hand-written HIP: gemm8p_pers_kernel (ping-pong schedule; the 95 % of the flops in bf16-output shapes with N % 256 == 0: fused-GELU / residual epilogues, conv-as-GEMM with overlapping rows) + gemm256_kernel / gemm_bf16_kernel (fp32 outputs, small shapes)",
                     "achieved": hw["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(hw["achieved"] / PEAK_BF16_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": tsrc, "traffic_launches_per_step": traffic_launches, "launches_per_step": hw["launches_per_step"], "avg_launch_ms": hw["avg_launch_ms"],
                     "ms_per_step": hw["ms_per_step"],

@@ -10,6 +10,19 @@ usage: python tools/make_traffic_json.py <pmc_FETCH_SIZE dir> <pmc_WRITE_SIZE di
 import collections, csv, glob, json, os, sys
 
 
+GEMM_KERNELS = ("gemm256_kernel", "gemm_bf16_kernel", "gemm8p_pers_kernel", "gemm8p_kernel")      # every kernel behind sc_gemm_bf16 (round 5: + gemm8p)
+
+
+def act_of(k):
+    """Activation template argument of a GEMM kernel name: gemm256_kernel<ABL, TRACE, ACT, ..> / gemm8p_pers_kernel<ACT, RES>; None for gemm_bf16_kernel."""
+    args = [a.strip() for a in k.split("<")[1].rstrip(">").split(",")] if "<" in k else []
+    if k.startswith("gemm256_kernel"):
+        return args[2]
+    if k.startswith("gemm8p"):
+        return args[0]
+    return None
+
+
 def load(d):
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     agg, cnt = collections.defaultdict(float), collections.Counter()
@@ -26,7 +39,7 @@ def load_rows(d):
     rows = []
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-        if k.startswith(("gemm256_kernel", "gemm_bf16_kernel")):
+        if k.startswith(GEMM_KERNELS):
             rows.append((int(r["Dispatch_Id"]), k, float(r["Counter_Value"]) * 1024.0))
     rows.sort()
     return [(k, v) for _, k, v in rows]
@@ -40,8 +53,8 @@ def aligned(fd, wd, steps, launch_json):
     fr, wr = load_rows(fd), load_rows(wd)
     assert len(fr) == len(wr) == steps * len(per), (len(fr), len(wr), steps, len(per))
     for i, (k, _) in enumerate(fr):          # soft consistency check: the QuickGELU template variant is the image tower's fc1
-        quick = k.startswith("gemm256_kernel") and k.split("<")[1].split(",")[2].strip() == "2"
-        assert quick == (per[i % len(per)]["act"] == 2 and per[i % len(per)]["M"] >= 256 and k.startswith("gemm256")) or not k.startswith("gemm256"), (i, k, per[i % len(per)])
+        quick = act_of(k) == "2"
+        assert act_of(k) is None or quick == (per[i % len(per)]["act"] == 2), (i, k, per[i % len(per)])
     return [(per[i % len(per)]["tower"], 2 * fr[i][1], wr[i][1]) for i in range(len(fr))], per
 
 
@@ -62,8 +75,8 @@ def main():
         ks = [k for k in fetch if pred(k)]
         return {"kernels": sorted(ks), "launches_per_step": sum(fc[k] for k in ks) // steps,
                 "fetch_bytes_per_step": int(2 * sum(fetch[k] for k in ks) / steps), "write_bytes_per_step": int(sum(write.get(k, 0.0) for k in ks) / steps)}
-    is_gemm = lambda k: k.startswith(("gemm256_kernel", "gemm_bf16_kernel"))              # noqa: E731
-    is_vit = lambda k: k.startswith("gemm256_kernel") and k.split("<")[1].split(",")[2].strip() == "2"   # noqa: E731  QuickGELU variant: image tower only
+    is_gemm = lambda k: k.startswith(GEMM_KERNELS)              # noqa: E731
+    is_vit = lambda k: act_of(k) == "2"   # noqa: E731  QuickGELU variant: image tower only
     out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `python bench.py --steps %d --warmup 0 --cpu-pairs 0 "
                      "--no-roofline-events --no-vendor-comparator` (tools/collect_round_profiles.sh); FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950; "
                      "both counters in KiB" % steps,
