@@ -54,7 +54,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // Timing probes (SC_GEMM_ABL ablations, the per-phase s_memtime trace, the 2-slot-ring A/B switch) are compiled only into the PROBES build
 // (`make PROBES=1` -> libspeechclip_hip_probes.so, -DSC_PROBES=1); the product library instantiates the kernel without them.  The operand
 // cache-policy (nt / sc bits on the LDS-DMA pieces), buffer-form DMA, wave-priority and DMA-placement variants measured in rounds 1-2 are
-// recorded in DESIGN.md section 3.1 with their numbers and no longer live in this file.
+// recorded in EXPERIMENTS.md (rounds 1-4, old section 3.1) with their numbers and no longer live in this file.
 #ifndef SC_PROBES
 #define SC_PROBES 0
 #endif
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                             else piece_w(i - 4, dk, dma_slot + 256 * 128 + ((i - 4) * 512 + wave * 64) * 16);
                         } else {
                             // one piece in MFMA groups 0, 2, 4, 6 of each half-step: the 8 pieces of a k-step spread evenly over its 16 groups
-                            // (measured alternatives, DESIGN.md section 3.1: odd groups +0.17 ms per step, groups 0-3 +-0.05, groups 4-7 -5 ... 0 %)
+                            // (measured alternatives, EXPERIMENTS.md old section 3.1: odd groups +0.17 ms per step, groups 0-3 +-0.05, groups 4-7 -5 ... 0 %)
                             const bool slot_ = (i & 1) == 0; const int g_ = i >> 1;
                             if (slot_) {
                                 if (dma_k0 >= 0) piece_w(g_, dma_k0, dma_slot + (g_ * 512 + wave * 64) * 16);
@@ -1058,7 +1058,9 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         d.kpair = (g_duet_mode == 20 && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) ? (int)(lda / 2 / 64) : 0;      // tap-paired K walk: A/B (mode 20)
         d.esteps = g_duet_mode == 8 ? 8 : g_duet_mode == 17 ? 1 : 4;      // 17: gemm8p per-tile kernel
         d.trace = g_gemm_trace;
-        d.rows = g_duet_mode == 19 ? 1 : 0;      // gemm8p: K rotation per M panel (A/B: mode 19)
+        d.rows = g_duet_mode == 19 ? 1 : g_duet_mode == 24 ? 2 : g_duet_mode == 25 ? 3 : 0;      // 24 / 25: the N tiles of an M panel one / two k-steps apart
+        if (0) d.rows = 0;      // gemm8p: K rotation per M panel (A/B: mode 19)
+        d.band = g_duet_mode == 21 ? 3 : g_duet_mode == 22 ? 4 : g_duet_mode == 23 ? 6 : 0;      // column-band tile order (A/B: modes 21-23)
         const bool aligned = ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!residual || ((uintptr_t)residual & 15) == 0);
         // (wide outputs, N >= 4096: gemm256_kernel's column-band tile order keeps a W band L2-resident -- 8192^3: 1 440 vs 1 290 TF/s; gemm8p has no banding)
         const bool dflt_ok = N % 256 == 0 && N < 4096 && ((M + 255) / 256) * (int64_t)(N / 256) >= 256;

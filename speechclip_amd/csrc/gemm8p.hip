@@ -271,7 +271,22 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
     const int cnt = q8 + (xcd < r8 ? 1 : 0);
     const int my_tiles = slot_in_xcd < cnt ? (cnt - slot_in_xcd + nb_xcd - 1) / nb_xcd : 0;
     if (my_tiles == 0) return;
-    auto tile_mn = [&](int it, int& tm, int& tn) { const int v = begin + it * nb_xcd + slot_in_xcd; tm = v / tiles_n; tn = v - tm * tiles_n; };
+    // Column bands (p.band N tiles, 0 = all of N): the order walks every M panel of a band before the next band, so an XCD has only the band's slice of
+    // W (band x 256 x K) in flight: with all of N in flight (QKV 3.5 MiB, fc1 4.7 MiB of W against a 4 MiB L2) W is re-fetched once per tile round.
+    const int band = p.band;
+    auto tile_mn = [&](int it, int& tm, int& tn) {
+        int v = begin + it * nb_xcd + slot_in_xcd;
+        int nb = tiles_n, tn0 = 0;
+        if (band > 0 && band < tiles_n) {
+            const int per_band = band * tiles_m;
+            const int b = v / per_band;
+            tn0 = b * band;
+            v -= b * per_band;
+            nb = tiles_n - tn0 < band ? tiles_n - tn0 : band;
+        }
+        tm = v / nb;
+        tn = tn0 + (v - tm * nb);
+    };
 
     const int frow = lane & 15, fk = lane >> 4;
     const int off_h0 = frow * 128 + ((fk ^ (frow & 7)) << 4);
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
     tile_mn(0, tm, tn);
     const bf16_t* ta = tile_a(tm);
     const bf16_t* tw = p.W + (int64_t)tn * 256 * p.ldw;
-    int rot = p.rows ? tm % nk : 0;          // (p.rows reused as the rotation switch: 0 = off)
+    int rot = p.rows == 1 ? tm % nk : p.rows == 2 ? tn % nk : p.rows == 3 ? (2 * tn) % nk : 0;      // (p.rows reused as the rotation switch: 0 = off)
     {
         char* b0 = smem; char* b1 = smem + BUF;
         const int k0 = kofs(0, rot), k1 = kofs(1, rot);
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
         if (have_next) tile_mn(it + 1, ntm, ntn);
         const bf16_t* ta_n = tile_a(ntm);
         const bf16_t* tw_n = p.W + (int64_t)ntn * 256 * p.ldw;
-        const int rot_n = p.rows ? ntm % nk : 0;
+        const int rot_n = p.rows == 1 ? ntm % nk : p.rows == 2 ? ntn % nk : p.rows == 3 ? (2 * ntn) % nk : 0;
         // (Measured alternatives of this schedule, round 5, same box, TF/s qkv / out / fc2: this one 1128 / 1100 / 1306; TWO phases of 32 MFMAs per k-step --
         //  half as many barriers -- 1075 / 997 / 1275; ONE barrier per phase with a leader / follower order of the two groups inside the interval
         //  1100 / 1015 / 1235.  EXPERIMENTS.md.)

@@ -17,7 +17,8 @@ struct DuetParams {
     int tn;                            // N / 256: blocks per row of blocks
     int rows;                          // rows of blocks (grid / tn); blocks beyond rows * tn exit at once
     int64_t units;                     // ceil(M / 128): 128-row half panels
-    int esteps;                        // epilogue steps per half tile: 4 or 8
+    int esteps;                        // duet: epilogue steps per half tile: 4 or 8; gemm8p: 1 = the per-tile A/B kernel
+    int band;                          // gemm8p: N tiles per column band of the tile order (0: all of N)
     unsigned long long* trace;         // PROBES: per-block cycle stamps
 };
 

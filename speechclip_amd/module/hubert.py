@@ -301,7 +301,7 @@ class HubertModel(nn.Module):
         fill the 256 x 256-tile GEMM: B*Tp >= 256 and d a multiple of 256 (HuBERT-base: 768).  OPT-IN (SC_FOLD_LN=1): measured on the B = 256
         step it removes the 24 LayerNorm launches (2.1 ms at the HBM roofline, 71 us each) but pays them back in epilogue time of the
         out-proj GEMM (+34 us), statistics finalisation (2 x 8 us per layer) and a VALU-bound layer mix (+0.33 ms), and the HBM-bound
-        LayerNorm phases are where the side-stream image tower overlaps best: 46.5 ms folded vs 46.2 ms unfolded."""
+        LayerNorm phases are where the side-stream image tower overlaps best: 46.5 ms folded vs 46.2 ms unfolded (EXPERIMENTS.md, old section 7)."""
         if self.cfg.layer_norm_first or os.environ.get("SC_FOLD_LN", "0") != "1":
             return False
         d = self.cfg.encoder_embed_dim

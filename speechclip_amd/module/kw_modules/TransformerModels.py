@@ -25,10 +25,8 @@ def _frames_view(audio_feat: torch.Tensor):
     B, T, D = audio_feat.shape
     if audio_feat.stride(2) == 1 and audio_feat.stride(1) == D and audio_feat.stride(0) % D == 0 and audio_feat.dtype == BF:
         Tp = audio_feat.stride(0) // D if B > 1 else T
-        need = ((B - 1) * Tp + T) * D
         if audio_feat.untyped_storage().nbytes() // 2 - audio_feat.storage_offset() >= B * Tp * D or Tp == T:
             return torch.as_strided(audio_feat, (B * Tp, D), (D, 1)), Tp
-        del need
     x = audio_feat.to(BF).contiguous()
     return x.view(B * T, D), T
 
@@ -111,13 +109,21 @@ def _pool_operands(cls, in_w, in_b, heads):
         hd = D // heads
         c = cls.detach().reshape(NQ, D).float()
         w, b = in_w.detach().float(), in_b.detach().float()
-        q = (c @ w[:D].t() + b[:D]).view(NQ, heads, hd) * hd ** -0.5
-        u = torch.einsum("qhj,hjd->qhd", q, w[D:2 * D].view(heads, hd, D)).reshape(NQ * heads, D).contiguous()
-        beta = (q * b[D:2 * D].view(1, heads, hd)).sum(-1).reshape(NQ * heads).contiguous()
+        # the matrix products run on sc_sgemm / sc_sgemm_batched (fp32 SIMT, this library): no vendor BLAS kernel on the product path, not even in
+        # the cached parameter preprocessing (`@` / einsum on device tensors launched Tensile kernels)
+        q = ops.sgemm(c.contiguous(), w[:D].contiguous(), transb=True, bias=b[:D].contiguous(), alpha=1.0)          # [NQ, D] = c Wq^T + bq
+        q = (q * hd ** -0.5).contiguous()
+        # u[q, h, :] = q[q, h, :] . Wk_h  (Wk_h = rows [h hd, (h+1) hd) of w[D:2D]): `heads` products [NQ, hd] x [hd, D], strided views of q / Wk / u
+        wk = w[D:2 * D].contiguous()
+        u = torch.empty(NQ, heads * D, device=c.device, dtype=torch.float32)
+        ops.sgemm_batched(NQ, D, hd, q, D, hd, wk, D, hd * D, u, heads * D, D, heads)
+        u = u.view(NQ * heads, D)
+        beta = (q.view(NQ, heads, hd) * b[D:2 * D].view(1, heads, hd)).sum(-1).reshape(NQ * heads).contiguous()
         c16 = c.to(BF)
         wv16 = w[2 * D:].to(BF).contiguous()
-        ops_ = dict(u16=u.to(BF).contiguous(), beta=beta, cls16=c16.contiguous(), wv=wv16, wv3=_w3(w[2 * D:]), bv=b[2 * D:].contiguous(),
-                    cls_scores=(c16.float() @ u.to(BF).float().t() + beta).contiguous())                    # [NQ, R]
+        u16 = u.to(BF).contiguous()
+        ops_ = dict(u16=u16, beta=beta, cls16=c16.contiguous(), wv=wv16, wv3=_w3(w[2 * D:]), bv=b[2 * D:].contiguous(),
+                    cls_scores=ops.sgemm(c16.float().contiguous(), u16.float().contiguous(), transb=True, bias=beta))                    # [NQ, R]
     if len(_POOL_CACHE) > 256:
         _POOL_CACHE.clear()
     _POOL_CACHE[key] = (ver, ops_, tuple(weakref.ref(o) for o in (cls, in_w, in_b)))

@@ -103,7 +103,7 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         self.encoder.eval()
         # speech_encoder_plus.py:416-446: the listed transformer layers train (reinit_layers: re-initialised first, as `layer.apply(init_weights)` does);
         # every other layer, pos_conv, layer_norm, the feature extractor and post_extract_proj stay frozen (feature_grad_mult = 0)
-        # KNOWN DIVERGENCE (documented in DESIGN.md section 5c): the reference freezes the unlisted layers, pos_conv, the FEATURE
+        # KNOWN DIVERGENCE (documented in EXPERIMENTS.md, old section 5c): the reference freezes the unlisted layers, pos_conv, the FEATURE
         # LayerNorm (`encoder.layer_norm`), the extractor and post_extract_proj -- but not `encoder.encoder.layer_norm`, the LayerNorm behind the
         # positional conv of post-LN HuBERT-base, nor the never-reached mask_emb / final_proj / label_embs_concat.  That LayerNorm sits below
         # every layer, so the reference back-propagates through ALL frozen layers just to train its 2 x 768 numbers.  Here it stays frozen and

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_gemm_traffic${2:+_$2}
 mkdir -p $O
-SHAPES="conv1:4096000,512,1536,1024,1 conv1_n256:4096000,256,1536,1024,1 conv2:2048000,512,1536,1024,1 qkv:128000,2304,768,768,0 fc1:128000,3072,768,768,1 out:128000,768,768,768,0 fc2:128000,768,3072,3072,0"
+SHAPES=${SHAPES:-"conv1:4096000,512,1536,1024,1 conv1_n256:4096000,256,1536,1024,1 conv2:2048000,512,1536,1024,1 qkv:128000,2304,768,768,0 fc1:128000,3072,768,768,1 out:128000,768,768,768,0 fc2:128000,768,3072,3072,0"}
 SPEECHCLIP_HIP_LIB=$1 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/raw -- python $R/tools/gemm_traffic_probe.py $SHAPES > $O/run.log 2>&1
 python - "$O" <<'PY' | tee $O/summary.txt
 import glob, csv, sys
