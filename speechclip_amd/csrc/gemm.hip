@@ -1048,12 +1048,12 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         const int rc = sc_vendor_gemm_try(A, lda, W, ldw, C, ldc, bias, residual, ldr, M, N, K, (flags & SC_GEMM_OUT_F32) ? 1 : 0, (hipStream_t)stream);
         if (rc <= 0) { g_last_path = 1; return rc; }
     }
-    if (g_duet_mode != 0 && !(flags & SC_GEMM_OUT_F32) && (!g_gemm_trace || g_duet_mode > 0) && A && W && C && M > 0 && N > 0 && K > 0) {
-        // bf16-output GEMMs with N % 256 == 0: the ping-pong kernel (gemm8p.hip), persistent form, from 256 tiles up (below that one round of tiles
-        // does not fill the chip and gemm256_kernel's / gemm_bf16_kernel's smaller grids do as well)
+    if (g_duet_mode != 0 && (!g_gemm_trace || g_duet_mode > 0) && A && W && C && M > 0 && N > 0 && K > 0) {
+        // bf16-output GEMMs with N % 256 == 0: the ping-pong kernel (gemm8p.hip), persistent form, from 128 tiles up (ViT-B/32 at 256 images: 150 tiles,
+        // +5 ... +19 % over gemm256_kernel; below that the 128 x 128 kernel's finer grid wins); bf16 or fp32 output
         DuetParams d{};
-        d.A = (const bf16_t*)A; d.lda = lda; d.W = (const bf16_t*)W; d.ldw = ldw; d.C = (bf16_t*)C; d.ldc = ldc;
-        d.bias = bias; d.residual = (const bf16_t*)residual; d.ldr = ldr; d.M = M; d.N = N; d.K = K;
+        d.A = (const bf16_t*)A; d.lda = lda; d.W = (const bf16_t*)W; d.ldw = ldw; d.C = C; d.ldc = ldc; d.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0;
+        d.bias = bias; d.residual = residual; d.ldr = ldr; d.M = M; d.N = N; d.K = K;
         d.act = flags & SC_GEMM_ACT_MASK;
         d.kpair = (g_duet_mode == 20 && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) ? (int)(lda / 2 / 64) : 0;      // tap-paired K walk: A/B (mode 20)
         d.esteps = g_duet_mode == 8 ? 8 : g_duet_mode == 17 ? 1 : 4;      // 17: gemm8p per-tile kernel
@@ -1062,8 +1062,8 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         if (0) d.rows = 0;      // gemm8p: K rotation per M panel (A/B: mode 19)
         d.band = g_duet_mode == 21 ? 3 : g_duet_mode == 22 ? 4 : g_duet_mode == 23 ? 6 : 0;      // column-band tile order (A/B: modes 21-23)
         const bool aligned = ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!residual || ((uintptr_t)residual & 15) == 0);
-        // (wide outputs, N >= 4096: gemm256_kernel's column-band tile order keeps a W band L2-resident -- 8192^3: 1 440 vs 1 290 TF/s; gemm8p has no banding)
-        const bool dflt_ok = N % 256 == 0 && N < 4096 && ((M + 255) / 256) * (int64_t)(N / 256) >= 256;
+        // (wide outputs, N >= 4096 (8192^3; HuBERT-large fc1 1 095 vs 1 080): gemm256_kernel's column-band tile order keeps a W band L2-resident -- 8192^3: 1 440 vs 1 290 TF/s; gemm8p has no banding)
+        const bool dflt_ok = N % 256 == 0 && N < 4096 && ((M + 255) / 256) * (int64_t)(N / 256) >= 128;
         if (aligned && (g_duet_mode > 0 || dflt_ok)) {
             const bool duet = g_duet_mode == 4 || g_duet_mode == 8;
             const int rc = duet ? sc_gemm_duet_try(d, (hipStream_t)stream) : sc_gemm8p_try(d, (hipStream_t)stream);

@@ -192,8 +192,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(DuetParams p) {
     const int bperm = (src_fk * 16 + srow) << 2;
     const int ncol0 = n0 + w4 * 64 + schunk * 8;
     const int64_t mrow0 = m0 + g * 128 + srow;
-    bf16_t* cptr = p.C + mrow0 * p.ldc + ncol0;
-    const bf16_t* rptr = RES ? p.residual + mrow0 * p.ldr + ncol0 : nullptr;
+    bf16_t* cptr = (bf16_t*)p.C + mrow0 * p.ldc + ncol0;
+    const bf16_t* rptr = RES ? (const bf16_t*)p.residual + mrow0 * p.ldr + ncol0 : nullptr;
     const int64_t cstep = 16 * p.ldc, rstep = 16 * p.ldr;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(DuetParams p) {
 // quadrant Q_p of the next tile -- was built and measured in round 5: 3-7 % SLOWER than even the per-tile kernel on the K = 768 shapes.  The CU's
 // store path moves 24-36 B/clk; 16 KiB of stores per group and interval stretch each of the 8 intervals of that k-step far beyond the 256 cycles
 // of the MFMA cluster they were meant to hide under.  EXPERIMENTS.md, round 5.)
-template <int ACT, bool RES>
+template <int ACT, bool RES, bool F32>
 __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -485,8 +485,47 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
             const int skip = (int)(m_lo - m0) - g * 128 - srow;            // rows i * 16 + .. below this belong to the previous tile (ragged last M panel)
             const int64_t mrow0 = m0 + g * 128 + srow;
             const int ncol0 = tn * 256 + w4 * 64 + schunk * 8;
-            bf16_t* cptr = p.C + mrow0 * p.ldc + ncol0;
-            const bf16_t* rptr = RES ? p.residual + mrow0 * p.ldr + ncol0 : nullptr;
+            if (F32) {
+                // fp32 outputs (pre-LN / ViT residual streams: C and the residual are f32): lane (frow, fk) holds 4 consecutive fp32 = 16 bytes of row
+                // frow; lane L fetches (LDS crossbar) the value of lane (L >> 2) + 16 (L & 3), so that the 4 lanes of a quad own one 64-byte segment and a
+                // store instruction writes 16 rows x 64 contiguous bytes per 16-column block (the quad rule of the bf16 path).
+                const int bperm32 = (srow + 16 * schunk) << 2;
+                const int ncol32 = tn * 256 + w4 * 64 + schunk * 4;
+                float* cf = (float*)p.C + mrow0 * p.ldc + ncol32;
+                const float* rf = RES ? (const float*)p.residual + mrow0 * p.ldr + ncol32 : nullptr;
+                f32x4_t rs[RES ? 2 : 1][4];
+                auto load_rs = [&](int i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rs[i & 1][j] = *(const f32x4_t*)(rf + i * rstep + j * 16);
+                };
+                if (RES) { load_rs(0); load_rs(1); }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    f32x4_t o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4_t v4 = acc[i][j] + bias4[j];
+                        if (ACT == SC_ACT_GELU) {       // f32 output: the fp32 polynomial (the packed-half form carries ~11 bits, meant for bf16 results)
+                            const f32x2_t g0 = gelu_poly2_f32((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2_f32((f32x2_t){v4[2], v4[3]});
+                            v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+                        } else if (ACT == SC_ACT_QUICKGELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[j][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm32, __float_as_int(v4[r])));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (RES) o[j] += rs[i & 1][j];
+                        if (i * 16 >= skip) *(f32x4_t*)(cf + i * cstep + j * 16) = o[j];
+                    }
+                    if (RES && i + 2 < 8) load_rs(i + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+            bf16_t* cptr = (bf16_t*)p.C + mrow0 * p.ldc + ncol0;
+            const bf16_t* rptr = RES ? (const bf16_t*)p.residual + mrow0 * p.ldr + ncol0 : nullptr;
             uint4 res[RES ? 4 : 1][2];
             auto load_res = [&](int i) {
 #pragma unroll
@@ -549,6 +588,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
                 if (RES && i + 4 < 8) load_res(i + 4);
                 __builtin_amdgcn_sched_barrier(0);
             }
+                    }
         }
         if (tracing) { const unsigned long long c = __builtin_readcyclecounter(); tr_epi += c - tr_t; tr_t = c; }
         tm = ntm; tn = ntn; ta = ta_n; tw = tw_n; rot = rot_n;
@@ -560,15 +600,15 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
     }
 }
 
-template <int ACT, bool RES>
+template <int ACT, bool RES, bool F32>
 int launch_pers(const DuetParams& p, int grid, hipStream_t s) {
     constexpr int lds = 2 * BUF + 32768;   // 128 KiB of operands + the bias vector
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm8p_pers_kernel<ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm8p_pers_kernel<ACT, RES, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm8p_pers_kernel<ACT, RES>), dim3(grid), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((gemm8p_pers_kernel<ACT, RES, F32>), dim3(grid), dim3(512), lds, s, p);
     SC_CHECK_LAUNCH();
     return 0;
 }
@@ -594,7 +634,7 @@ int sc_gemm8p_try(const DuetParams& pin, hipStream_t s) {
     if (p.M % 256 && (p.esteps == 1 || p.N > 8192)) return 1;      // the per-tile A/B kernel takes full M panels only
     p.tn = p.N / 256; p.nk = p.K / 64;
     if (p.nk < 2) return 1;
-    if (p.ldc % 8 || (p.residual && p.ldr % 8) || p.lda % 8 || p.ldw % 8) return 1;
+    if (p.ldc % (p.out_f32 ? 4 : 8) || (p.residual && p.ldr % (p.out_f32 ? 4 : 8)) || p.lda % 8 || p.ldw % 8) return 1;
     const int64_t tiles = ((p.M + 255) / 256) * p.tn;
     if (tiles > 0x7fffffff) return 1;
     const int grid = (int)tiles;
@@ -603,12 +643,20 @@ int sc_gemm8p_try(const DuetParams& pin, hipStream_t s) {
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
         const int pg = grid < n_cu ? grid : n_cu;
+        if (p.out_f32) {
+            switch (p.act) {
+                case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false, true>(p, pg, s);
+                case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true, true>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false, true>(p, pg, s);
+                default: return res ? launch_pers<SC_ACT_NONE, true, true>(p, pg, s) : launch_pers<SC_ACT_NONE, false, true>(p, pg, s);
+            }
+        }
         switch (p.act) {
-            case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false>(p, pg, s);
-            case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false>(p, pg, s);
-            default: return res ? launch_pers<SC_ACT_NONE, true>(p, pg, s) : launch_pers<SC_ACT_NONE, false>(p, pg, s);
+            case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, false>(p, pg, s) : launch_pers<SC_ACT_GELU, false, false>(p, pg, s);
+            case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true, false>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false, false>(p, pg, s);
+            default: return res ? launch_pers<SC_ACT_NONE, true, false>(p, pg, s) : launch_pers<SC_ACT_NONE, false, false>(p, pg, s);
         }
     }
+    if (p.out_f32) return 1;
     switch (p.act) {
         case SC_ACT_GELU: return res ? launch_one<SC_ACT_GELU, true>(p, grid, s) : launch_one<SC_ACT_GELU, false>(p, grid, s);
         case SC_ACT_QUICKGELU: return res ? launch_one<SC_ACT_QUICKGELU, true>(p, grid, s) : launch_one<SC_ACT_QUICKGELU, false>(p, grid, s);

@@ -7,9 +7,10 @@
 struct DuetParams {
     const bf16_t* A; int64_t lda;
     const bf16_t* W; int64_t ldw;
-    bf16_t* C; int64_t ldc;
+    void* C; int64_t ldc;                 // bf16, or f32 when out_f32 (gemm8p only)
     const float* bias;                 // may be null
-    const bf16_t* residual; int64_t ldr;
+    const void* residual; int64_t ldr;   // same element type as C
+    int out_f32;
     int64_t M; int N; int K;
     int act;                           // SC_ACT_*
     int nk;                            // K / 64

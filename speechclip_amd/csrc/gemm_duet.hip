@@ -271,8 +271,8 @@ __global__ __launch_bounds__(512) void gemm_duet_kernel(DuetParams p) {
             if (SC_DUET_PRIO) __builtin_amdgcn_s_setprio(0);
             const int64_t u = u_begin + 2 * (int64_t)q_me + g;
             const int64_t mrow0 = u * 128 + srow;                          // M % 128 == 0 (host check): every unit is a full half panel
-            bf16_t* cptr = p.C + mrow0 * p.ldc + ncol0;
-            const bf16_t* rptr = RES ? p.residual + mrow0 * p.ldr + ncol0 : nullptr;
+            bf16_t* cptr = (bf16_t*)p.C + mrow0 * p.ldc + ncol0;
+            const bf16_t* rptr = RES ? (const bf16_t*)p.residual + mrow0 * p.ldr + ncol0 : nullptr;
             const int64_t cstep = 16 * p.ldc, rstep = 16 * p.ldr;
             // A pieces of stage t + 2 (the slot stage t - 1 left at the previous barrier)
             int n_a = 0;
@@ -430,7 +430,7 @@ int sc_gemm_duet_try(const DuetParams& pin, hipStream_t s) {
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     const int grid = n_cu & ~7;                       // blocks b, b + 8, .. share an XCD; one block per CU (160 KiB of LDS each)
     if (grid < 8) return 1;
-    if (p.N % 256 || p.K % 64 || p.M < 256 || p.M % 128) return 1;      // full 128-row half panels only: the epilogue stores unpredicated (counted vmcnt)
+    if (p.out_f32 || p.N % 256 || p.K % 64 || p.M < 256 || p.M % 128) return 1;      // full 128-row half panels only: the epilogue stores unpredicated (counted vmcnt)
     p.tn = p.N / 256; p.nk = p.K / 64;
     if (p.tn > grid || p.tn > 32 || p.nk < 8) return 1;
     if (p.ldc % 8 || (p.residual && p.ldr % 8) || p.lda % 8 || p.ldw % 8) return 1;

@@ -1,0 +1,91 @@
+"""gemm8p_pers_kernel (the ping-pong persistent GEMM, speechclip_amd/csrc/gemm8p.hip) against fp32 torch: every epilogue variant it serves --
+bf16 / fp32 output, bias, GELU / QuickGELU, bf16 / fp32 residual -- ragged M (the last panel shifted back), overlapping rows (conv as GEMM), operands
+beyond 32-bit offsets, and the dispatcher's choice.  Replaces in the reference: every nn.Linear / Conv1d of the encoders
+(avssl/module/speech_encoder_plus.py:49-56,75,84-85 -> fairseq TransformerSentenceEncoderLayer [3P]; clip ResidualAttentionBlock [3P])."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(a, w, bias, act, res):
+    y = a.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias
+    if act == 1:
+        y = torch.nn.functional.gelu(y)
+    elif act == 2:
+        y = y * torch.sigmoid(1.702 * y)
+    if res is not None:
+        y = y + res.float()
+    return y
+
+
+@pytest.fixture()
+def force_8p():
+    from speechclip_amd._lib import lib
+    lib().sc_debug_set_gemm_duet(16)
+    yield
+    lib().sc_debug_set_gemm_duet(-1)
+
+
+@pytest.mark.parametrize("M,N,K,lda", [(256 * 37, 768, 768, None), (256 * 20 + 77, 1024, 128, None), (19000, 512, 1536, 1024), (9001, 2304, 192, None)])
+@pytest.mark.parametrize("act,res,f32", [(0, False, False), (1, False, False), (0, True, False), (2, True, False), (0, True, True), (1, False, True), (2, True, True)])
+def test_gemm8p_epilogue_variants_vs_fp32(force_8p, M, N, K, lda, act, res, f32):
+    from speechclip_amd import ops
+    from speechclip_amd._lib import lib
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + act)
+    ld = lda or K
+    flat = (torch.randn(M * ld + K + 8, generator=g) * 0.5).to("cuda", torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16)
+    bias = torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).to("cuda", torch.float32 if f32 else torch.bfloat16) if res else None
+    y = ops.gemm(flat, w, bias, act, r, out_f32=f32, M=M, K=K, lda=ld)
+    assert lib().sc_gemm_last_path() == 3                      # gemm8p_pers_kernel ran (ragged M, overlapping rows and fp32 outputs included)
+    assert y.dtype == (torch.float32 if f32 else torch.bfloat16)
+    a = torch.as_strided(flat, (M, K), (ld, 1))
+    tol = 3e-3 if f32 else 2e-2
+    torch.testing.assert_close(y.float(), _ref(a, w, bias, act, r), atol=tol, rtol=tol)
+
+
+def test_gemm8p_is_transpose_detecting_and_bias_free(force_8p):
+    """Identity-like A with a non-symmetric W: a swapped fragment layout or a transposed store shows up as W instead of W^T; bias = None reads zeros."""
+    from speechclip_amd import ops
+    from speechclip_amd._lib import lib
+    M = N = K = 256 * 12
+    a = torch.eye(M, device="cuda", dtype=torch.bfloat16)
+    w = ((torch.arange(N * K, device="cuda").reshape(N, K) * 7) % 251).to(torch.bfloat16)
+    y = ops.gemm(a, w)
+    assert lib().sc_gemm_last_path() == 3
+    torch.testing.assert_close(y.float(), w.float().t())
+
+
+def test_gemm8p_is_the_default_for_the_step_shapes_and_old_kernels_keep_the_rest():
+    """Dispatcher rule (gemm.hip): bf16 / fp32 output, N % 256 == 0, N < 4096, >= 128 tiles -> gemm8p (path 3); everything else -> gemm256_kernel /
+    gemm_bf16_kernel (path 0).  Both are hand-written; path 1 (vendor library) only with the comparator switched on."""
+    from speechclip_amd import ops
+    from speechclip_amd._lib import lib
+    lib().sc_debug_set_gemm_duet(-1)
+    g = torch.Generator().manual_seed(3)
+    for (M, N, K, f32), want in (((12800, 768, 768, True), 3), ((32000, 2304, 768, False), 3), ((4096, 768, 768, False), 0), ((12800, 520, 768, False), 0),
+                                 ((8192, 4096, 512, False), 0)):
+        a = (0.5 * torch.randn(M, K, generator=g)).to("cuda", torch.bfloat16)
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16)
+        y = ops.gemm(a, w, out_f32=f32)
+        assert lib().sc_gemm_last_path() == want, (M, N, K, f32, lib().sc_gemm_last_path())
+        torch.testing.assert_close(y.float(), a.float() @ w.float().t(), atol=3e-2, rtol=2e-2)
+
+
+def test_gemm8p_operands_beyond_32bit_offsets(force_8p):
+    """A operand of 4.4e9 elements (conv layer 1 at B = 256 has 4.19e9): tile base pointers are 64-bit, per-lane offsets inside a half tile 32-bit."""
+    from speechclip_amd import ops
+    from speechclip_amd._lib import lib
+    M, N, K, ld = 4300000, 256, 192, 1024
+    flat = torch.empty(M * ld + K + 8, device="cuda", dtype=torch.bfloat16)
+    flat.normal_(0, 0.5)
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    y = ops.gemm(flat, w, None, 0, None, M=M, K=K, lda=ld)
+    assert lib().sc_gemm_last_path() == 3
+    for m0 in (0, 2200000, M - 4096):
+        a = torch.as_strided(flat[m0 * ld:], (4096, K), (ld, 1))
+        torch.testing.assert_close(y[m0:m0 + 4096].float(), a.float() @ w.float().t(), atol=2e-2, rtol=2e-2)

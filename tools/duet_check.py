@@ -78,6 +78,9 @@ SHAPES = [  # name, M, N, K, lda, act, res
     ("fc2_res", 128000, 768, 3072, None, 0, True), ("out", 128000, 768, 768, None, 0, False),
     ("conv1", 4096000, 512, 1536, 1024, 1, False), ("conv2", 2048000, 512, 1536, 1024, 1, False), ("conv5", 256000, 512, 1024, 1024, 1, False),
     ("proj", 128000, 768, 512, None, 0, False), ("sq8k", 8192, 8192, 8192, None, 0, False), ("fc2", 128000, 768, 3072, None, 0, False),
+    # P-large at 64 pairs (pre-LN: fp32 residual stream) and the ViT-B/32 residual GEMMs: "f32" = fp32 output + fp32 residual
+    ("out_l_f32", 31936, 1024, 1024, None, 0, "f32"), ("fc2_l_f32", 31936, 1024, 4096, None, 0, "f32"), ("fc1_l", 31936, 4096, 1024, None, 1, False),
+    ("qkv_l", 31936, 3072, 1024, None, 0, False), ("vit_fc2_f32", 12800, 768, 3072, None, 0, "f32"), ("vit_out_f32", 12800, 768, 768, None, 0, "f32"),
 ]
 
 
@@ -90,12 +93,13 @@ def timeit(sustain, modes, only):
         a = (torch.randn(M * ld + K + 64, device="cuda") * 0.5).to(torch.bfloat16)
         w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
         bias = torch.randn(N, device="cuda")
-        resid = torch.randn(M, N, device="cuda").to(torch.bfloat16) if use_res else None
-        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        f32 = use_res == "f32"
+        resid = torch.randn(M, N, device="cuda").to(torch.float32 if f32 else torch.bfloat16) if use_res else None
+        out = torch.empty(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
 
         def run(n):
             for _ in range(n):
-                ops.gemm(a, w, bias, act, resid, out=out, M=M, K=K, lda=ld)
+                ops.gemm(a, w, bias, act, resid, out=out, out_f32=f32, M=M, K=K, lda=ld)
         run(3)
         torch.cuda.synchronize()
         t0 = time.time()
