@@ -1060,10 +1060,11 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         d.trace = g_gemm_trace;
         d.rows = g_duet_mode == 19 ? 1 : g_duet_mode == 24 ? 2 : g_duet_mode == 25 ? 3 : 0;      // 24 / 25: the N tiles of an M panel one / two k-steps apart
         if (0) d.rows = 0;      // gemm8p: K rotation per M panel (A/B: mode 19)
-        d.band = g_duet_mode == 21 ? 3 : g_duet_mode == 22 ? 4 : g_duet_mode == 23 ? 6 : 0;      // column-band tile order (A/B: modes 21-23)
+        // column-band tile order: wide outputs (>= 16 N tiles: 8192^3 1 444 vs 1 323 TF/s unbanded, gemm256_kernel 1 406; HuBERT-large fc1 +2 %) walk 4 N tiles
+        // at a time; A/B: modes 21-23 force 3 / 4 / 6, mode 16 none
+        d.band = g_duet_mode == 21 ? 3 : g_duet_mode == 22 ? 4 : g_duet_mode == 23 ? 6 : (g_duet_mode == -1 && N / 256 >= 16) ? 4 : 0;
         const bool aligned = ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!residual || ((uintptr_t)residual & 15) == 0);
-        // (wide outputs, N >= 4096 (8192^3; HuBERT-large fc1 1 095 vs 1 080): gemm256_kernel's column-band tile order keeps a W band L2-resident -- 8192^3: 1 440 vs 1 290 TF/s; gemm8p has no banding)
-        const bool dflt_ok = N % 256 == 0 && N < 4096 && ((M + 255) / 256) * (int64_t)(N / 256) >= 128;
+        const bool dflt_ok = N % 256 == 0 && N <= 8192 && ((M + 255) / 256) * (int64_t)(N / 256) >= 128;
         if (aligned && (g_duet_mode > 0 || dflt_ok)) {
             const bool duet = g_duet_mode == 4 || g_duet_mode == 8;
             const int rc = duet ? sc_gemm_duet_try(d, (hipStream_t)stream) : sc_gemm8p_try(d, (hipStream_t)stream);

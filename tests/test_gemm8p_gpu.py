@@ -61,14 +61,14 @@ def test_gemm8p_is_transpose_detecting_and_bias_free(force_8p):
 
 
 def test_gemm8p_is_the_default_for_the_step_shapes_and_old_kernels_keep_the_rest():
-    """Dispatcher rule (gemm.hip): bf16 / fp32 output, N % 256 == 0, N < 4096, >= 128 tiles -> gemm8p (path 3); everything else -> gemm256_kernel /
+    """Dispatcher rule (gemm.hip): bf16 / fp32 output, N % 256 == 0, N <= 8192, >= 128 tiles -> gemm8p (path 3); everything else -> gemm256_kernel /
     gemm_bf16_kernel (path 0).  Both are hand-written; path 1 (vendor library) only with the comparator switched on."""
     from speechclip_amd import ops
     from speechclip_amd._lib import lib
     lib().sc_debug_set_gemm_duet(-1)
     g = torch.Generator().manual_seed(3)
     for (M, N, K, f32), want in (((12800, 768, 768, True), 3), ((32000, 2304, 768, False), 3), ((4096, 768, 768, False), 0), ((12800, 520, 768, False), 0),
-                                 ((8192, 4096, 512, False), 0)):
+                                 ((8192, 8192 + 256, 512, False), 0)):
         a = (0.5 * torch.randn(M, K, generator=g)).to("cuda", torch.bfloat16)
         w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16)
         y = ops.gemm(a, w, out_f32=f32)
