@@ -33,10 +33,10 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.sc_last_error.restype = c_char_p
         _declare(_lib)
-        # SC_GEMM_KERNEL_MODE: developer override of the bf16 GEMM kernel choice (sc_debug_set_gemm_duet: 0 = gemm256_kernel only, 16 = gemm8p wherever
+        # SC_GEMM_KERNEL_MODE: developer override of the bf16 GEMM kernel choice (sc_debug_set_gemm_mode: 0 = gemm256_kernel only, 16 = gemm8p wherever
         # the shape allows, ...), for in-step A/B timing; unset = the dispatcher's rule
         if os.environ.get("SC_GEMM_KERNEL_MODE"):
-            _lib.sc_debug_set_gemm_duet(int(os.environ["SC_GEMM_KERNEL_MODE"]))
+            _lib.sc_debug_set_gemm_mode(int(os.environ["SC_GEMM_KERNEL_MODE"]))
     return _lib
 
 
@@ -116,7 +116,7 @@ def _declare(L):
         "sc_layernorm_bwd": ([P, P, P, P, P, P, P, I, I, F, I, P], c_int),
         "sc_gelu_f32": ([P, P, L64, I, P], c_int),
         "sc_gemm_last_path": ([], c_int),
-        "sc_debug_set_gemm_duet": ([I], None),
+        "sc_debug_set_gemm_mode": ([I], None),
         "sc_debug_vendor_stream_slot": ([P], c_int),
         "sc_split_hilo_bf16": ([P, L64, P, L64, I, I, P], c_int),
         "sc_cosine_refine": ([P, P, P, I, I, I, F, F, P], c_int),

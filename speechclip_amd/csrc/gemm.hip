@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
-#include "gemm_duet.h"
+#include "gemm8p.h"
 #include "../../include/speechclip_hip.h"
 
 namespace {
@@ -1028,14 +1028,15 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
 int sc_vendor_gemm_try(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* residual,
                        int64_t ldr, int64_t M, int N, int K, int out_f32, hipStream_t s);   // vendor_gemm.hip
 
-static int g_last_path = 0;   // 0: gemm256_kernel / gemm_bf16_kernel, 1: vendor library, 2: gemm_duet_kernel (instrumentation: which kernel a launch hit)
+static int g_last_path = 0;   // 0: gemm256_kernel / gemm_bf16_kernel, 1: vendor library, 3: gemm8p_pers_kernel (instrumentation: which kernel a launch hit)
 extern "C" int sc_gemm_last_path(void) { return g_last_path; }
-// Duet kernel (gemm_duet.hip) selection: -1 the dispatcher's rule (default), 0 never, 4 / 8 whenever the shape allows, with that many epilogue steps
-#ifndef SC_GEMM_DUET
-#define SC_GEMM_DUET -1
+// gemm8p (gemm8p.hip) selection: -1 the dispatcher's rule (default), 0 never (gemm256_kernel / gemm_bf16_kernel only), 16 whenever the shape allows,
+// 17-25 A/B variants (see the dispatcher below)
+#ifndef SC_GEMM_MODE_DEFAULT
+#define SC_GEMM_MODE_DEFAULT -1
 #endif
-static int g_duet_mode = SC_GEMM_DUET;
-extern "C" void sc_debug_set_gemm_duet(int mode) { g_duet_mode = mode; }
+static int g_gemm_mode = SC_GEMM_MODE_DEFAULT;
+extern "C" void sc_debug_set_gemm_mode(int mode) { g_gemm_mode = mode; }
 static unsigned long long* g_gemm_trace = nullptr;
 // per-phase s_memtime stamps of the 256-tile kernel: effective only in the PROBES build (the product library instantiates no TRACE variant)
 extern "C" void sc_debug_set_gemm_trace(void* dev_buf) { g_gemm_trace = SC_PROBES ? (unsigned long long*)dev_buf : nullptr; }
@@ -1048,27 +1049,26 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         const int rc = sc_vendor_gemm_try(A, lda, W, ldw, C, ldc, bias, residual, ldr, M, N, K, (flags & SC_GEMM_OUT_F32) ? 1 : 0, (hipStream_t)stream);
         if (rc <= 0) { g_last_path = 1; return rc; }
     }
-    if (g_duet_mode != 0 && (!g_gemm_trace || g_duet_mode > 0) && A && W && C && M > 0 && N > 0 && K > 0) {
+    if (g_gemm_mode != 0 && (!g_gemm_trace || g_gemm_mode > 0) && A && W && C && M > 0 && N > 0 && K > 0) {
         // bf16-output GEMMs with N % 256 == 0: the ping-pong kernel (gemm8p.hip), persistent form, from 128 tiles up (ViT-B/32 at 256 images: 150 tiles,
         // +5 ... +19 % over gemm256_kernel; below that the 128 x 128 kernel's finer grid wins); bf16 or fp32 output
-        DuetParams d{};
+        Gemm8pParams d{};
         d.A = (const bf16_t*)A; d.lda = lda; d.W = (const bf16_t*)W; d.ldw = ldw; d.C = C; d.ldc = ldc; d.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0;
         d.bias = bias; d.residual = residual; d.ldr = ldr; d.M = M; d.N = N; d.K = K;
         d.act = flags & SC_GEMM_ACT_MASK;
-        d.kpair = (g_duet_mode == 20 && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) ? (int)(lda / 2 / 64) : 0;      // tap-paired K walk: A/B (mode 20)
-        d.esteps = g_duet_mode == 8 ? 8 : g_duet_mode == 17 ? 1 : 4;      // 17: gemm8p per-tile kernel
+        d.kpair = (g_gemm_mode == 20 && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) ? (int)(lda / 2 / 64) : 0;      // tap-paired K walk: A/B (mode 20)
+        d.esteps = g_gemm_mode == 17 ? 1 : 4;      // 17: gemm8p per-tile kernel
         d.trace = g_gemm_trace;
-        d.rows = g_duet_mode == 19 ? 1 : g_duet_mode == 24 ? 2 : g_duet_mode == 25 ? 3 : 0;      // 24 / 25: the N tiles of an M panel one / two k-steps apart
+        d.rows = g_gemm_mode == 19 ? 1 : g_gemm_mode == 24 ? 2 : g_gemm_mode == 25 ? 3 : 0;      // 24 / 25: the N tiles of an M panel one / two k-steps apart
         if (0) d.rows = 0;      // gemm8p: K rotation per M panel (A/B: mode 19)
         // column-band tile order: wide outputs (>= 16 N tiles: 8192^3 1 444 vs 1 323 TF/s unbanded, gemm256_kernel 1 406; HuBERT-large fc1 +2 %) walk 4 N tiles
         // at a time; A/B: modes 21-23 force 3 / 4 / 6, mode 16 none
-        d.band = g_duet_mode == 21 ? 3 : g_duet_mode == 22 ? 4 : g_duet_mode == 23 ? 6 : (g_duet_mode == -1 && N / 256 >= 16) ? 4 : 0;
+        d.band = g_gemm_mode == 21 ? 3 : g_gemm_mode == 22 ? 4 : g_gemm_mode == 23 ? 6 : (g_gemm_mode == -1 && N / 256 >= 16) ? 4 : 0;
         const bool aligned = ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!residual || ((uintptr_t)residual & 15) == 0);
         const bool dflt_ok = N % 256 == 0 && N <= 8192 && ((M + 255) / 256) * (int64_t)(N / 256) >= 128;
-        if (aligned && (g_duet_mode > 0 || dflt_ok)) {
-            const bool duet = g_duet_mode == 4 || g_duet_mode == 8;
-            const int rc = duet ? sc_gemm_duet_try(d, (hipStream_t)stream) : sc_gemm8p_try(d, (hipStream_t)stream);
-            if (rc <= 0) { g_last_path = duet ? 2 : 3; return rc; }
+        if (aligned && (g_gemm_mode > 0 || dflt_ok)) {
+            const int rc = sc_gemm8p_try(d, (hipStream_t)stream);
+            if (rc <= 0) { g_last_path = 3; return rc; }
         }
     }
     g_last_path = 0;

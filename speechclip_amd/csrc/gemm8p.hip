@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
-#include "gemm_duet.h"
+#include "gemm8p.h"
 #include "../../include/speechclip_hip.h"
 
 #ifndef SC_PROBES
@@ -42,7 +42,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 template <int ACT, bool RES>
-__global__ __launch_bounds__(512) void gemm8p_kernel(DuetParams p) {
+__global__ __launch_bounds__(512) void gemm8p_kernel(Gemm8pParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(DuetParams p) {
 // store path moves 24-36 B/clk; 16 KiB of stores per group and interval stretch each of the 8 intervals of that k-step far beyond the 256 cycles
 // of the MFMA cluster they were meant to hide under.  EXPERIMENTS.md, round 5.)
 template <int ACT, bool RES, bool F32>
-__global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
+__global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(DuetParams p) {
 }
 
 template <int ACT, bool RES, bool F32>
-int launch_pers(const DuetParams& p, int grid, hipStream_t s) {
+int launch_pers(const Gemm8pParams& p, int grid, hipStream_t s) {
     constexpr int lds = 2 * BUF + 32768;   // 128 KiB of operands + the bias vector
     static bool attr_set = false;
     if (!attr_set) {
@@ -614,7 +614,7 @@ int launch_pers(const DuetParams& p, int grid, hipStream_t s) {
 }
 
 template <int ACT, bool RES>
-int launch_one(const DuetParams& p, int grid, hipStream_t s) {
+int launch_one(const Gemm8pParams& p, int grid, hipStream_t s) {
     constexpr int lds = 2 * BUF;   // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
@@ -628,8 +628,8 @@ int launch_one(const DuetParams& p, int grid, hipStream_t s) {
 
 }  // namespace
 
-int sc_gemm8p_try(const DuetParams& pin, hipStream_t s) {
-    DuetParams p = pin;
+int sc_gemm8p_try(const Gemm8pParams& pin, hipStream_t s) {
+    Gemm8pParams p = pin;
     if (p.N % 256 || p.K % 64 || p.M < 256) return 1;
     if (p.M % 256 && (p.esteps == 1 || p.N > 8192)) return 1;      // the per-tile A/B kernel takes full M panels only
     p.tn = p.N / 256; p.nk = p.K / 64;

@@ -24,9 +24,9 @@ def _ref(a, w, bias, act, res):
 @pytest.fixture()
 def force_8p():
     from speechclip_amd._lib import lib
-    lib().sc_debug_set_gemm_duet(16)
+    lib().sc_debug_set_gemm_mode(16)
     yield
-    lib().sc_debug_set_gemm_duet(-1)
+    lib().sc_debug_set_gemm_mode(-1)
 
 
 @pytest.mark.parametrize("M,N,K,lda", [(256 * 37, 768, 768, None), (256 * 20 + 77, 1024, 128, None), (19000, 512, 1536, 1024), (9001, 2304, 192, None)])
@@ -65,7 +65,7 @@ def test_gemm8p_is_the_default_for_the_step_shapes_and_old_kernels_keep_the_rest
     gemm_bf16_kernel (path 0).  Both are hand-written; path 1 (vendor library) only with the comparator switched on."""
     from speechclip_amd import ops
     from speechclip_amd._lib import lib
-    lib().sc_debug_set_gemm_duet(-1)
+    lib().sc_debug_set_gemm_mode(-1)
     g = torch.Generator().manual_seed(3)
     for (M, N, K, f32), want in (((12800, 768, 768, True), 3), ((32000, 2304, 768, False), 3), ((4096, 768, 768, False), 0), ((12800, 520, 768, False), 0),
                                  ((8192, 8192 + 256, 512, False), 0)):

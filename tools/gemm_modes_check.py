@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gemm_duet_kernel vs gemm256_kernel: correctness against fp32 torch on a spread of shapes, then sustained-clock timing on the step's shapes.
+"""The GEMM kernels behind sc_gemm_bf16 side by side (sc_debug_set_gemm_mode): correctness against fp32 torch on a spread of shapes, then sustained-clock timing on the step's shapes.
 usage: duet_check.py [check] [time] [--sustain S] [--modes 0,4,8]"""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -46,7 +46,7 @@ def check():
         # reference in row chunks (fp32 of the big shapes does not fit comfortably otherwise)
         outs = {}
         for mode in CHECK_MODES:
-            lib().sc_debug_set_gemm_duet(mode)
+            lib().sc_debug_set_gemm_mode(mode)
             y = ops.gemm(flat, w, bias, act, res, M=M, K=K, lda=ld)
             path = lib().sc_gemm_last_path()
             torch.cuda.synchronize()
@@ -68,7 +68,7 @@ def check():
                 ok = False
         same = all(torch.equal(outs[0][0], outs[m][0]) for m in CHECK_MODES[1:])
         print(line, "bitwise-equal-to-256-tile" if same else "", flush=True)
-    lib().sc_debug_set_gemm_duet(-1)
+    lib().sc_debug_set_gemm_mode(-1)
     print("CHECK", "OK" if ok else "FAILED", flush=True)
     return ok
 
@@ -110,7 +110,7 @@ def timeit(sustain, modes, only):
         for rnd in range(3):          # interleaved rounds
             for mode in modes:
                 ops.set_vendor_gemm(mode == 99)            # mode 99: the hipBLASLt comparator (plain shapes only)
-                lib().sc_debug_set_gemm_duet(mode if mode != 99 else -1)
+                lib().sc_debug_set_gemm_mode(mode if mode != 99 else -1)
                 run(5)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); run(30); e1.record()
@@ -120,7 +120,7 @@ def timeit(sustain, modes, only):
         res[name] = row
         print(f"{name:8s} " + "  ".join(f"mode{m}: {v}" for m, v in row.items()), flush=True)
         del a, w, out, resid
-    lib().sc_debug_set_gemm_duet(-1)
+    lib().sc_debug_set_gemm_mode(-1)
     ops.set_vendor_gemm(False)
     print(json.dumps(res))
 
@@ -139,7 +139,7 @@ def trace8p(only):
         bias = torch.randn(N, device="cuda")
         resid = torch.randn(M, N, device="cuda").to(torch.bfloat16) if use_res else None
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        L.sc_debug_set_gemm_duet(17)
+        L.sc_debug_set_gemm_mode(17)
         for _ in range(10):
             ops.gemm(a, w, bias, act, resid, out=out, M=M, K=K, lda=ld)
         tr = torch.zeros(4096 * 64, dtype=torch.int64, device="cuda")
@@ -155,7 +155,7 @@ def trace8p(only):
         span = t[:, :, 4].max() - t[:, :, 3][t[:, :, 3] > 0].min()
         print(f"{name}: per tile: prologue {pro:7.0f}  loop {loop:7.0f} ({loop/nk:6.0f} per k-step)  epilogue+drain {epi:7.0f}  block lifetime {life:7.0f}; "
               f"{ntiles} traced tiles span {span:.0f} cycles = {span/ (ntiles/256):.0f} per round of 256", flush=True)
-        L.sc_debug_set_gemm_duet(-1)
+        L.sc_debug_set_gemm_mode(-1)
         del a, w, out, resid
 
 
@@ -173,7 +173,7 @@ def trace8pp(only):
         bias = torch.randn(N, device="cuda")
         resid = torch.randn(M, N, device="cuda").to(torch.bfloat16) if use_res else None
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        L.sc_debug_set_gemm_duet(16)
+        L.sc_debug_set_gemm_mode(16)
         for _ in range(10):
             ops.gemm(a, w, bias, act, resid, out=out, M=M, K=K, lda=ld)
         tr = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
@@ -188,7 +188,7 @@ def trace8pp(only):
             tiles = x[:, :, 4].mean()
             print(f"{name} g{grp}: per tile: first k-step {x[:, :, 0].mean()/tiles:7.0f}  other k-steps {x[:, :, 1].mean()/tiles/(nk-1):6.0f} each  epilogue {x[:, :, 2].mean()/tiles:7.0f}"
                   f"  | tile {x[:, :, 3].mean()/tiles:7.0f}  tiles/block {tiles:.2f}  lifetime min/max {x[:, :, 3].min():.0f}/{x[:, :, 3].max():.0f}", flush=True)
-        L.sc_debug_set_gemm_duet(-1)
+        L.sc_debug_set_gemm_mode(-1)
         del a, w, out, resid
 
 
@@ -209,7 +209,7 @@ def trace(only, modes):
         for mode in modes:
             if mode == 0:
                 continue
-            L.sc_debug_set_gemm_duet(mode)
+            L.sc_debug_set_gemm_mode(mode)
             for _ in range(10):
                 ops.gemm(a, w, bias, act, resid, out=out, M=M, K=K, lda=ld)
             tr = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
@@ -228,7 +228,7 @@ def trace(only, modes):
                 ns, nj, ne = tiles_g * E, tiles_g * (nk - E), tiles_g * E
                 print(f"{name} mode{mode} g{grp}: per step  solo work {x[0]/ns:6.0f} +bar {x[1]/ns:6.0f} | joint work {x[2]/max(nj,1):6.0f} +bar {x[3]/max(nj,1):6.0f} | "
                       f"epi work {x[4]/ne:6.0f} +bar {x[5]/ne:6.0f} (c0 dma wait {x[7]/tiles_g:6.0f} per tile) | null {x[6]:8.0f}  total {x.sum():.0f}", flush=True)
-        L.sc_debug_set_gemm_duet(-1)
+        L.sc_debug_set_gemm_mode(-1)
         del a, w, out, resid
 
 

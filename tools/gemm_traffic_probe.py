@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from speechclip_amd import ops
 from speechclip_amd._lib import lib
-if os.environ.get('SC_DUET_MODE'):
-    lib().sc_debug_set_gemm_duet(int(os.environ['SC_DUET_MODE']))
+if os.environ.get('SC_GEMM_KERNEL_MODE'):
+    lib().sc_debug_set_gemm_mode(int(os.environ['SC_GEMM_KERNEL_MODE']))
 for spec in sys.argv[1:]:
     name, rest = spec.split(":")
     M, N, K, lda, act = (int(v) for v in rest.split(","))

@@ -1,3 +1,5 @@
+// ROUND-5 EXPERIMENT, NOT PART OF THE PRODUCT (moved out of speechclip_amd/csrc at the end of round 5; builds against csrc/gemm8p.h of that revision with the
+// rows / units / esteps fields in their original meaning).  Result: NEGATIVE, EXPERIMENTS.md R5-2.
 // bf16 MFMA GEMM, "duet" form for gfx950 (CDNA4):  C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual, bf16 out.
 //
 // Why a second kernel.  gemm256_kernel (gemm.hip) runs ONE 256x256 tile per CU at a time: all 8 waves reach the tile's epilogue together, so the
@@ -21,7 +23,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
-#include "gemm_duet.h"
+#include "gemm8p.h"
 #include "../../include/speechclip_hip.h"
 
 #ifndef SC_PROBES
@@ -44,7 +46,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 template <int ACT, bool RES, int E>
-__global__ __launch_bounds__(512) void gemm_duet_kernel(DuetParams p) {
+__global__ __launch_bounds__(512) void gemm_duet_kernel(Gemm8pParams p) {
     static_assert(E == 4 || E == 8, "epilogue steps");
     constexpr int RB = 8 / E;                      // row blocks (16 rows each) per epilogue step
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(512) void gemm_duet_kernel(DuetParams p) {
 }
 
 template <int ACT, bool RES, int E>
-int launch_one(const DuetParams& p, int grid, hipStream_t s) {
+int launch_one(const Gemm8pParams& p, int grid, hipStream_t s) {
     constexpr int lds = 5 * HALF_SLOT;   // 160 KiB
     static bool attr_set = false;
     if (!attr_set) {
@@ -413,7 +415,7 @@ int launch_one(const DuetParams& p, int grid, hipStream_t s) {
 }
 
 template <int E>
-int launch_var(const DuetParams& p, int grid, hipStream_t s) {
+int launch_var(const Gemm8pParams& p, int grid, hipStream_t s) {
     const bool res = p.residual != nullptr;
     switch (p.act) {
         case SC_ACT_GELU: return res ? launch_one<SC_ACT_GELU, true, E>(p, grid, s) : launch_one<SC_ACT_GELU, false, E>(p, grid, s);
@@ -424,8 +426,8 @@ int launch_var(const DuetParams& p, int grid, hipStream_t s) {
 
 }  // namespace
 
-int sc_gemm_duet_try(const DuetParams& pin, hipStream_t s) {
-    DuetParams p = pin;
+int sc_gemm_duet_try(const Gemm8pParams& pin, hipStream_t s) {
+    Gemm8pParams p = pin;
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     const int grid = n_cu & ~7;                       // blocks b, b + 8, .. share an XCD; one block per CU (160 KiB of LDS each)
