@@ -444,6 +444,8 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             // (A "balanced" fragment-read schedule -- quadrant order (a0,b0) (a0,b1) (a1,b0) (a1,b1), the next k-step's b0 read in phase 3's memory interval, the
             //  k-half-1 fragments of a0 requested at the head of phase 0's cluster: 4 / 4 / 8 / 4 reads per memory interval instead of 12 / 4 / 8 / 0 -- measured
             //  3 % SLOWER on every shape (fc2 1235 vs 1270, conv1 1125 vs 1158 TF/s, same box), round 5.  EXPERIMENTS.md.)
+            // (Fragment reads of phases 1 and 2 issued at the tail of the previous matrix interval -- behind the cluster's last MFMA, in front of the barrier, so
+            //  that their LDS latency runs across the barrier: measured 1-3 % SLOWER on every shape, round 5.  EXPERIMENTS.md R5-3.)
             // ---- phase 0: quadrant (a0, b0)
             if (first) init_q(I0{}, I0{});
             read_a(bx, 0); read_b(bx, 0);
