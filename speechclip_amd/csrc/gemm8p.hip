@@ -446,6 +446,9 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             //  3 % SLOWER on every shape (fc2 1235 vs 1270, conv1 1125 vs 1158 TF/s, same box), round 5.  EXPERIMENTS.md.)
             // (Fragment reads of phases 1 and 2 issued at the tail of the previous matrix interval -- behind the cluster's last MFMA, in front of the barrier, so
             //  that their LDS latency runs across the barrier: measured 1-3 % SLOWER on every shape, round 5.  EXPERIMENTS.md R5-3.)
+            // (Deferred output stores -- 10 of the 16 stores per wave of the finished tile kept in registers / 2 KiB of LDS and issued one per phase 0 and one
+            //  behind phase 3's wait of the next tile's first k-steps: 2-14 % SLOWER (QKV 946 vs 1097, fc1 880 vs 999 TF/s): the stores share the in-order
+            //  vmcnt queue with the LDS-DMA refills, so the counted waits also wait for store acknowledgements.  Round 5, EXPERIMENTS.md R5-3.)
             // ---- phase 0: quadrant (a0, b0)
             if (first) init_q(I0{}, I0{});
             read_a(bx, 0); read_b(bx, 0);
