@@ -1064,6 +1064,7 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         // column-band tile order: wide outputs (>= 16 N tiles: 8192^3 1 444 vs 1 323 TF/s unbanded, gemm256_kernel 1 406; HuBERT-large fc1 +2 %) walk 4 N tiles
         // at a time; A/B: modes 21-23 force 3 / 4 / 6, mode 16 none
         d.band = g_gemm_mode == 21 ? 3 : g_gemm_mode == 22 ? 4 : g_gemm_mode == 23 ? 6 : (g_gemm_mode == -1 && N / 256 >= 16) ? 4 : 0;
+        d.sched = g_gemm_mode == 26 ? -1 : 0;      // 26: static tile order (A/B)
         const bool aligned = ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!residual || ((uintptr_t)residual & 15) == 0);
         const bool dflt_ok = N % 256 == 0 && N <= 8192 && ((M + 255) / 256) * (int64_t)(N / 256) >= 128;
         if (aligned && (g_gemm_mode > 0 || dflt_ok)) {

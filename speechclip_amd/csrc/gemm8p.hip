@@ -13,6 +13,7 @@
 // every slot is re-staged at least one full phase after the last wave finished reading it (reads are waited for BEFORE the barrier that ends a
 // memory interval), and at least 3.5 phases before its first reader.  One counted wait per k-step (phase 3: vmcnt(4)).
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 #include "common.h"
 #include "gemm8p.h"
@@ -30,11 +31,20 @@
 #ifndef SC_8P_PRIO
 #define SC_8P_PRIO 1
 #endif
+#ifndef SC_8P_DYN             // 1: the persistent kernel takes its tiles from per-XCD counters (Gemm8pParams::sched >= 0) instead of a fixed stride
+#define SC_8P_DYN 1
+#endif
 
 namespace {
 
 constexpr int HT = 128 * 128;            // one half tile: 128 rows x 128 B = 16 KiB
 constexpr int BUF = 4 * HT;              // A0 A1 B0 B1
+
+// Tile counters of the persistent kernel's dynamic order: one 64-byte slot per launch in flight (the host hands out slots round robin; a launch leaves
+// its slot zeroed): [0..7] next tile of XCD x's chunk (beyond the one tile every block owns by its position), [8] blocks finished.
+constexpr int SCHED_RING = 4096;
+constexpr int SCHED_LDS = 2 * BUF + 32752;      // where a block's waves exchange the fetched index (behind the bias vector: dynamic order needs N < 8192)
+__device__ unsigned int g_sched[SCHED_RING * 16];
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -269,13 +279,28 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int cnt = q8 + (xcd < r8 ? 1 : 0);
-    const int my_tiles = slot_in_xcd < cnt ? (cnt - slot_in_xcd + nb_xcd - 1) / nb_xcd : 0;
-    if (my_tiles == 0) return;
+    // Tile order inside the chunk.  Static: every nb_xcd-th tile.  Dynamic (p.sched >= 0): the first tile by position, every further one from the XCD's
+    // counter -- a block that starts late (the image tower's kernels on the side stream hold CUs when this launch begins: 144 KiB of LDS, one block per
+    // CU) or runs slower takes fewer tiles instead of stretching the launch by its whole fixed share.  The fetch is issued by wave 0 in k-step 0 of a
+    // tile (behind phase 3's counted wait, so it is the oldest entry of the in-order queue for one k-step only), is covered by k-step 1's wait, goes
+    // through LDS to the other waves and is used from k-step nk - 2 on (the refill that crosses into the next tile): nk >= 6, host check.
+    const bool dyn = SC_8P_DYN && p.sched >= 0;
+    unsigned int* const sched = g_sched + (dyn ? p.sched : 0) * 16;
+    auto block_done = [&]() {      // the last block out re-arms the slot for the launch that gets it next
+        if (dyn && tid == 0) {
+            const unsigned int d = __hip_atomic_fetch_add(sched + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == (unsigned int)G - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) __hip_atomic_store(sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    if (slot_in_xcd >= cnt) { block_done(); return; }
     // Column bands (p.band N tiles, 0 = all of N): the order walks every M panel of a band before the next band, so an XCD has only the band's slice of
     // W (band x 256 x K) in flight: with all of N in flight (QKV 3.5 MiB, fc1 4.7 MiB of W against a 4 MiB L2) W is re-fetched once per tile round.
     const int band = p.band;
-    auto tile_mn = [&](int it, int& tm, int& tn) {
-        int v = begin + it * nb_xcd + slot_in_xcd;
+    auto tile_mn = [&](int idx, int& tm, int& tn) {      // idx: position inside the XCD's chunk
+        int v = begin + idx;
         int nb = tiles_n, tn0 = 0;
         if (band > 0 && band < tiles_n) {
             const int per_band = band * tiles_m;
@@ -338,7 +363,8 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
     auto tile_a = [&](int tm_) -> const bf16_t* { const int64_t m = (int64_t)tm_ * 256; return p.A + (m + 256 <= p.M ? m : p.M - 256) * p.lda; };
 
     int tm, tn;
-    tile_mn(0, tm, tn);
+    int cur = slot_in_xcd;
+    tile_mn(cur, tm, tn);
     const bf16_t* ta = tile_a(tm);
     const bf16_t* tw = p.W + (int64_t)tn * 256 * p.ldw;
     int rot = p.rows == 1 ? tm % nk : p.rows == 2 ? tn % nk : p.rows == 3 ? (2 * tn) % nk : 0;      // (p.rows reused as the rotation switch: 0 = off)
@@ -416,13 +442,23 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
     const bool tracing = SC_PROBES && p.trace;
     if (tracing) tr_t = __builtin_readcyclecounter();
     const unsigned long long tr_begin = tr_t;
-    for (int it = 0; it < my_tiles; ++it) {
-        const bool have_next = it + 1 < my_tiles;
-        int ntm = tm, ntn = tn;
-        if (have_next) tile_mn(it + 1, ntm, ntn);
-        const bf16_t* ta_n = tile_a(ntm);
-        const bf16_t* tw_n = p.W + (int64_t)ntn * 256 * p.ldw;
-        const int rot_n = p.rows == 1 ? ntm % nk : p.rows == 2 ? ntn % nk : p.rows == 3 ? (2 * ntn) % nk : 0;
+    unsigned int fetched = 0;
+    int n_tiles = 0;
+    for (;;) {
+        bool have_next = false;
+        int nxt = cur, ntm = tm, ntn = tn, rot_n = 0;
+        const bf16_t* ta_n = ta;
+        const bf16_t* tw_n = tw;
+        auto set_next = [&](int idx) {
+            nxt = idx;
+            have_next = idx < cnt;
+            if (have_next) tile_mn(idx, ntm, ntn);
+            ta_n = tile_a(ntm);
+            tw_n = p.W + (int64_t)ntn * 256 * p.ldw;
+            rot_n = p.rows == 1 ? ntm % nk : p.rows == 2 ? ntn % nk : p.rows == 3 ? (2 * ntn) % nk : 0;
+        };
+        if (!dyn) set_next(cur + nb_xcd);
+        ++n_tiles;
         // (Measured alternatives of this schedule, round 5, same box, TF/s qkv / out / fc2: this one 1128 / 1100 / 1306; TWO phases of 32 MFMAs per k-step --
         //  half as many barriers -- 1075 / 997 / 1275; ONE barrier per phase with a leader / follower order of the two groups inside the interval
         //  1100 / 1015 / 1235.  EXPERIMENTS.md.)
@@ -449,6 +485,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             // (Deferred output stores -- 10 of the 16 stores per wave of the finished tile kept in registers / 2 KiB of LDS and issued one per phase 0 and one
             //  behind phase 3's wait of the next tile's first k-steps: 2-14 % SLOWER (QKV 946 vs 1097, fc1 880 vs 999 TF/s): the stores share the in-order
             //  vmcnt queue with the LDS-DMA refills, so the counted waits also wait for store acknowledgements.  Round 5, EXPERIMENTS.md R5-3.)
+            if (dyn && kt == 2) set_next(nb_xcd + __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) int*)(smem + SCHED_LDS)));
             // ---- phase 0: quadrant (a0, b0)
             if (first) init_q(I0{}, I0{});
             read_a(bx, 0); read_b(bx, 0);
@@ -473,6 +510,15 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             if (first) init_q(I1{}, I0{});
             if (s_ok) { stage_a(sa, 0, s_k, bx); stage_a(sa, 1, s_k, bx); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (dyn && wave == 0 && kt < 2) {
+                if (kt == 0) {      // lane 0 only (exec switched inside the asm: no per-lane select on `fetched`, which is in flight until k-step 1's wait)
+                    unsigned long long ex;
+                    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
+                                 : "+v"(fetched), "=&s"(ex) : "v"(sched + xcd), "v"(1u) : "memory");
+                } else if (lane == 0) {
+                    *(volatile __attribute__((address_space(3))) unsigned int*)(smem + SCHED_LDS) = fetched;      // (k-step 1's wait above covered the fetch)
+                }
+            }
             // (residual variants: touching the tile's residual lines two k-steps ahead -- 4-byte LDS-DMA loads into a dummy LDS area, gemm256_kernel's trick --
             //  measured in the step, round 5: out-proj 789 -> 761, fc2 1170 -> 1112 TF/s.  Not kept.)
             mem_end();
@@ -596,12 +642,14 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                     }
         }
         if (tracing) { const unsigned long long c = __builtin_readcyclecounter(); tr_epi += c - tr_t; tr_t = c; }
-        tm = ntm; tn = ntn; ta = ta_n; tw = tw_n; rot = rot_n;
+        if (!have_next) break;
+        cur = nxt; tm = ntm; tn = ntn; ta = ta_n; tw = tw_n; rot = rot_n;
     }
     if (g == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    block_done();
     if (tracing && lane == 0) {      // per wave: first k-step of every tile / the other k-steps / epilogue issue, block lifetime, tiles
         unsigned long long* tr = p.trace + ((size_t)blockIdx.x * 8 + wave) * 8;
-        tr[0] = tr_first; tr[1] = tr_loop; tr[2] = tr_epi; tr[3] = __builtin_readcyclecounter() - tr_begin; tr[4] = my_tiles;
+        tr[0] = tr_first; tr[1] = tr_loop; tr[2] = tr_epi; tr[3] = __builtin_readcyclecounter() - tr_begin; tr[4] = n_tiles;
     }
 }
 
@@ -648,6 +696,9 @@ int sc_gemm8p_try(const Gemm8pParams& pin, hipStream_t s) {
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
         const int pg = grid < n_cu ? grid : n_cu;
+        // dynamic tile order: a slot of the counter ring per launch (SCHED_RING launches would have to be in flight at once for two to meet)
+        static std::atomic<unsigned> sched_seq{0};
+        p.sched = (SC_8P_DYN && p.sched >= 0 && p.nk >= 6 && p.N < 8192 && pg >= 8) ? (int)(sched_seq.fetch_add(1) % SCHED_RING) : -1;
         if (p.out_f32) {
             switch (p.act) {
                 case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false, true>(p, pg, s);

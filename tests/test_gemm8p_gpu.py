@@ -89,3 +89,42 @@ def test_gemm8p_operands_beyond_32bit_offsets(force_8p):
     for m0 in (0, 2200000, M - 4096):
         a = torch.as_strided(flat[m0 * ld:], (4096, K), (ld, 1))
         torch.testing.assert_close(y[m0:m0 + 4096].float(), a.float() @ w.float().t(), atol=2e-2, rtol=2e-2)
+
+
+def test_gemm8p_dynamic_tile_order_equals_static_and_survives_ring_reuse():
+    """The persistent kernel takes its tiles from per-XCD counters (one 64-byte slot of a 4096-slot ring per launch, re-armed by the launch's last block;
+    gemm8p.hip, K >= 384).  Mode 26 = the static stride order.  Same tiles, same arithmetic per tile -> bit-identical outputs; more launches than ring
+    slots, half of them racing on a second stream, must leave every slot armed."""
+    from speechclip_amd import ops
+    from speechclip_amd._lib import lib
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 256 * 123 + 100, 1280, 768                      # 620 tiles on 256 blocks, ragged last panel
+    a = (0.5 * torch.randn(M, K, generator=g)).to("cuda", torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16)
+    bias = torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).to("cuda", torch.bfloat16)
+    try:
+        lib().sc_debug_set_gemm_mode(26)
+        y_static = ops.gemm(a, w, bias, 1, r)
+        assert lib().sc_gemm_last_path() == 3
+        lib().sc_debug_set_gemm_mode(16)
+        y_dyn = ops.gemm(a, w, bias, 1, r)
+        assert torch.equal(y_static, y_dyn)
+        # ring reuse: 2 x 2200 small launches (40 x 8 = 320 tiles each) on two streams at once, then the big shape again
+        a2 = a[:256 * 40]
+        w2 = (torch.randn(2048, 384, generator=g) * 384 ** -0.5).to("cuda", torch.bfloat16)
+        M2 = a2.shape[0]
+        want = ops.gemm(a2, w2, M=M2, K=384, lda=K)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        outs = [torch.empty_like(want), torch.empty_like(want)]
+        for _ in range(2200):
+            ops.gemm(a2, w2, out=outs[0], M=M2, K=384, lda=K)
+            with torch.cuda.stream(side):
+                ops.gemm(a2, w2, out=outs[1], M=M2, K=384, lda=K)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(outs[0], want) and torch.equal(outs[1], want)
+        assert torch.equal(ops.gemm(a, w, bias, 1, r), y_static)
+    finally:
+        lib().sc_debug_set_gemm_mode(-1)
+    torch.testing.assert_close(y_dyn.float(), _ref(a, w, bias, 1, r), atol=2e-2, rtol=2e-2)
