@@ -31,6 +31,9 @@
 #ifndef SC_8P_PRIO
 #define SC_8P_PRIO 1
 #endif
+#ifndef SC_8P_RES_ASM         // 1: residual epilogues load the residual tile with explicit loads + counted waits and store after the last add (see the epilogue)
+#define SC_8P_RES_ASM 1
+#endif
 #ifndef SC_8P_DYN             // 1: the persistent kernel takes its tiles from per-XCD counters (Gemm8pParams::sched >= 0) instead of a fixed stride
 #define SC_8P_DYN 1
 #endif
@@ -45,6 +48,10 @@ constexpr int BUF = 4 * HT;              // A0 A1 B0 B1
 constexpr int SCHED_RING = 4096;
 constexpr int SCHED_LDS = 2 * BUF + 32752;      // where a block's waves exchange the fetched index (behind the bias vector: dynamic order needs N < 8192)
 __device__ unsigned int g_sched[SCHED_RING * 16];
+// Where the residual epilogues send the stores of rows that belong to the previous tile (ragged last M panel, tile shifted back): their stores all follow
+// the last residual add, and 8-32 per-lane store predicates held until then cost more registers than the kernel has (spills inside the k-loop);
+// an address select per row block costs none.  Contents are never read.
+__device__ __attribute__((aligned(16))) char g_sink[64 * 16 + 256];
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -458,6 +465,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             rot_n = p.rows == 1 ? ntm % nk : p.rows == 2 ? ntn % nk : p.rows == 3 ? (2 * ntn) % nk : 0;
         };
         if (!dyn) set_next(cur + nb_xcd);
+        const bool no_wait0 = RES && SC_8P_RES_ASM && !SC_8P_RES_LATE && n_tiles > 0 && nk >= 3;
         ++n_tiles;
         // (Measured alternatives of this schedule, round 5, same box, TF/s qkv / out / fc2: this one 1128 / 1100 / 1306; TWO phases of 32 MFMAs per k-step --
         //  half as many barriers -- 1075 / 997 / 1275; ONE barrier per phase with a leader / follower order of the two groups inside the interval
@@ -508,7 +516,9 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             // ---- phase 3: quadrant (a1, b0), operands already in registers; both A halves of k-step + 2; k-step + 1 must have landed: in-order,
             //      everything but the 8 pieces of phases 2 and 3
             if (first) init_q(I1{}, I0{});
-            if (s_ok) { stage_a(sa, 0, s_k, bx); stage_a(sa, 1, s_k, bx); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            // (residual variants, k-step 0 of every tile but the block's first: the previous epilogue waited vmcnt(0) -- this tile's k-step 1 included -- before
+            //  its first store, so no counted wait here: it would wait for that epilogue's whole store burst to be acknowledged)
+            if (s_ok) { stage_a(sa, 0, s_k, bx); stage_a(sa, 1, s_k, bx); if (!(first && no_wait0)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (dyn && wave == 0 && kt < 2) {
                 if (kt == 0) {      // lane 0 only (exec switched inside the asm: no per-lane select on `fetched`, which is in flight until k-step 1's wait)
@@ -529,9 +539,18 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
         if (tracing) { const unsigned long long c = __builtin_readcyclecounter(); tr_loop += c - tr_t; tr_t = c; }
         // ---- epilogue: 16 rows x 64 contiguous bytes per store (gemm.hip's fast path); the next tile's first k-step is landing meanwhile
         {
-            f32x4_t bias4[4];
+            // (residual variants with the explicit residual pipeline re-read the bias from LDS at every use: 16 VGPRs the epilogue needs elsewhere)
+            constexpr bool BIAS_LDS = RES && SC_8P_RES_ASM;
+            f32x4_t bias4[BIAS_LDS ? 1 : 4];
+            const char* bias_at = lds_bias + (tn * 256 + w4 * 64 + fk * 4) * 4;
+            if constexpr (!BIAS_LDS) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bias4[j] = *(const f32x4_t*)(lds_bias + (tn * 256 + w4 * 64 + j * 16 + fk * 4) * 4);
+                for (int j = 0; j < 4; ++j) bias4[j] = *(const f32x4_t*)(bias_at + j * 64);
+            }
+            auto bias_of = [&](int j) -> f32x4_t {
+                if constexpr (BIAS_LDS) return *(volatile const __attribute__((address_space(3))) f32x4_t*)(bias_at + j * 64);
+                else return bias4[j];
+            };
             const int64_t m_lo = (int64_t)tm * 256, m0 = m_lo + 256 <= p.M ? m_lo : p.M - 256;
             const int skip = (int)(m_lo - m0) - g * 128 - srow;            // rows i * 16 + .. below this belong to the previous tile (ragged last M panel)
             const int64_t mrow0 = m0 + g * 128 + srow;
@@ -544,6 +563,52 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                 const int ncol32 = tn * 256 + w4 * 64 + schunk * 4;
                 float* cf = (float*)p.C + mrow0 * p.ldc + ncol32;
                 const float* rf = RES ? (const float*)p.residual + mrow0 * p.ldr + ncol32 : nullptr;
+                if constexpr (RES && SC_8P_RES_ASM) {
+                    // Residual tile through EXPLICIT loads and counted waits.  Left to the compiler, a residual row block read ahead of its use sits in the
+                    // queue with the output stores of the blocks before it, and hipcc (loads and stores pending on the one vmcnt counter) waits vmcnt(0) in
+                    // front of every use: each row block paid a full HBM round trip plus the acknowledgement of all earlier stores.  Here the queue holds only
+                    // loads until the last residual has been added: two row blocks in flight (32 VGPRs, 8 KiB per wave), refilled as they are used, waits
+                    // counted exactly (loads return in order); the outputs replace the accumulators and all stores go out at the end, after vmcnt(0).
+                    f32x4_t rs[2][4];
+                    auto load_rs = [&](int i) {
+                        const float* a = rf + i * rstep;
+                        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
+                                     "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+                                     : "=&v"(rs[i & 1][0]), "=&v"(rs[i & 1][1]), "=&v"(rs[i & 1][2]), "=&v"(rs[i & 1][3]) : "v"(a) : "memory");
+                    };
+                    load_rs(0); load_rs(1);
+                    auto blk = [&](auto itag) {
+                        constexpr int i = decltype(itag)::value;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4_t v4 = acc[i][j] + bias_of(j);
+                            if (ACT == SC_ACT_GELU) {
+                                const f32x2_t g0 = gelu_poly2_f32((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2_f32((f32x2_t){v4[2], v4[3]});
+                                v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+                            } else if (ACT == SC_ACT_QUICKGELU) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm32, __float_as_int(v4[r])));
+                        }
+                        constexpr int newer = (i + 1 < 8 ? 1 : 0) * 4;      // loads issued behind row block i's
+                        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rs[i & 1][0]), "+v"(rs[i & 1][1]), "+v"(rs[i & 1][2]), "+v"(rs[i & 1][3]) : "n"(newer) : "memory");
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] += rs[i & 1][j];
+                        if (i + 2 < 8) load_rs(i + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    blk(std::integral_constant<int, 0>{}); blk(std::integral_constant<int, 1>{}); blk(std::integral_constant<int, 2>{}); blk(std::integral_constant<int, 3>{});
+                    blk(std::integral_constant<int, 4>{}); blk(std::integral_constant<int, 5>{}); blk(std::integral_constant<int, 6>{}); blk(std::integral_constant<int, 7>{});
+                    // (vmcnt is 0 here: the next tile's k-step 1 has landed too -- no_wait0 above)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float* dst = i * 16 >= skip ? cf + i * cstep : (float*)(g_sink + lane * 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *(f32x4_t*)(dst + j * 16) = acc[i][j];
+                    }
+                } else {
                 f32x4_t rs[RES ? 2 : 1][4];
                 auto load_rs = [&](int i) {
 #pragma unroll
@@ -555,7 +620,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                     f32x4_t o[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        f32x4_t v4 = acc[i][j] + bias4[j];
+                        f32x4_t v4 = acc[i][j] + bias_of(j);
                         if (ACT == SC_ACT_GELU) {       // f32 output: the fp32 polynomial (the packed-half form carries ~11 bits, meant for bf16 results)
                             const f32x2_t g0 = gelu_poly2_f32((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2_f32((f32x2_t){v4[2], v4[3]});
                             v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
@@ -574,6 +639,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                     if (RES && i + 2 < 8) load_rs(i + 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                }
             } else {
             bf16_t* cptr = (bf16_t*)p.C + mrow0 * p.ldc + ncol0;
             const bf16_t* rptr = RES ? (const bf16_t*)p.residual + mrow0 * p.ldr + ncol0 : nullptr;
@@ -582,7 +648,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) res[i & 3][jp] = *(const uint4*)(rptr + i * rstep + jp * 32);
             };
-            if (RES) { load_res(0); load_res(1); load_res(2); load_res(3); }
+            if (RES && !SC_8P_RES_ASM) { load_res(0); load_res(1); load_res(2); load_res(3); }
             if (RES && SC_8P_RES_LATE && have_next) {      // the refill the last k-step left out (bx / by are swapped by now: `by` held k-step nk - 1)
                 const int k1 = kofs(1, rot_n);
                 stage_b(tw_n, 0, k1, by); stage_b(tw_n, 1, k1, by); stage_a(ta_n, 0, k1, by); stage_a(ta_n, 1, k1, by);
@@ -593,7 +659,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                     f32x2_t xs[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const f32x4_t v4 = acc[i][j] + bias4[j];
+                        const f32x4_t v4 = acc[i][j] + bias_of(j);
                         xs[2 * j] = (f32x2_t){v4[0], v4[1]}; xs[2 * j + 1] = (f32x2_t){v4[2], v4[3]};
                     }
                     gelu_poly2_x8(xs);
@@ -602,7 +668,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                 } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    f32x4_t v4 = acc[i][j] + bias4[j];
+                    f32x4_t v4 = acc[i][j] + bias_of(j);
                     if (ACT == SC_ACT_QUICKGELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
@@ -619,6 +685,44 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                                        __builtin_amdgcn_ds_bpermute(bperm, r0[1]), __builtin_amdgcn_ds_bpermute(bperm, r1[1]));
                 }
             };
+            if constexpr (RES && SC_8P_RES_ASM) {
+                // (explicit residual loads, as the fp32 path above: four row blocks in flight -- 32 VGPRs, 8 KiB per wave -- refilled as they are used, counted
+                //  waits, results kept, every store behind the last add)
+                typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                u32x4_t rv[4][2];
+                uint4 ov[8][2];
+                auto load_rv = [&](int i) {
+                    const bf16_t* a = rptr + i * rstep;
+                    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64" : "=&v"(rv[i & 3][0]), "=&v"(rv[i & 3][1]) : "v"(a) : "memory");
+                };
+                load_rv(0); load_rv(1); load_rv(2); load_rv(3);
+                auto blk = [&](auto itag) {
+                    constexpr int i = decltype(itag)::value;
+                    shuffled(i, ov[i]);
+                    constexpr int newer = (i + 3 < 8 ? 3 : 7 - i) * 2;      // loads issued behind row block i's
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rv[i & 3][0]), "+v"(rv[i & 3][1]) : "n"(newer) : "memory");
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        uint4 o = ov[i][jp];
+                        const uint4 r4 = make_uint4(rv[i & 3][jp][0], rv[i & 3][jp][1], rv[i & 3][jp][2], rv[i & 3][jp][3]);
+                        o.x = pack2bf(lo2f(o.x) + lo2f(r4.x), hi2f(o.x) + hi2f(r4.x));
+                        o.y = pack2bf(lo2f(o.y) + lo2f(r4.y), hi2f(o.y) + hi2f(r4.y));
+                        o.z = pack2bf(lo2f(o.z) + lo2f(r4.z), hi2f(o.z) + hi2f(r4.z));
+                        o.w = pack2bf(lo2f(o.w) + lo2f(r4.w), hi2f(o.w) + hi2f(r4.w));
+                        ov[i][jp] = o;
+                    }
+                    if (i + 4 < 8) load_rv(i + 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                blk(std::integral_constant<int, 0>{}); blk(std::integral_constant<int, 1>{}); blk(std::integral_constant<int, 2>{}); blk(std::integral_constant<int, 3>{});
+                blk(std::integral_constant<int, 4>{}); blk(std::integral_constant<int, 5>{}); blk(std::integral_constant<int, 6>{}); blk(std::integral_constant<int, 7>{});
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    bf16_t* dst = i * 16 >= skip ? cptr + i * cstep : (bf16_t*)(g_sink + lane * 16);
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) *(uint4*)(dst + jp * 32) = ov[i][jp];
+                }
+            } else {
             uint4 oc[2][2];
             shuffled(0, oc[0]);
 #pragma unroll
@@ -638,6 +742,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                 }
                 if (RES && i + 4 < 8) load_res(i + 4);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
                     }
         }
