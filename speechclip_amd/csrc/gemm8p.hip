@@ -577,8 +577,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                                      : "=&v"(rs[i & 1][0]), "=&v"(rs[i & 1][1]), "=&v"(rs[i & 1][2]), "=&v"(rs[i & 1][3]) : "v"(a) : "memory");
                     };
                     load_rs(0); load_rs(1);
-                    auto blk = [&](auto itag) {
-                        constexpr int i = decltype(itag)::value;
+                    auto conv = [&](int i) {      // bias, activation, lane exchange of row block i, in place
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             f32x4_t v4 = acc[i][j] + bias_of(j);
@@ -592,6 +591,11 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) acc[i][j][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm32, __float_as_int(v4[r])));
                         }
+                    };
+                    conv(0); conv(1);      // two row blocks ahead of the add: work under the first residual's round trip
+                    auto blk = [&](auto itag) {
+                        constexpr int i = decltype(itag)::value;
+                        if (i + 2 < 8) conv(i + 2 < 8 ? i + 2 : 7);
                         constexpr int newer = (i + 1 < 8 ? 1 : 0) * 4;      // loads issued behind row block i's
                         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rs[i & 1][0]), "+v"(rs[i & 1][1]), "+v"(rs[i & 1][2]), "+v"(rs[i & 1][3]) : "n"(newer) : "memory");
 #pragma unroll
@@ -696,9 +700,10 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                     asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64" : "=&v"(rv[i & 3][0]), "=&v"(rv[i & 3][1]) : "v"(a) : "memory");
                 };
                 load_rv(0); load_rv(1); load_rv(2); load_rv(3);
+                shuffled(0, ov[0]); shuffled(1, ov[1]);      // the conversion runs two row blocks ahead of the add: work under the first residual's round trip
                 auto blk = [&](auto itag) {
                     constexpr int i = decltype(itag)::value;
-                    shuffled(i, ov[i]);
+                    if (i + 2 < 8) shuffled(i + 2, ov[i + 2 < 8 ? i + 2 : 7]);
                     constexpr int newer = (i + 3 < 8 ? 3 : 7 - i) * 2;      // loads issued behind row block i's
                     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rv[i & 3][0]), "+v"(rv[i & 3][1]) : "n"(newer) : "memory");
 #pragma unroll
