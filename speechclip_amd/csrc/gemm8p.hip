@@ -806,9 +806,16 @@ int sc_gemm8p_try(const Gemm8pParams& pin, hipStream_t s) {
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
         const int pg = grid < n_cu ? grid : n_cu;
-        // dynamic tile order: a slot of the counter ring per launch (SCHED_RING launches would have to be in flight at once for two to meet)
+        // dynamic tile order: a slot of the counter ring per launch (SCHED_RING launches would have to be in flight at once for two to meet).  A launch
+        // that is being CAPTURED into a HIP graph keeps the static order: its slot would be frozen into the graph node, and a replay could then run
+        // beside an eager launch that the ring has handed the same slot.
         static std::atomic<unsigned> sched_seq{0};
-        p.sched = (SC_8P_DYN && p.sched >= 0 && p.nk >= 6 && p.N < 8192 && pg >= 8) ? (int)(sched_seq.fetch_add(1) % SCHED_RING) : -1;
+        bool dyn = SC_8P_DYN && p.sched >= 0 && p.nk >= 6 && p.N < 8192 && pg >= 8;
+        if (dyn) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) dyn = false;
+        }
+        p.sched = dyn ? (int)(sched_seq.fetch_add(1) % SCHED_RING) : -1;
         if (p.out_f32) {
             switch (p.act) {
                 case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false, true>(p, pg, s);
