@@ -188,6 +188,10 @@ def trace8pp(only):
             tiles = x[:, :, 4].mean()
             print(f"{name} g{grp}: per tile: first k-step {x[:, :, 0].mean()/tiles:7.0f}  other k-steps {x[:, :, 1].mean()/tiles/(nk-1):6.0f} each  epilogue {x[:, :, 2].mean()/tiles:7.0f}"
                   f"  | tile {x[:, :, 3].mean()/tiles:7.0f}  tiles/block {tiles:.2f}  lifetime min/max {x[:, :, 3].min():.0f}/{x[:, :, 3].max():.0f}", flush=True)
+        # dynamic tile order: tiles taken and lifetime per XCD (block b lives on XCD b % 8) -- how uneven the XCDs run
+        tiles_b, life_b = t[:, 0, 4], t[:, 0, 3]
+        print(f"{name} per XCD: tiles " + " ".join(f"{int(tiles_b[x::8].sum())}" for x in range(8)) + "  | lifetime max (k cycles) "
+              + " ".join(f"{life_b[x::8].max()/1e3:.0f}" for x in range(8)) + f"  | tiles per block min/max {int(tiles_b.min())}/{int(tiles_b.max())}", flush=True)
         L.sc_debug_set_gemm_mode(-1)
         del a, w, out, resid
 
