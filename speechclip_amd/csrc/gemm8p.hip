@@ -34,6 +34,9 @@
 #ifndef SC_8P_RES_ASM         // 1: residual epilogues load the residual tile with explicit loads + counted waits and store after the last add (see the epilogue)
 #define SC_8P_RES_ASM 1
 #endif
+#ifndef SC_8P_EPI_PAIR        // 1: the two groups' epilogues share ONE barrier interval (group 1 drops the barrier behind its last cluster and re-enters every tile one barrier late)
+#define SC_8P_EPI_PAIR 1
+#endif
 #ifndef SC_8P_DYN             // 1: the persistent kernel takes its tiles from per-XCD counters (Gemm8pParams::sched >= 0) instead of a fixed stride
 #define SC_8P_DYN 1
 #endif
@@ -269,6 +272,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(Gemm8pParams p) {
 // of the MFMA cluster they were meant to hide under.  EXPERIMENTS.md, round 5.)
 template <int ACT, bool RES, bool F32>
 __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
+    // (fp32 outputs keep the plain pairing: their epilogues move 512 KiB per tile and are bound by the CU's load / store path -- side by side they
+    //  measured 6 % slower (P-large out-proj 740 -> 697 TF/s), one after the other group 0's stores overlap group 1's residual loads)
+    constexpr bool PAIR = SC_8P_EPI_PAIR && !F32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    if (g == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // group 1 runs one barrier interval behind group 0
+    if (!PAIR && g == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // group 1 runs one barrier interval behind group 0
 
     // epilogue lane mapping (gemm.hip): lane L stores row L >> 2, 16-byte chunk L & 3 of a 32-column half
     const int srow = lane >> 2, schunk = lane & 3;
@@ -465,8 +471,14 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             rot_n = p.rows == 1 ? ntm % nk : p.rows == 2 ? ntn % nk : p.rows == 3 ? (2 * ntn) % nk : 0;
         };
         if (!dyn) set_next(cur + nb_xcd);
-        const bool no_wait0 = RES && SC_8P_RES_ASM && !SC_8P_RES_LATE && n_tiles > 0 && nk >= 3;
+        const bool no_wait0 = RES && SC_8P_RES_ASM && !SC_8P_RES_LATE && n_tiles > 0 && nk >= 3;      // (the same for the plain variants: +-0, twice)
         ++n_tiles;
+        // Barrier pairing at a tile boundary.  Group 1 runs one barrier interval behind group 0 inside a tile.  With the same pairing across the boundary
+        // the two epilogues land in DIFFERENT intervals (group 0's beside group 1's last cluster, group 1's beside group 0's first cluster of the next
+        // tile) and run one after the other: the trace showed group 0 waiting a whole epilogue at its first barrier (first k-step 6.5 k cycles plain,
+        // 10 k residual / GELU, against 3 k).  So group 1 drops the barrier behind its last cluster (nothing after it touches an operand buffer before the
+        // barriers of the next tile's k-step 0) and enters every tile with one extra barrier: both epilogues sit between the same two barriers.
+        if (PAIR && g == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
         // (Measured alternatives of this schedule, round 5, same box, TF/s qkv / out / fc2: this one 1128 / 1100 / 1306; TWO phases of 32 MFMAs per k-step --
         //  half as many barriers -- 1075 / 997 / 1275; ONE barrier per phase with a leader / follower order of the two groups inside the interval
         //  1100 / 1015 / 1235.  EXPERIMENTS.md.)
@@ -533,7 +545,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             //  measured in the step, round 5: out-proj 789 -> 761, fc2 1170 -> 1112 TF/s.  Not kept.)
             mem_end();
             quadrant(I1{}, I0{});
-            mat_end();
+            if (PAIR && g == 1 && kt == nk - 1) __builtin_amdgcn_sched_barrier(0); else mat_end();
             { char* x = bx; bx = by; by = x; }
         }
         if (tracing) { const unsigned long long c = __builtin_readcyclecounter(); tr_loop += c - tr_t; tr_t = c; }
@@ -755,7 +767,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
         if (!have_next) break;
         cur = nxt; tm = ntm; tn = ntn; ta = ta_n; tw = tw_n; rot = rot_n;
     }
-    if (g == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    if (!PAIR && g == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     block_done();
     if (tracing && lane == 0) {      // per wave: first k-step of every tile / the other k-steps / epilogue issue, block lifetime, tiles
         unsigned long long* tr = p.trace + ((size_t)blockIdx.x * 8 + wave) * 8;
