@@ -6,7 +6,7 @@
 // (16 back-to-back MFMAs at s_setprio 1) -- and the two groups run ONE INTERVAL APART: while a SIMD's group-0 wave is in its MFMA cluster the
 // group-1 wave issues its reads and DMA, and vice versa.  The matrix pipe always has exactly one wave streaming MFMAs and never waits behind a
 // vector-memory / LDS issue stall of the same wave (gemm256_kernel interleaves 4 MFMA : 1 read : 1 DMA in every wave, all 8 waves in lock step,
-// and measures as if MFMA, DMA issue and LDS reads did not overlap at all: profiles/r05_duet_ablation.txt).
+// and measures as if MFMA, DMA issue and LDS reads did not overlap at all: EXPERIMENTS.md R5-1).
 //
 // LDS: 2 buffers x {A0, A1, B0, B1} half tiles of 128 rows x 128 B (A_g: the 128 rows of group g; B_h: W rows h*128 ..), swizzled on the source
 // side like gemm.hip (chunk position c of row r holds k-chunk c ^ (r & 7)).  Refill: phase (t,0) A0(t+1), (t,1) A1(t+1), (t,2) B0(t+2), (t,3) B1(t+2):
