@@ -37,6 +37,9 @@
 #ifndef SC_8P_EPI_PAIR        // 1: the two groups' epilogues share ONE barrier interval (group 1 drops the barrier behind its last cluster and re-enters every tile one barrier late)
 #define SC_8P_EPI_PAIR 1
 #endif
+#ifndef SC_8P_BIAS_INIT       // 1: a tile's accumulators start from the bias (read from LDS in the first k-step's memory intervals) instead of zero: no bias add in the epilogue
+#define SC_8P_BIAS_INIT 1
+#endif
 #ifndef SC_8P_DYN             // 1: the persistent kernel takes its tiles from per-XCD counters (Gemm8pParams::sched >= 0) instead of a fixed stride
 #define SC_8P_DYN 1
 #endif
@@ -433,7 +436,9 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) acc[a * 4 + ii][b * 2 + jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int jj = 0; jj < 2; ++jj)
+                acc[a * 4 + ii][b * 2 + jj] = SC_8P_BIAS_INIT ? *(const f32x4_t*)(lds_bias + (tn * 256 + w4 * 64 + (b * 2 + jj) * 16 + fk * 4) * 4)
+                                                              : (f32x4_t){0.f, 0.f, 0.f, 0.f};
     };
     auto mem_end = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
         // ---- epilogue: 16 rows x 64 contiguous bytes per store (gemm.hip's fast path); the next tile's first k-step is landing meanwhile
         {
             // (residual variants with the explicit residual pipeline re-read the bias from LDS at every use: 16 VGPRs the epilogue needs elsewhere)
-            constexpr bool BIAS_LDS = RES && SC_8P_RES_ASM;
+            constexpr bool BIAS_LDS = (RES && SC_8P_RES_ASM) || SC_8P_BIAS_INIT;
             f32x4_t bias4[BIAS_LDS ? 1 : 4];
             const char* bias_at = lds_bias + (tn * 256 + w4 * 64 + fk * 4) * 4;
             if constexpr (!BIAS_LDS) {
@@ -562,6 +567,10 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             auto bias_of = [&](int j) -> f32x4_t {
                 if constexpr (BIAS_LDS) return *(volatile const __attribute__((address_space(3))) f32x4_t*)(bias_at + j * 64);
                 else return bias4[j];
+            };
+            auto biased = [&](const f32x4_t& v, int j) -> f32x4_t {
+                if constexpr (SC_8P_BIAS_INIT) return v;      // the accumulators started from the bias
+                else return v + bias_of(j);
             };
             const int64_t m_lo = (int64_t)tm * 256, m0 = m_lo + 256 <= p.M ? m_lo : p.M - 256;
             const int skip = (int)(m_lo - m0) - g * 128 - srow;            // rows i * 16 + .. below this belong to the previous tile (ragged last M panel)
@@ -592,7 +601,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                     auto conv = [&](int i) {      // bias, activation, lane exchange of row block i, in place
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            f32x4_t v4 = acc[i][j] + bias_of(j);
+                            f32x4_t v4 = biased(acc[i][j], j);
                             if (ACT == SC_ACT_GELU) {
                                 const f32x2_t g0 = gelu_poly2_f32((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2_f32((f32x2_t){v4[2], v4[3]});
                                 v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                     f32x4_t o[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        f32x4_t v4 = acc[i][j] + bias_of(j);
+                        f32x4_t v4 = biased(acc[i][j], j);
                         if (ACT == SC_ACT_GELU) {       // f32 output: the fp32 polynomial (the packed-half form carries ~11 bits, meant for bf16 results)
                             const f32x2_t g0 = gelu_poly2_f32((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2_f32((f32x2_t){v4[2], v4[3]});
                             v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
@@ -675,7 +684,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                     f32x2_t xs[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const f32x4_t v4 = acc[i][j] + bias_of(j);
+                        const f32x4_t v4 = biased(acc[i][j], j);
                         xs[2 * j] = (f32x2_t){v4[0], v4[1]}; xs[2 * j + 1] = (f32x2_t){v4[2], v4[3]};
                     }
                     gelu_poly2_x8(xs);
@@ -684,7 +693,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                 } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    f32x4_t v4 = acc[i][j] + bias_of(j);
+                    f32x4_t v4 = biased(acc[i][j], j);
                     if (ACT == SC_ACT_QUICKGELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
