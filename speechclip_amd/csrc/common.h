@@ -74,14 +74,23 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {   // two values: the p
 #ifndef SC_GELU_DEG
 #define SC_GELU_DEG 6
 #endif
+#ifndef SC_GELU_TCLAMP        // 1: clamp the polynomial argument t to <= 1 (rounds 3-5); 0: rely on the Phi clamp alone (see gelu_poly2)
+#define SC_GELU_TCLAMP (SC_GELU_DEG == 6 ? 0 : 1)
+#endif
 typedef _Float16 sc_half2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
-    // y = x Phi(x), Phi = clamp(1/2 + x g(t), 0, 1), t = min(x^2 / 8 - 1, 1).  Only t is clamped (one v_pk_min): beyond |x| = 4 the product x g(1)
-    // leaves [-1/2, 1/2] and the [0, 1] clamp -- the VOP3P clamp bit of the v_pk_fma that forms Phi -- pins Phi to 0 / 1.  The last product is
-    // formed in fp32 from the half operands (v_fma_mix_f32), which is also the conversion the bf16 pack needs.
+    // y = x Phi(x), Phi = clamp(1/2 + x g(t), 0, 1), t = x^2 / 8 - 1.  NOTHING but Phi is clamped (the VOP3P clamp bit of the v_pk_fma that forms it):
+    // beyond |x| = 4 (t > 1) the even-degree g with its positive leading coefficient only grows, x g(t) leaves [-1/2, 1/2] and the clamp pins Phi to
+    // 0 / 1; x^2 overflowing to +inf (|x| > 255) keeps every Horner step at +inf and Phi at clamp(+-inf).  (Rounds 3-5 also clamped t with a v_pk_min:
+    // bit-identical results on every finite half input, tests/test_gemm8p_gpu.py::test_gelu_epilogue_every_bf16_input, 7 % of the epilogue's VALU work.)
+    // The last product is formed in fp32 from the half operands (v_fma_mix_f32), which is also the conversion the bf16 pack needs.
     const sc_half2_t h = __builtin_bit_cast(sc_half2_t, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
     const sc_half2_t one = {(_Float16)1.0f, (_Float16)1.0f}, zero = {(_Float16)0.0f, (_Float16)0.0f};
+#if SC_GELU_TCLAMP
     const sc_half2_t t = __builtin_elementwise_min(h * h * (_Float16)0.125f - (_Float16)1.0f, one);
+#else
+    const sc_half2_t t = h * h * (_Float16)0.125f - (_Float16)1.0f;
+#endif
 #if SC_GELU_DEG == 5
     sc_half2_t g = t * (_Float16)-1.177580447e-02f + (_Float16)2.993807372e-02f;
     g = g * t + (_Float16)-3.959858472e-02f;
@@ -114,7 +123,7 @@ __device__ __forceinline__ void gelu_poly2_x8(f32x2_t (&x)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = h[i] * h[i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = __builtin_elementwise_min(t[i] * (_Float16)0.125f - (_Float16)1.0f, one);
+    for (int i = 0; i < 8; ++i) t[i] = SC_GELU_TCLAMP ? __builtin_elementwise_min(t[i] * (_Float16)0.125f - (_Float16)1.0f, one) : t[i] * (_Float16)0.125f - (_Float16)1.0f;
 #if SC_GELU_DEG == 5
     const float c[6] = {-1.177580447e-02f, 2.993807372e-02f, -3.959858472e-02f, 5.414790186e-02f, -8.377277171e-02f, 1.760021146e-01f};
     constexpr int NC = 6;

@@ -128,3 +128,39 @@ def test_gemm8p_dynamic_tile_order_equals_static_and_survives_ring_reuse():
     finally:
         lib().sc_debug_set_gemm_mode(-1)
     torch.testing.assert_close(y_dyn.float(), _ref(a, w, bias, 1, r), atol=2e-2, rtol=2e-2)
+
+
+def test_gelu_epilogue_every_bf16_input():
+    """The fused-GELU epilogue (packed-half polynomial, common.h gelu_poly2_x8) on EVERY finite bf16 pre-activation with |x| <= 60000, each fed through the
+    kernel exactly (one non-zero per A row against an identity W): against exact erf-GELU within bf16 rounding + the polynomial's 3.2e-3, and saturated
+    exactly (y == x / y == 0) beyond |x| = 5.5 -- the region where only the clamp of Phi keeps the un-clamped polynomial argument in check.
+    Reference arithmetic: torch.nn.functional.gelu (fairseq TransformerSentenceEncoderLayer activation_fn, speech_encoder_plus.py:49-56 [3P])."""
+    from speechclip_amd import ops
+    from speechclip_amd._lib import lib
+    bits = torch.arange(0, 65536, dtype=torch.int32)
+    vals = bits.to(torch.int16).view(torch.bfloat16)
+    vals = vals[torch.isfinite(vals.float()) & (vals.float().abs() <= 60000)]
+    n = vals.numel()
+    M = (n + 255) // 256 * 256
+    a = torch.zeros(M, 256, dtype=torch.bfloat16)
+    rows = torch.arange(n)
+    a[rows, rows % 256] = vals
+    w = torch.eye(256, dtype=torch.bfloat16)
+    try:
+        lib().sc_debug_set_gemm_mode(16)
+        y = ops.gemm(a.cuda(), w.cuda(), None, 1).float().cpu()
+        assert lib().sc_gemm_last_path() == 3
+    finally:
+        lib().sc_debug_set_gemm_mode(-1)
+    got = y[rows, rows % 256]
+    x = vals.float()
+    want = torch.nn.functional.gelu(x.double()).float()
+    assert torch.isfinite(got).all()
+    tol = 3.2e-3 + want.abs() * 2.0 ** -7            # polynomial + half input + bf16 output rounding
+    bad = (got - want).abs() > tol
+    assert not bad.any(), (x[bad][:8], got[bad][:8], want[bad][:8])
+    big = x.abs() >= 5.5
+    assert torch.equal(got[big & (x > 0)], x[big & (x > 0)])          # Phi == 1: y is x (bf16 -> half -> bf16 is exact up to 65504)
+    assert (got[big & (x < 0)] == 0).all()                             # Phi == 0
+    off = y.clone(); off[rows, rows % 256] = 0
+    assert (off == 0).all()                                            # GELU(0) == 0 everywhere else
