@@ -511,8 +511,6 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             //  behind phase 3's wait of the next tile's first k-steps: 2-14 % SLOWER (QKV 946 vs 1097, fc1 880 vs 999 TF/s): the stores share the in-order
             //  vmcnt queue with the LDS-DMA refills, so the counted waits also wait for store acknowledgements.  Round 5, EXPERIMENTS.md R5-3.)
             if (dyn && kt == 2) set_next(nb_xcd + __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) int*)(smem + SCHED_LDS)));
-            // (Split A refill -- a0 rows of k-step + 2 requested from phase 1, W from phase 2, a1 rows from phase 3, two counted waits per k-step, every piece
-            //  >= 1.25 k-steps ahead of its wait instead of >= 1.0: 3-5 % SLOWER on every bf16 shape, step +0.8 ms.  Round 5, EXPERIMENTS.md R5-3.)
             // ---- phase 0: quadrant (a0, b0)
             if (first) init_q(I0{}, I0{});
             read_a(bx, 0); read_b(bx, 0);
