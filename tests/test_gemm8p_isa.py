@@ -1,0 +1,63 @@
+"""Compiler-output guards for the dominant kernel (speechclip_amd/csrc/gemm8p.hip), checked on the gfx950 ISA hipcc emits (no GPU needed):
+ * no persistent-kernel variant uses scratch (a spill inside the k-loop costs more than any schedule gains: round-5 log, EXPERIMENTS.md R5-3);
+ * the register that receives the tile counter's `global_atomic_add` result is in flight for a whole k-step behind an inline-asm issue the compiler
+   knows nothing about: between its initialisation, the atomic and the `ds_write_b32` that hands it to the other waves nothing may read or write it;
+ * the residual epilogues contain exactly the counted waits that were designed (no compiler-inserted vmcnt(0) between residual uses)."""
+import os
+import re
+import shutil
+import subprocess
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "gemm8p.s"
+    src = os.path.join(ROOT, "speechclip_amd", "csrc", "gemm8p.hip")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only", src, "-o", str(out)],
+                   check=True, capture_output=True, timeout=600)
+    txt = out.read_text()
+    ks = {}
+    for part in re.split(r"\n(?=_ZN12_GLOBAL__N_118gemm8p_pers_kernel\S+:)", txt)[1:]:
+        name = part.split(":", 1)[0]
+        ks[name] = part.split(".end_amdhsa_kernel")[0]
+    assert len(ks) == 12, sorted(ks)                       # ACT x RES x F32
+    return ks
+
+
+def test_no_variant_spills(kernels):
+    for name, body in kernels.items():
+        m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
+        assert m and int(m.group(1)) == 0, (name, m and m.group(1))
+        assert "scratch_" not in body, name
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) <= 256
+
+
+def test_tile_counter_result_register_is_untouched_while_in_flight(kernels):
+    for name, body in kernels.items():
+        m = re.search(r"global_atomic_add (v\d+), v\[\d+:\d+\], v\d+, off sc0", body)
+        assert m, name
+        reg = m.group(1)
+        uses = [l.strip() for l in body.splitlines() if re.search(r"\b" + reg + r"\b", l) and not l.strip().startswith(";")]
+        kinds = [u.split()[0] for u in uses]
+        assert kinds == ["v_mov_b32_e32", "global_atomic_add", "ds_write_b32"], (name, uses)
+
+
+def test_residual_epilogues_wait_by_count_only(kernels):
+    """Behind the last MFMA of a residual variant: the explicit residual loads, then waits vmcnt(6 6 6 6 6 4 2 0) (bf16: 4 row blocks x 2 loads in flight) or
+    vmcnt(4 x 7, 0) (fp32: 2 row blocks x 4 loads), then the stores -- and no other vmcnt wait in between."""
+    for name, body in kernels.items():
+        if "ELb1ELb" not in name:                           # RES == false
+            continue
+        f32 = name.endswith("ELb1ELb1EEEv12Gemm8pParams")
+        tail = body[body.rfind("v_mfma"):]
+        first_store = tail.find("global_store_dwordx4")
+        waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", tail[:first_store])]
+        want = [4] * 7 + [0] if f32 else [6] * 5 + [4, 2, 0]
+        assert waits[-len(want):] == want, (name, waits)
+        assert len(re.findall(r"global_load_dwordx4", tail[:first_store])) == (32 if f32 else 16), name
