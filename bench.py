@@ -672,7 +672,7 @@ def main():
         w8 = torch.randn(n8, n8, device=dev, dtype=torch.bfloat16)
         c8 = torch.empty(n8, n8, device=dev, dtype=torch.bfloat16)
         ceiling = {"shape": "8192^3 bf16, 30 back-to-back launches after 10 warm-up launches"}
-        for name, on in (("hand_written_gemm256_tflops", False), ("hipblaslt_tflops", True)):
+        for name, on in (("hand_written_tflops", False), ("hipblaslt_tflops", True)):      # hand-written: gemm8p_pers_kernel, column bands of 4 N tiles (gemm.hip dispatcher)
             ops.set_vendor_gemm(on)
             for _ in range(10):
                 ops.gemm(a8, w8, out=c8)
