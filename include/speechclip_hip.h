@@ -59,8 +59,9 @@ int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
 int sc_set_gemm_workspace(void* workspace, int64_t bytes);
 int sc_gemm_last_path(void);   /* instrumentation: which kernel the last sc_gemm_bf16 call ran on: 0 gemm256_kernel / gemm_bf16_kernel, 1 the vendor
                                 * library (comparator), 3 gemm8p_pers_kernel (ping-pong schedule, gemm8p.hip) -- 0 and 3 are the hand-written kernels */
-/* Developer / test switch between the hand-written bf16-output GEMM kernels: -1 dispatcher's rule (default: gemm8p from 256 tiles up, N % 256 == 0),
- * 0 gemm256_kernel / gemm_bf16_kernel only, 16 gemm8p whenever the shape allows; 17-25 A/B variants of it (per-tile launch, K rotation, tap-paired K walk, column bands). */
+/* Developer / test switch between the hand-written GEMM kernels: -1 dispatcher's rule (default: gemm8p from 128 tiles up, N % 256 == 0, N <= 8192),
+ * 0 gemm256_kernel / gemm_bf16_kernel only, 16 gemm8p whenever the shape allows; 17-26 A/B variants of it (per-tile launch, K rotation, tap-paired K walk,
+ * column bands, 26 = static instead of dynamic tile order). */
 void sc_debug_set_gemm_mode(int mode);
 /* instrumentation (comparator only): which half of the comparator workspace `stream` owns: 0 / 1, -1 none yet, -2 both halves belong to other
  * streams (that stream's GEMMs run on the hand-written kernels), -3 comparator library not loaded.  The comparator ABI itself is declared once,
