@@ -489,10 +489,14 @@ def main():
         # First-contact check for the 8-GPU node: every rank must sit on its OWN physical GPU.  A launcher that hands each rank
         # HIP_VISIBLE_DEVICES=<one id> collapses LOCAL_RANK -> cuda:0 legitimately; ranks that share a PCI bus id do not.  (--share-gpu is the
         # explicit single-GPU test hook and says so in `data`.)
-        bus = torch.cuda.get_device_properties(dev).pci_bus_id if hasattr(torch.cuda.get_device_properties(dev), "pci_bus_id") else local_rank
+        pr = torch.cuda.get_device_properties(dev)
+        # identity of the GPU behind this rank: uuid where torch exposes it, else PCI domain : bus : device (the bus number alone repeats across PCI
+        # domains on multi-socket nodes); a second, independent key is (HIP_VISIBLE_DEVICES, device index).  The ranks are on distinct GPUs if EITHER key
+        # separates them -- the check must not abort a healthy node because one property is missing or coarse.
+        bus = "/".join(str(getattr(pr, a, "?")) for a in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"))
         ids = [None] * world
         dist.all_gather_object(ids, (int(torch.cuda.current_device()), str(bus), os.environ.get("HIP_VISIBLE_DEVICES", "")))
-        devices_seen = len({b for _, b, _ in ids})
+        devices_seen = max(len({b for _, b, _ in ids}), len({(v, d) for d, _, v in ids}))
         if not args.share_gpu and devices_seen != world:
             sys.exit(f"bench.py: {world} ranks but only {devices_seen} distinct GPU(s) behind them {ids}: check HIP_VISIBLE_DEVICES / LOCAL_RANK")
 
