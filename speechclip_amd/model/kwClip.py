@@ -21,6 +21,7 @@ from torch import nn
 from .. import ops, parallel
 
 _OVERLAP_IMAGE_TOWER = os.environ.get("SC_OVERLAP_VIT", "1") != "0"
+_VIT_START = os.environ.get("SC_VIT_START", "")       # "" = the image tower starts with the step; "extractor" / "layer<i>": behind that stage of the speech tower (A/B)
 _SIDE_STREAMS = {}
 from ..base import OrderedNamespace
 from ..module import ClipModel, FairseqSpeechEncoder_Hubert, MLPLayers, S3prlSpeechEncoderPlus, losses, mutualRetrieval
@@ -564,18 +565,36 @@ class KWClip_GeneralTransformer(KWClipBase):
             side = _SIDE_STREAMS.get(image.device.index)          # one side stream per device for the whole process (the library path keeps
             if side is None:                                      # one workspace half per stream: vendor_gemm.hip)
                 side = _SIDE_STREAMS[image.device.index] = torch.cuda.Stream(device=image.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                if ops.PROFILE is not None:        # bench instrumentation: the window in which two kernels may share the CUs
-                    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    w0.record()
-                ops.PROFILE_TAG = "image"
-                image_feat = self.forward_image(image)
-                ops.PROFILE_TAG = "speech"
-                if ops.PROFILE is not None:
-                    w1.record()
-                    ops.PROFILE_SIDE.append((w0, w1))
-            audio_feat, audio_len = self.forward_audio(wav, wav_len)
+            def launch_image():
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    if ops.PROFILE is not None:        # bench instrumentation: the window in which two kernels may share the CUs
+                        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        w0.record()
+                    tag = ops.PROFILE_TAG
+                    ops.PROFILE_TAG = "image"
+                    feat = self.forward_image(image)
+                    ops.PROFILE_TAG = tag
+                    if ops.PROFILE is not None:
+                        w1.record()
+                        ops.PROFILE_SIDE.append((w0, w1))
+                return feat
+            if not _VIT_START:
+                image_feat = launch_image()
+                audio_feat, audio_len = self.forward_audio(wav, wav_len)
+            else:                                  # A/B: the image tower enters the launch sequence behind a stage of the speech tower (module/hubert.py STAGE_HOOK)
+                from ..module import hubert as _hubert
+                box = []
+
+                def hook(name):
+                    if name == _VIT_START and not box:
+                        box.append(launch_image())
+                _hubert.STAGE_HOOK = hook
+                try:
+                    audio_feat, audio_len = self.forward_audio(wav, wav_len)
+                finally:
+                    _hubert.STAGE_HOOK = None
+                image_feat = box[0] if box else launch_image()
             cur.wait_stream(side)
             image_feat.record_stream(cur)
         else:

@@ -26,6 +26,10 @@ import torch.nn as nn
 from .. import ops
 from ..ops import ACT_GELU, ACT_NONE
 
+# Launch-order hook (kwClip.forward): called with "extractor" behind the conv feature extractor and "layer<i>" in front of transformer layer i, so that the
+# caller can enqueue independent work (the image tower on its side stream) at that point of the speech tower's launch sequence.  None: no calls.
+STAGE_HOOK = None
+
 CONV_LAYERS = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2
 
 
@@ -401,6 +405,8 @@ class HubertModel(nn.Module):
             return site[0]
         if rates and rates["features"] > 0:
             ops.dropout_bf16(xp, rates["features"], next_seed(), out=xp)                      # dropout_input (speech_encoder_plus.py:87)
+        if STAGE_HOOK is not None:
+            STAGE_HOOK("extractor")
         # ---- frame mask, positional conv (+ LN for post-LN models)
         valid = self.valid_frames(lens, lmax, T)
         valid_i32 = ops.dev_ints(valid, torch.int32, dev)
@@ -476,6 +482,8 @@ class HubertModel(nn.Module):
                 continue
             h, h_out = hidden[kept], hidden[kept + 1]
             kept += 1
+            if STAGE_HOOK is not None:
+                STAGE_HOOK("layer%d" % i)
             if not pre_ln and rates:      # [3P fairseq] TransformerSentenceEncoderLayer in train mode: x = LN(x + dropout1(attn(x))); x = LN(x + dropout3(fc2(dropout2(act(fc1 x)))))
                 ops.gemm(h, L["wqkv"], L["bqkv"], out=qkv)
                 if pack is not None:
