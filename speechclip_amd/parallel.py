@@ -9,6 +9,7 @@ DataParallel's dim-0 gather order, so the global-batch loss is identical to the 
 """
 from typing import Dict
 
+import math
 import torch
 import torch.distributed as dist
 
@@ -113,7 +114,9 @@ def gather_rows_dict(d: dict, keys_1d=ROW_KEYS_1D) -> dict:
     flt = {k: v for k, v in d.items() if torch.is_tensor(v) and v.is_floating_point() and v.dim() >= 1 and v.shape[0] == B
            and (v.dim() >= 2 or k in keys_1d)}
     shapes = {k: v.shape[1:] for k, v in flt.items()}
-    feats = {k: pad(v.reshape(B, -1)) for k, v in flt.items()}
+    # (explicit width: reshape(0, -1) of an EMPTY local batch is ambiguous and would raise on that rank only, behind the row-count collective --
+    #  the other ranks would then block in the packed gather)
+    feats = {k: pad(v.reshape(B, int(math.prod(v.shape[1:])))) for k, v in flt.items()}
     feats["id"] = pad(d["id"])
     out = gather_loss_feats(feats)
     res = dict(d)

@@ -392,13 +392,13 @@ def test_train_gather_is_one_collective_and_validation_outputs_are_gathered_gloo
         assert np.array_equal(res[0][6][k], res[1][6][k])
 
 
-def _ragged_gather_worker(rank, world, port, q):
+def _ragged_gather_worker(rank, world, port, q, rows=(3, 2)):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from speechclip_amd import parallel
     g = torch.Generator().manual_seed(11 + rank)
-    B = 3 if rank == 0 else 2                                # DataParallel's scatter of a 5-row last batch over 2 replicas: 3 + 2
+    B = rows[rank]                                           # DataParallel's scatter of a 5-row last batch over 2 replicas: 3 + 2
     others = {"id": torch.arange(B) + 10 * rank + 2 ** 33, "audio_feat": torch.randn(B, 6, generator=g), "image_feat": torch.randn(B, 6, generator=g),
               "keywords": torch.randn(B, 2, 3, generator=g), "gold_text": torch.arange(B * 4).view(B, 1, 4) + 100 * rank, "row_score": torch.randn(B, generator=g)}
     go = parallel.gather_rows_dict(others)
@@ -424,6 +424,27 @@ def test_validation_gather_accepts_a_ragged_last_batch_gloo_world2():
     for k in ("id", "audio_feat", "image_feat", "keywords", "gold_text", "row_score"):
         want = np.concatenate([res[0][2][k], res[1][2][k]], 0)
         assert want.shape[0] == 5
+        for r in res:
+            assert r[1][k].dtype == want.dtype and np.array_equal(r[1][k], want), k
+
+
+def test_validation_gather_accepts_an_empty_rank_gloo_world2():
+    """a rank whose last validation batch is EMPTY (2 rows over 2 replicas scatter as 2 + 0 when the loader's shard runs dry) must not raise
+    behind the row-count collective (the other rank would block in the packed gather): the gather returns the 2 rows on both ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_gather_worker, args=(r, 2, port, q, (2, 0))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for k in ("id", "audio_feat", "image_feat", "keywords", "gold_text", "row_score"):
+        want = res[0][2][k]
+        assert want.shape[0] == 2
         for r in res:
             assert r[1][k].dtype == want.dtype and np.array_equal(r[1][k], want), k
 

@@ -1,0 +1,286 @@
+// What can the matrix pipes of this socket sustain under its POWER cap?  ("next round" item 1a.)
+// One block per CU streams MFMAs on random, register-resident bf16 operands for >= 2.5 s per variant -- no global memory in the loop, LDS only in the
+// variants that say so -- while a host thread polls socket power and shader clock (sysfs hwmon, rocm-smi as a fallback).  The kernel also stamps
+// s_memtime (shader cycles) against s_memrealtime (100 MHz) so the effective clock comes from the GPU itself.
+//
+// Per wave and iteration, the register / LDS traffic of ONE 64-deep k-step of the two GEMM wave-tile structures:
+//   shape 0: wave tile 128 x 64 as 8 x 4 tiles of v_mfma_f32_16x16x32_bf16, 2 k-halves = 64 MFMAs; 8 + 4 operand fragments per k-half
+//            (gemm8p: 24 ds_read_b128 per k-step and wave, 8 waves per CU)
+//   shape 2: wave tile 128 x 64 as 4 x 2 tiles of v_mfma_f32_32x32x16_bf16 (32 MFMAs per k-step; 2 waves per SIMD possible: the in-place A/B of gemm8p)
+//   shape 1: wave tile 128 x 128 as 4 x 4 tiles of v_mfma_f32_32x32x16_bf16, 4 k-quarters = 64 MFMAs; 4 + 4 operand fragments per k-quarter
+//            (4-wave structure: 32 ds_read_b128 per k-step and wave, 4 waves per CU)
+// Both are 2 * 128 * 64 * 64 * (1 or 2) flops: shape 0 = 1 048 576 flops per wave-iteration, shape 1 = 2 097 152.
+//   wps  : waves per SIMD (1 -> 256 threads, 2 -> 512 threads per block)
+//   lds  : 0 operands stay in registers; 1 every k-step re-reads its fragments from LDS (conflict-free lane-linear ds_read_b128, software-pipelined one
+//          k-half / k-quarter ahead) -- prices the LDS + register-write traffic of the real loop in watts
+//   acc  : builtin = the compiler places the accumulators (AGPRs for the 256-register tiles, VGPRs at 2 waves per SIMD); asm-agpr = inline asm, "a" constraint
+//   data : 0 random operands (N(0, 0.5)), 1 zeros (the DVFS give-back case: what "peak" benchmarks on zero-filled buffers measure)
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o mfma_power_probe_bin mfma_power_probe.hip -lpthread
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <glob.h>
+#include <string>
+#include <thread>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ bf16x8_t lds_read16(const char* p) {
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)p) : "memory");
+    return v;
+}
+
+template <int SHAPE, bool LDS, bool AGPR, int WPS>
+__global__ __launch_bounds__(WPS * 256) void probe(const bf16x8_t* __restrict__ src, float* out, int iters, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 64 KiB of operand image in LDS (random), lane-linear 1 KiB pieces: a ds_read_b128 of piece q by lane l reads smem + q * 1024 + l * 16 (conflict-free)
+    for (int i = tid; i < 4096; i += blockDim.x) ((bf16x8_t*)smem)[i] = src[(blockIdx.x * 4096 + i) & 0xffff];
+    __syncthreads();
+    const char* base = smem + lane * 16 + (wave & 3) * 8192;
+    unsigned long long c0 = 0, r0 = 0;
+    if (tid == 0) { c0 = __builtin_readcyclecounter(); r0 = wall_clock64(); }
+    float r = 0.f;
+    if constexpr (SHAPE == 0) {
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        bf16x8_t fa[2][8], fb[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[s][i] = lds_read16(base + (s * 12 + i) * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[s][j] = lds_read16(base + (s * 12 + 8 + j) * 1024);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(fa[s][i]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(fb[s][j]));
+        }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if constexpr (LDS) {      // the other k-half's fragments for the NEXT use, requested ahead of this half's MFMAs
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) fa[h ^ 1][i] = lds_read16(base + (((it + h) & 1) * 24 + (h ^ 1) * 12 + i) * 1024);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[h ^ 1][j] = lds_read16(base + (((it + h) & 1) * 24 + (h ^ 1) * 12 + 8 + j) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[h][j]), "v"(fa[h][i]));
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[h][j], fa[h][i], acc[i][j], 0, 0, 0);
+                    }
+                if constexpr (LDS) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(fa[h ^ 1][i]));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(fb[h ^ 1][j]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if constexpr (AGPR) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    } else {
+        constexpr int NJ = SHAPE == 1 ? 4 : 2;      // shape 2: wave tile 128 x 64 = 4 x 2 tiles of 32x32x16 (gemm8p's wave tile with the larger MFMA; fits 2 waves per SIMD)
+        f32x16_t acc[4][NJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        bf16x8_t fa[2][4], fb[2][NJ];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fa[s][i] = lds_read16(base + (s * 8 + i) * 1024); if (i < NJ) fb[s][i] = lds_read16(base + (s * 8 + 4 + i) * 1024); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(fa[s][i])); if (i < NJ) asm volatile("" : "+v"(fb[s][i])); }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                constexpr int dummy = 0; (void)dummy;
+                const int s = q & 1;
+                if constexpr (LDS) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        fa[s ^ 1][i] = lds_read16(base + ((((q + 1) & 3) * 8 + i)) * 1024);
+                        if (i < NJ) fb[s ^ 1][i] = lds_read16(base + ((((q + 1) & 3) * 8 + 4 + i)) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[s][j]), "v"(fa[s][i]));
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);
+                    }
+                if constexpr (LDS) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(fa[s ^ 1][i])); if (i < NJ) asm volatile("" : "+v"(fb[s ^ 1][i])); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if constexpr (AGPR) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) r += acc[i][j][e];
+    }
+    if (tid == 0) {
+        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+        stamps[blockIdx.x * 2] = c1 - c0; stamps[blockIdx.x * 2 + 1] = r1 - r0;
+    }
+    if (r == 12345.678f) out[tid] = r;
+}
+
+struct Sample { double w; double mhz; };
+static std::atomic<bool> g_stop{false};
+static std::vector<Sample> g_samples;
+static std::string g_power_path, g_freq_path;
+
+static bool read_num(const std::string& p, double& v) {
+    FILE* f = fopen(p.c_str(), "r"); if (!f) return false;
+    const int ok = fscanf(f, "%lf", &v); fclose(f); return ok == 1;
+}
+static void find_sysfs() {
+    for (const char* pat : {"/sys/class/drm/card*/device/hwmon/hwmon*/power1_average", "/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"}) {
+        glob_t g; if (glob(pat, 0, nullptr, &g) == 0 && g.gl_pathc > 0) { double v; for (size_t i = 0; i < g.gl_pathc; ++i) if (read_num(g.gl_pathv[i], v) && v > 0) { g_power_path = g.gl_pathv[i]; break; } }
+        globfree(&g); if (!g_power_path.empty()) break;
+    }
+    glob_t g; if (glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input", 0, nullptr, &g) == 0 && g.gl_pathc > 0) g_freq_path = g.gl_pathv[0];
+    globfree(&g);
+}
+static Sample smi_sample() {
+    Sample s{0, 0};
+    FILE* p = popen("rocm-smi --showclocks --showpower 2>/dev/null", "r"); if (!p) return s;
+    char line[512];
+    while (fgets(line, sizeof line, p)) {
+        const char* q;
+        if ((q = strstr(line, "sclk clock level")) && (q = strchr(q, '('))) s.mhz = atof(q + 1);
+        if (strstr(line, "Power (W)") && (q = strrchr(line, ':'))) s.w = atof(q + 1);
+    }
+    pclose(p); return s;
+}
+static void poll_thread(bool use_smi) {
+    while (!g_stop.load()) {
+        Sample s{0, 0};
+        if (!use_smi) { double v; if (read_num(g_power_path, v)) s.w = v * 1e-6; if (!g_freq_path.empty() && read_num(g_freq_path, v)) s.mhz = v * 1e-6; std::this_thread::sleep_for(std::chrono::milliseconds(50)); }
+        else s = smi_sample();
+        g_samples.push_back(s);
+    }
+}
+
+template <int SHAPE, bool LDS, bool AGPR, int WPS>
+static void run(const char* name, const bf16x8_t* src, float* out, unsigned long long* stamps, double seconds, int grid, bool use_smi) {
+    constexpr int wps = WPS; const int threads = wps * 256, lds = 65536 + 8192;
+    HIPCHECK(hipFuncSetAttribute((const void*)probe<SHAPE, LDS, AGPR, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int iters = 20000;      // 64 MFMAs each: >= 20 ms per launch
+    hipEvent_t e0, e1; HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((probe<SHAPE, LDS, AGPR, WPS>), dim3(grid), dim3(threads), lds, 0, src, out, 2000, stamps);
+    HIPCHECK(hipDeviceSynchronize());
+    g_samples.clear(); g_stop = false;
+    std::thread th(poll_thread, use_smi);
+    const auto t0 = std::chrono::steady_clock::now();
+    int launches = 0;
+    HIPCHECK(hipEventRecord(e0));
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+        for (int i = 0; i < 4; ++i) hipLaunchKernelGGL((probe<SHAPE, LDS, AGPR, WPS>), dim3(grid), dim3(threads), lds, 0, src, out, iters, stamps);
+        launches += 4;
+        HIPCHECK(hipStreamSynchronize(0));
+    }
+    HIPCHECK(hipEventRecord(e1)); HIPCHECK(hipEventSynchronize(e1));
+    g_stop = true; th.join();
+    float ms = 0; HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> st(grid * 2);
+    HIPCHECK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, real = 0; for (int b = 0; b < grid; ++b) { cyc += st[b * 2]; real += st[b * 2 + 1]; }
+    const double flops_per_wave_iter = SHAPE == 1 ? 2.0 * 128 * 128 * 64 : 2.0 * 128 * 64 * 64;
+    const int mfma_per_iter = SHAPE == 2 ? 32 : 64;
+    const double flops = flops_per_wave_iter * (wps * 4) * grid * (double)iters * launches;
+    const double tf = flops / (ms * 1e-3) / 1e12;
+    const double mhz_kernel = cyc / real * 100.0;      // s_memrealtime ticks at 100 MHz
+    const double cyc_per_mfma = (cyc / grid) / ((double)iters * mfma_per_iter * wps);      // SIMD cycles per MFMA issued on that SIMD (both waves counted)
+    // drop the first 30 % of the samples (ramp), average the rest
+    double w = 0, mhz = 0; int n = 0; const size_t skip = g_samples.size() * 3 / 10;
+    for (size_t i = skip; i < g_samples.size(); ++i) { if (g_samples[i].w > 0) { w += g_samples[i].w; mhz += g_samples[i].mhz; ++n; } }
+    if (n) { w /= n; mhz /= n; }
+    printf("%-34s wps %d grid %3d | %7.1f TF/s | sclk(kernel stamps) %6.0f MHz | %5.2f cyc/MFMA/SIMD | socket %6.0f W  sclk(host) %5.0f MHz  (%d samples) | %6.2f pJ/flop | frac of 2500: %.3f, of clock-adjusted peak: %.3f\n",
+           name, wps, grid, tf, mhz_kernel, cyc_per_mfma, w, mhz, n, w > 0 ? w / (tf * 1e12) * 1e12 : 0.0, tf / 2500.0, tf / (2500.0 * mhz_kernel / 2400.0));
+    fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    const double seconds = argc > 1 ? atof(argv[1]) : 2.5;
+    find_sysfs();
+    // (sysfs lists every GPU of the node, the visible one is not necessarily card0: rocm-smi honours the container's device visibility)
+    const bool use_smi = !getenv("PROBE_SYSFS") || g_power_path.empty();
+    printf("# power source: %s ; clock source: %s\n", use_smi ? "rocm-smi" : g_power_path.c_str(), use_smi ? "rocm-smi" : (g_freq_path.empty() ? "(none)" : g_freq_path.c_str()));
+    { Sample s = smi_sample(); printf("# idle (rocm-smi): %.0f W, sclk %.0f MHz\n", s.w, s.mhz); }
+    hipDeviceProp_t pr; HIPCHECK(hipGetDeviceProperties(&pr, 0));
+    const int cus = pr.multiProcessorCount;
+    printf("# %s, %d CUs; %.1f s per variant; cyc/MFMA/SIMD floors: 16x16x32 = 16, 32x32x16 = 32\n", pr.gcnArchName, cus, seconds);
+    bf16x8_t *rnd, *zero; float* out; unsigned long long* stamps;
+    HIPCHECK(hipMalloc(&rnd, 65536 * 16)); HIPCHECK(hipMalloc(&zero, 65536 * 16)); HIPCHECK(hipMalloc(&out, 4096)); HIPCHECK(hipMalloc(&stamps, 4096 * 16));
+    {
+        std::vector<unsigned short> h(65536 * 8);
+        unsigned long long s = 0x9E3779B97F4A7C15ull;
+        auto u = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0; };
+        for (auto& x : h) { const double g = (u() + u() + u() + u() - 2.0) * 0.866;      // ~N(0, 0.25): sigma 0.5
+            float f = (float)g; unsigned int b; memcpy(&b, &f, 4); x = (unsigned short)((b + 0x7fff + ((b >> 16) & 1)) >> 16); }
+        HIPCHECK(hipMemcpy(rnd, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemset(zero, 0, 65536 * 16));
+    }
+    const bool small_too = argc > 2 && atoi(argv[2]) != 0;
+    for (int grid : {cus, 16}) {
+        if (grid == 16 && !small_too) continue;      // 16 CUs: far below the power cap -- the issue-rate ceiling of the same code at full clock
+        printf("## grid %d blocks (one per CU)\n", grid);
+        run<1, false, false, 1>("32x32x16 regs builtin  random", rnd, out, stamps, seconds, grid, use_smi);
+        run<1, false, true, 1>("32x32x16 regs asm-agpr random", rnd, out, stamps, seconds, grid, use_smi);
+        run<2, false, false, 2>("32x32x16 128x64-tile regs random", rnd, out, stamps, seconds, grid, use_smi);
+        run<0, false, false, 1>("16x16x32 regs builtin  random", rnd, out, stamps, seconds, grid, use_smi);
+        run<0, false, true, 1>("16x16x32 regs asm-agpr random", rnd, out, stamps, seconds, grid, use_smi);
+        run<0, false, false, 2>("16x16x32 regs builtin  random", rnd, out, stamps, seconds, grid, use_smi);
+        run<1, true, false, 1>("32x32x16 +LDS  builtin  random", rnd, out, stamps, seconds, grid, use_smi);
+        run<1, true, true, 1>("32x32x16 +LDS  asm-agpr random", rnd, out, stamps, seconds, grid, use_smi);
+        run<0, true, false, 2>("16x16x32 +LDS  builtin  random", rnd, out, stamps, seconds, grid, use_smi);
+        run<2, true, false, 2>("32x32x16 128x64-tile +LDS random", rnd, out, stamps, seconds, grid, use_smi);
+        run<1, false, false, 1>("32x32x16 regs builtin  ZEROS", zero, out, stamps, seconds, grid, use_smi);
+        run<0, false, false, 2>("16x16x32 regs builtin  ZEROS", zero, out, stamps, seconds, grid, use_smi);
+    }
+    return 0;
+}
