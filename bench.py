@@ -98,7 +98,7 @@ def build_model(seed=7122, large=False, cascaded=False, vocab=8112, finetune_lay
     return KWClip_GeneralTransformer(cfg).eval()
 
 
-def make_batch(B, L, rank=0, dev="cuda", varlen=False):
+def make_batch(B, L, rank=0, dev="cuda", varlen=False, lo=32000):
     """The synthetic batch of the timed region: seed 7122 + rank, waves 0.1 * randn (every wave L samples, or
     L_i ~ U{32000..L} zero-padded to the batch maximum as collate_general hands it over), images randn [B, 3, 224, 224], unique ids.
     tests/test_headline_parity_gpu.py checks the HIP path against the fp32 oracle on THIS batch."""
@@ -106,7 +106,7 @@ def make_batch(B, L, rank=0, dev="cuda", varlen=False):
     wav = (0.1 * torch.randn(B, L, generator=g)).to(dev)
     lens = [L] * B
     if varlen:
-        lens = [int(x) for x in torch.randint(min(32000, L), L + 1, (B,), generator=g)]
+        lens = [int(x) for x in torch.randint(min(lo, L), L + 1, (B,), generator=g)]
         wav = wav[:, :max(lens)].contiguous()
         wav *= (torch.arange(wav.shape[1], device=dev)[None, :] < torch.tensor(lens, device=dev)[:, None])
     batch = {"wav": wav, "wav_len": torch.tensor(lens, dtype=torch.long), "image": torch.randn(B, 3, 224, 224, generator=g).to(dev),
@@ -248,7 +248,9 @@ def parity_check(model, keep, dev):
     return out
 
 
-OTHER_CONFIGS = ("cascaded_v8112", "large_b64", "varlen_packed", "varlen_padded", "train")
+MFMA_POWER_CAPPED_TFLOPS = 2150.0          # profiles/r06_mfma_power_ceiling.txt: 16x16x32 bf16, random operands, MFMA-only, power-capped socket
+MFMA_POWER_CAPPED_LDS_TFLOPS = 1750.0      # the same with the GEMM k-loop's fragment reads (ds_read_b128 at the loop's read : MFMA ratio)
+OTHER_CONFIGS = ("cascaded_v8112", "large_b64", "large_b64_ragged", "varlen_packed", "varlen_padded", "train")
 
 
 def other_config(kind, dev, batch=None, steps=5, warmup=2):
@@ -256,14 +258,16 @@ def other_config(kind, dev, batch=None, steps=5, warmup=2):
     line carries every BASELINE.json config.  Never part of `value`.
       cascaded_v8112  configs[2]  Cascaded SpeechCLIP base, reduced vocabulary of 8112 sub-words, B = 256, 10 s
       large_b64       configs[4]  Parallel SpeechCLIP large (HuBERT-large + ViT-L/14), 64 pairs per GPU (model_large/coco/spchclp_p.yaml:10 over 4 GPUs), 10 s
+      large_b64_ragged  configs[4] as SURVEY.md section 8d C5 specifies it: SpokenCOCO-shaped RAGGED batch, L_i ~ U{48000..160000}, padding-free engine
       varlen_packed / varlen_padded   configs[1] with L_i ~ U{32000..160000}: padding-free engine vs the reference's padded layout (SC_VARLEN_PACK=0)
       train           configs[1] training step of the trainable tail (train-mode crop to 102400 samples, loss.backward(), clip, Adam, LR schedule)"""
     from speechclip_amd import parallel
-    large, casc, train, varlen = kind == "large_b64", kind == "cascaded_v8112", kind == "train", kind.startswith("varlen")
+    large, casc, train = kind.startswith("large_b64"), kind == "cascaded_v8112", kind == "train"
+    varlen = kind.startswith("varlen") or kind == "large_b64_ragged"
     model = build_model(large=large, cascaded=casc).to(dev)
     B = batch or (64 if large else 256)
     L = 160000
-    b, lens = make_batch(B, L, 0, dev, varlen)
+    b, lens = make_batch(B, L, 0, dev, varlen, lo=48000 if kind == "large_b64_ragged" else 32000)
     old_pack = os.environ.get("SC_VARLEN_PACK")
     if kind == "varlen_padded":
         os.environ["SC_VARLEN_PACK"] = "0"
@@ -420,7 +424,12 @@ def clock_under_load(step, fence, seconds=1.2):
     pw = sorted(s[1] for s in busy)[len(busy) // 2]
     return {"sclk_mhz_under_load": sclk, "socket_power_w": pw, "samples": len(busy), "steps_run": n,
             "mfma_peak_at_this_clock_tflops": round(2500.0 * sclk / 2400.0, 1),
-            "note": "rocm-smi polled during extra untimed steps; the 2500 TF/s roofline peak is the 2.4 GHz figure"}
+            # what the matrix pipes of this socket sustain under its power cap on RANDOM register-resident operands, MFMAs only, >= 2.5 s
+            # (tools/probes/mfma_power_probe.hip, profiles/r06_mfma_power_ceiling.txt: v_mfma_f32_16x16x32_bf16 2151 TF/s at 2121 MHz / 1357 W;
+            #  32x32x16 1899-1917 TF/s at 1857-1871 MHz; with the k-loop's fragment reads 1720-1756).  A constant measured once, not in this run.
+            "mfma_power_capped_tflops": MFMA_POWER_CAPPED_TFLOPS, "mfma_power_capped_with_lds_reads_tflops": MFMA_POWER_CAPPED_LDS_TFLOPS,
+            "note": "rocm-smi polled during extra untimed steps; the 2500 TF/s roofline peak is the 2.4 GHz figure; mfma_power_capped_* from "
+                    "profiles/r06_mfma_power_ceiling.txt (random operands, MFMA-only / + the k-loop's ds_read traffic)"}
 
 
 def main():
@@ -849,6 +858,7 @@ def main():
             # the same achieved TF/s against the MFMA peak at the clock the socket actually held under this load (power-capped), beside the
             # nominal 2.4 GHz figure `frac` is priced against
             roof["frac_of_clock_adjusted_peak"] = round(roof["achieved"] / clock["mfma_peak_at_this_clock_tflops"], 4)
+            roof["frac_of_power_capped_mfma_ceiling"] = round(roof["achieved"] / MFMA_POWER_CAPPED_TFLOPS, 4)
         if clock is not None:
             clock["joules_per_step"] = round(clock["socket_power_w"] * dt / args.steps, 2)
             clock["joules_per_pair"] = round(clock["socket_power_w"] * dt / args.steps / (world * B), 4)

@@ -59,10 +59,6 @@ int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
 int sc_set_gemm_workspace(void* workspace, int64_t bytes);
 int sc_gemm_last_path(void);   /* instrumentation: which kernel the last sc_gemm_bf16 call ran on: 0 gemm256_kernel / gemm_bf16_kernel, 1 the vendor
                                 * library (comparator), 3 gemm8p_pers_kernel (ping-pong schedule, gemm8p.hip) -- 0 and 3 are the hand-written kernels */
-/* Developer / test switch between the hand-written GEMM kernels: -1 dispatcher's rule (default: gemm8p from 128 tiles up, N % 256 == 0, N <= 8192),
- * 0 gemm256_kernel / gemm_bf16_kernel only, 16 gemm8p whenever the shape allows; 17-26 A/B variants of it (per-tile launch, K rotation, tap-paired K walk,
- * column bands, 26 = static instead of dynamic tile order). */
-void sc_debug_set_gemm_mode(int mode);
 /* instrumentation (comparator only): which half of the comparator workspace `stream` owns: 0 / 1, -1 none yet, -2 both halves belong to other
  * streams (that stream's GEMMs run on the hand-written kernels), -3 comparator library not loaded.  The comparator ABI itself is declared once,
  * in speechclip_amd/csrc/vendor/vendor_abi.h, for both libraries. */
@@ -97,23 +93,6 @@ int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, const float* 
 #define SC_WS_IN_F32 0x2
 int sc_weighted_sum_fwd(const void* hidden, int64_t layer_stride, const float* weights, void* out, int n_layers,
                         int64_t rows, int D, int flags, float eps, void* stream);
-
-/* ---- LayerNorm folded into the GEMMs on both sides of it: the eval path of fairseq's POST-LN TransformerSentenceEncoderLayer
- * (speech_encoder_plus.py:52 -> x = LN1(x + SA(x)); x = LN2(x + FFN(x))) without a separate LayerNorm pass over the [B*T, 768] rows.
- *   mode 1: C = act(rstd_m (A W'^T - mean_m c) + bias)   A = PRE-norm rows, W' = gamma (.) W, c_n = sum_k W'[n,k], bias = W beta + b
- *   mode 2: C = A W^T + bias + LN(residual)               residual = PRE-norm rows; its LayerNorm is rebuilt per element from res_stats [M,2] =
- *           (mean, rstd), res_gamma / res_beta [N] and rounded to bf16 as the stand-alone kernel would; the per-(row, 64-column strip) partial
- *           (sum, sum of squares) of the stored C go to ln_partial [M, N/64, 2].
- * sc_ln_stats_finalize turns the partials into (mean, rstd) [M,2].  sc_weighted_sum_ln_fwd is WeightedSumLayer (weighted_sum.py:26-45) over
- * those pre-norm rows (h0 = the normalised layer-0 state; ypre = layers 1..n-1 at stride layer_stride; gamma/beta [n-1, D]).
- * sc_gemm_bf16_ln returns 1 without launching when the shape is outside the 256x256-tile kernel's rules (M, N >= 256, K % 64 == 0, mode 2:
- * N % 256 == 0): run sc_layernorm + sc_gemm_bf16 instead. */
-int sc_gemm_bf16_ln(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* residual,
-                    int64_t ldr, int64_t M, int N, int K, int flags, int mode, const float* ln_stats, const float* ln_c, const float* res_stats,
-                    const float* res_gamma, const float* res_beta, float* ln_partial, void* stream);
-int sc_ln_stats_finalize(const float* partial, int nparts, float* stats, int64_t rows, int D, float eps, void* stream);
-int sc_weighted_sum_ln_fwd(const void* h0, const void* ypre, int64_t layer_stride, const float* gamma, const float* beta, const float* weights,
-                           void* out, int n_layers, int64_t rows, int D, float eps, void* stream);
 
 /* ---- L2 normalise -- avssl/model/kwClip.py:1436,:1444-1454 (x / ||x||, no eps), f32 out.  SC_L2NORM_CLAMP: x / max(||x||, 1e-8), the
  * operand normalisation of F.cosine_similarity (kwClip.py:889-897) -- a zero row gives zeros, not NaN ------- */

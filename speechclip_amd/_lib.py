@@ -35,8 +35,13 @@ def lib():
         _declare(_lib)
         # SC_GEMM_KERNEL_MODE: developer override of the bf16 GEMM kernel choice (sc_debug_set_gemm_mode: 0 = gemm256_kernel only, 16 = gemm8p wherever
         # the shape allows, ...), for in-step A/B timing; unset = the dispatcher's rule
-        if os.environ.get("SC_GEMM_KERNEL_MODE"):
-            _lib.sc_debug_set_gemm_mode(int(os.environ["SC_GEMM_KERNEL_MODE"]))
+        mode = os.environ.get("SC_GEMM_KERNEL_MODE")
+        if mode:
+            try:
+                _lib.sc_debug_set_gemm_mode(int(mode))
+            except ValueError:
+                import warnings
+                warnings.warn(f"SC_GEMM_KERNEL_MODE={mode!r} is not an integer: ignored")
     return _lib
 
 
@@ -62,9 +67,6 @@ def _declare(L):
         "sc_colsum_bf16": ([P, L64, L64, I, P, P, I, P], c_int),
         "sc_axpy_bf16": ([P, P, F, L64, P], c_int),
         "sc_cls_pool_dz": ([P, P, P, P, P, P, I, I, I, I, I, L64, P], c_int),
-        "sc_gemm_bf16_ln": ([P, L64, P, L64, P, L64, P, P, L64, L64, I, I, I, I, P, P, P, P, P, P, P], c_int),
-        "sc_ln_stats_finalize": ([P, I, P, L64, I, F, P], c_int),
-        "sc_weighted_sum_ln_fwd": ([P, P, L64, P, P, P, P, I, L64, I, F, P], c_int),
         "sc_l2norm_fwd": ([P, L64, P, L64, I, I, P], c_int),
         "sc_splitk_reduce_f32": ([P, I, L64, I, P, P, L64, P, I, P], c_int),
         "sc_hidden_normalize": ([P, I, I, I, I, I, I, I, P, P], c_int),
@@ -116,7 +118,8 @@ def _declare(L):
         "sc_layernorm_bwd": ([P, P, P, P, P, P, P, I, I, F, I, P], c_int),
         "sc_gelu_f32": ([P, P, L64, I, P], c_int),
         "sc_gemm_last_path": ([], c_int),
-        "sc_debug_set_gemm_mode": ([I], None),
+        "sc_debug_set_gemm_mode": ([I], None),          # developer / test switch: exported, not in include/speechclip_hip.h
+        "sc_debug_poison_gemm_sched": ([], c_int),      # test hook: exported, not in the header
         "sc_debug_vendor_stream_slot": ([P], c_int),
         "sc_split_hilo_bf16": ([P, L64, P, L64, I, I, P], c_int),
         "sc_cosine_refine": ([P, P, P, I, I, I, F, F, P], c_int),

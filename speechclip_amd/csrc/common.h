@@ -71,10 +71,14 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {   // two values: the p
 // 1.06x the rms error of rounding the exact value to bf16 (absolute error <= ~1e-3, in the negative tail where 0.5 + xc g cancels in half
 // precision): below the resolution of the bf16 activations it feeds.  Measured: -0.62 ms per step (44.52-44.56 vs 45.07-45.21, three interleaved
 // passes), end-to-end parity metrics unchanged (centred cosines 0.9925-0.9995 on the same fixtures, loss equal to 5 digits).
-// Round 6: degree 4 (default), fitted on |x| <= 3.3 (minimax for the error of x Phi; beyond, the even-degree g with its positive leading coefficient grows and
-// the clamp of Phi saturates, as for degree 6): 11 instead of 13 VALU instructions per value pair in the VALU-bound GELU epilogue.  Numpy float16 simulation of
-// this exact instruction sequence on EVERY finite bf16 input (the test below feeds them through the kernel): rms error 1.065x the rms of rounding the exact
-// erf-GELU to bf16 (degree 6: 1.015x), worst |error| / test tolerance 0.53, saturation exact beyond |x| = 5.5.  -DSC_GELU_DEG=6: rounds 3-5.
+// Round 6: degree 4 (default): 11 instead of 13 VALU instructions per value pair in the VALU-bound GELU epilogue.  The fit is a DENSITY-WEIGHTED least-squares
+// fit of the error of x Phi on |x| <= 3.2 (weight: the mixture N(0, 0.6^2) / N(0, 1.5^2) that brackets the pre-activations of the conv stack and of fc1), not a
+// minimax one: an approximation error is a smooth function of x, i.e. SYSTEMATIC -- it adds up coherently in the next GEMM's K sum where rounding noise averages
+// out.  Measured in the fp32 oracle with only the GELU replaced (P-base, 4 pairs; 1 - mean centred cosine of the audio embedding): output rounding to bf16 alone
+// 4.7e-4, degree 6 5.9e-4, this fit 6.6e-4, the minimax degree-4 fit tried first 2.1e-3 (the same minimax fit on the GPU: bench parity_check 0.99659 -> 0.99425).
+// Beyond the fitted range the even-degree g with its positive leading coefficient grows and the clamp of Phi saturates, as for degree 6.  Numpy float16 simulation
+// of this exact instruction sequence on EVERY finite bf16 input (tests/test_gemm8p_gpu.py feeds them through the kernel): rms error 1.035x the rms of rounding the
+// exact erf-GELU to bf16 (degree 6: 1.015x), worst |error| / test tolerance 0.70, saturation exact beyond |x| = 5.5.  -DSC_GELU_DEG=6: rounds 3-5.
 #ifndef SC_GELU_DEG
 #define SC_GELU_DEG 4
 #endif
@@ -96,10 +100,10 @@ __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
     const sc_half2_t t = h * h * (_Float16)0.125f - (_Float16)1.0f;
 #endif
 #if SC_GELU_DEG == 4
-    sc_half2_t g = t * (_Float16)0.048675537109375f + (_Float16)-0.034210205078125f;
-    g = g * t + (_Float16)0.051544189453125f;
-    g = g * t + (_Float16)-0.08453369140625f;
-    g = g * t + (_Float16)0.176025390625f;
+    sc_half2_t g = t * (_Float16)0.067138671875f + (_Float16)-0.01300048828125f;
+    g = g * t + (_Float16)0.055389404296875f;
+    g = g * t + (_Float16)-0.08575439453125f;
+    g = g * t + (_Float16)0.1759033203125f;
 #elif SC_GELU_DEG == 5
     sc_half2_t g = t * (_Float16)-1.177580447e-02f + (_Float16)2.993807372e-02f;
     g = g * t + (_Float16)-3.959858472e-02f;
@@ -134,7 +138,7 @@ __device__ __forceinline__ void gelu_poly2_x8(f32x2_t (&x)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = SC_GELU_TCLAMP ? __builtin_elementwise_min(t[i] * (_Float16)0.125f - (_Float16)1.0f, one) : t[i] * (_Float16)0.125f - (_Float16)1.0f;
 #if SC_GELU_DEG == 4
-    const float c[5] = {0.048675537109375f, -0.034210205078125f, 0.051544189453125f, -0.08453369140625f, 0.176025390625f};
+    const float c[5] = {0.067138671875f, -0.01300048828125f, 0.055389404296875f, -0.08575439453125f, 0.1759033203125f};
     constexpr int NC = 5;
 #elif SC_GELU_DEG == 5
     const float c[6] = {-1.177580447e-02f, 2.993807372e-02f, -3.959858472e-02f, 5.414790186e-02f, -8.377277171e-02f, 1.760021146e-01f};

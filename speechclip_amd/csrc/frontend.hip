@@ -142,13 +142,16 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
 // GELU polynomial and the bf16 pack; the output leaves through the GEMM epilogue's quad-contiguous store (permlane swap + crossbar
 // transpose: 16 frames x 64 contiguous bytes per store instruction).  Block = one utterance x FB frames, 4 waves x 16-frame groups.
 // W fragments, built once per utterance: wfrag[b][cb][lane] (16 bytes) = channel cb*16 + (lane & 15), k-slots (lane >> 4)*8 .. +7
-// (slot -> (kind, tap): 0-9 w_hi, 10-19 w_hi, 20-29 w_lo, 30-31 zero), weights pre-multiplied by the GroupNorm scale of (b, channel).
-__global__ __launch_bounds__(256) void conv0_wfrag_kernel(const float* __restrict__ w, const float2* __restrict__ coef, bf16x8_t* __restrict__ wfrag, int C, int mode) {
+// (slot -> (kind, tap): 0-9 w_hi, 10-19 w_hi, 20-29 w_lo, 30 / 31 the shift's bf16 hi / lo halves), weights pre-multiplied by the GroupNorm scale of (b, channel).
+__global__ __launch_bounds__(256) void conv0_wfrag_kernel(const float* __restrict__ w, const float2* __restrict__ coef, const float* __restrict__ bias, bf16x8_t* __restrict__ wfrag,
+                                                          int C, int mode) {
     const int b = blockIdx.x, ncb = C / 16;
     for (int i = threadIdx.x; i < 32 * 64; i += 256) {
         const int cb = i >> 6, lane = i & 63, frow = lane & 15, fk = lane >> 4;
         const int c = cb * 16 + frow;
         const float scl = (cb < ncb) ? (mode == 0 ? coef[(int64_t)b * C + c].x : 1.0f) : 0.f;
+        const float shift = (cb < ncb) ? (mode == 0 ? coef[(int64_t)b * C + c].y : (bias ? bias[c] : 0.f)) : 0.f;
+        const __bf16 shift_hi = (__bf16)shift;
         bf16x8_t f;
 #pragma unroll
         for (int sidx = 0; sidx < 8; ++sidx) {
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void conv0_wfrag_kernel(const float* __restric
             const int tap = slot % CK, kind = slot / CK;
             const float wv = (cb < ncb && slot < 30) ? w[c * CK + tap] * scl : 0.f;
             const __bf16 hi = (__bf16)wv;
-            f[sidx] = kind == 2 ? (__bf16)(wv - (float)hi) : hi;
+            f[sidx] = slot == 30 ? shift_hi : slot == 31 ? (__bf16)(shift - (float)shift_hi) : kind == 2 ? (__bf16)(wv - (float)hi) : hi;
         }
         wfrag[((int64_t)b * 32 + cb) * 64 + lane] = f;
     }
@@ -167,8 +170,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
                                                          int C, int T0, int P_uniform, int mode, const int32_t* __restrict__ row_off, int row_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_c0[];
     bf16x8_t* wl = (bf16x8_t*)smem_c0;                    // [32][64] W fragments (32 KiB)
-    float* shs = (float*)(smem_c0 + 32 * 64 * 16);        // [512] per-channel shift (GroupNorm shift or conv bias)
-    float* xs = shs + 512;                                // FB * 5 + 8 samples
+    float* xs = (float*)(smem_c0 + 32 * 64 * 16);         // FB * 5 + 8 samples
     const int b = blockIdx.y, t0 = blockIdx.x * FB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // packed batches: utterance b owns output rows [row_scale * row_off[b], row_scale * row_off[b + 1]) (row_off counts transformer frames,
     // row_scale = the conv stack's total stride after layer 0); frames >= T0 are written as zeros as in the uniform layout
@@ -182,11 +184,6 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
         xs[i] = si < L ? x[si] : 0.f;
     }
     for (int i = tid; i < 32 * 64; i += 256) wl[i] = wfrag[(int64_t)b * 32 * 64 + i];
-    for (int c = tid; c < 512; c += 256) {
-        float sh = 0.f;
-        if (c < C) sh = mode == 0 ? coef[(int64_t)b * C + c].y : (bias ? bias[c] : 0.f);
-        shs[c] = sh;
-    }
     const int frow = lane & 15, fk = lane >> 4;
     const int ncb = C / 16;
     const int srow = lane >> 2, schunk = lane & 3;       // epilogue lane geometry (as gemm256_kernel)
@@ -195,16 +192,16 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
     const int ngroups = nfr / 16;                         // P is a multiple of 64
     for (int gidx = wave; gidx < ngroups; gidx += 4) {
         const int tg = t0 + gidx * 16;                    // first frame of the group
-        // X fragment: frame tg + frow, slots fk*8..+7 (0-9 x_hi, 10-19 x_lo, 20-29 x_hi)
+        // X fragment: frame tg + frow, slots fk*8..+7 (0-9 x_hi, 10-19 x_lo, 20-29 x_hi, 30-31 one: the shift's slots)
         bf16x8_t xf;
         const float* xr = xs + (gidx * 16 + frow) * CS;
 #pragma unroll
         for (int sidx = 0; sidx < 8; ++sidx) {
             const int slot = fk * 8 + sidx;
             const int tap = slot % CK, kind = slot / CK;
-            const float xv = slot < 30 ? xr[tap] : 0.f;
+            const float xv = slot < 30 ? xr[tap] : 1.0f;
             const __bf16 hi = (__bf16)xv;
-            xf[sidx] = kind == 1 ? (__bf16)(xv - (float)hi) : hi;
+            xf[sidx] = (kind == 1 && slot < 30) ? (__bf16)(xv - (float)hi) : hi;
         }
         const bool live_row = (tg + srow) < T0;           // frames in [T0, P) are written as zeros
         bf16_t* orow = out + (orow0 + tg + srow) * C + schunk * 8;
@@ -222,7 +219,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
             uint2 pk[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4_t v4 = acc[q & 1][j] + *(const f32x4_t*)(shs + (q * 4 + j) * 16 + fk * 4);
+                f32x4_t v4 = acc[q & 1][j];
                 if (mode == 0) {
                     const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
                     v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
@@ -420,11 +417,11 @@ static int conv0_fwd_impl(const float* wav, int64_t ld, int64_t L, const float* 
     static const bool force_valu = getenv("SC_CONV0_VALU") != nullptr;
     if (C % 64 == 0 && P % 64 == 0 && (!force_valu || row_off)) {      // matrix-core form (every shipped config: C = 512)
         SC_CHECK_ARG(wfrag_ws != nullptr, "sc_conv0_fwd: the matrix-core form needs the W-fragment workspace (sc_conv0_wfrag_workspace_bytes)");
-        hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, w, (const float2*)coef, (bf16x8_t*)wfrag_ws, C, mode);
+        hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, w, (const float2*)coef, bias, (bf16x8_t*)wfrag_ws, C, mode);
         SC_CHECK_LAUNCH();
         static const int fb = getenv("SC_CONV0_FB") ? atoi(getenv("SC_CONV0_FB")) : 256;   // measured 128..2048: 256 is the fastest
 #define CONV0_LAUNCH(FB_) do {                                                                                                                   \
-        const int lds = 32 * 64 * 16 + (512 + FB_ * CS + 16) * 4;                                                                                  \
+        const int lds = 32 * 64 * 16 + (FB_ * CS + 16) * 4;                                                                                  \
         (void)hipFuncSetAttribute((const void*)conv0_mfma_kernel<FB_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                           \
         hipLaunchKernelGGL(conv0_mfma_kernel<FB_>, dim3((P + FB_ - 1) / FB_, B), dim3(256), lds, (hipStream_t)stream, wav, ld, L,                  \
                            (const bf16x8_t*)wfrag_ws, bias, (const float2*)coef, (bf16_t*)out, C, T0, P, mode, row_off, row_scale); } while (0)

@@ -34,11 +34,6 @@ struct GemmParams {
     int band;                    // N-tiles per column band of the persistent tile order (0/>=tiles_n: M-panel-major over all of N)
     int epi_mode, epi_mode_res;                // next tile's first two stages: 0 issued before the epilogue, 2 interleaved with its stores (default), 3 after it
     // LayerNorm folded into the GEMMs around it (sc_gemm_bf16_ln; post-LN transformer layers, eval path):
-    const float* ln_stats;                     // EPI 1: [M,2] (mean, rstd) of the LayerNorm whose output is the A operand; A holds the PRE-norm rows, W = gamma (.) W
-    const float* ln_c;                         // EPI 1: [N] c_n = sum_k W'[n,k]   =>  out = rstd_m (acc - mean_m c_n) + bias_n   (bias = W beta + b)
-    const float* res_stats;                    // EPI 2: [M,2] stats of the LayerNorm whose output is the RESIDUAL; `residual` holds the pre-norm rows
-    const float* res_gamma; const float* res_beta;   // EPI 2: [N] affine of that LayerNorm
-    float* ln_partial;                         // EPI 2: [M, 4*tiles_n, 2] per-(row, 64-column strip) partial (sum, sum of squares) of the OUTPUT rows
     int stagger;                               // PROBES: block group (b >> 3) & 3 sleeps g * stagger * 4096 cycles before its first tile (de-synchronised epilogues)
     int eprobe;                                // PROBES, fast epilogue only (garbage results): 1 no stores, 2 no next-tile DMA pieces, 4 stores wrap inside 2 MiB of C, 8 no shuffles;
                                                // 64 (valid results) streaming stores
@@ -242,12 +237,11 @@ __device__ __forceinline__ void stage256(const StageAddr& sa, int lane_a, int la
 // retirement: everything but the A pieces just issued).  Round 2, same box: whole step 46.1-46.3 ms vs 47.5 with the two-slot ring (GEMM 953-955
 // vs 919-921 TF/s in the step; QKV +4-6 % isolated).  What did NOT help with the third slot: prefetching A a k-step deeper with all 8 pieces still
 // in the second half (-6 ... +1 %: the loop is not latency-bound), and 4 + 4 pieces in two bursts (groups 4..7 of each half: -5 ... 0 %).
-// EPI: 0 plain; 1 the A operand is a pre-LayerNorm tensor (LN folded: W pre-scaled by gamma, per-row (mean, rstd) applied to the accumulator);
-// 2 the residual operand is a pre-LayerNorm tensor (reconstructed per element from its row statistics) and the per-row partial statistics of
-// the output are emitted for the NEXT LayerNorm.  bf16 vector path only (the dispatcher checks the shape rules).
+// (Rounds 2-5 carried two more epilogue forms here -- LayerNorm folded into the GEMMs on both sides of it, `sc_gemm_bf16_ln` -- opt-in and measured neutral to
+//  negative in the step (the HBM-bound LayerNorm launches are where the image tower's side stream overlaps): removed in round 6, EXPERIMENTS.md R6-4.)
 // BATCH: the persistent tile list runs over nbatch independent products of the same shape (the split-K partial products of a weight gradient:
 // speechclip_amd/train_hubert.py::wgrad); every tile carries its product index, the operands move by a per-product stride.  Plain epilogue only.
-template <int ABL, bool TRACE, int ACT, bool RES, bool RING3, int EPI = 0, bool BATCH = false>
+template <int ABL, bool TRACE, int ACT, bool RES, bool RING3, bool BATCH = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -510,7 +504,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                                                      (__attribute__((address_space(3))) void*)(sA2 + (wave * 4 + j) * 256), 4, 0, 0);
                 }
             };
-            const bool touch_here = RES && RING3 && SC_GEMM_RES_TOUCH && EPI == 0 && !BATCH && kt == nk - 2 && k2 < 0 && nk >= 3;
+            const bool touch_here = RES && RING3 && SC_GEMM_RES_TOUCH && !BATCH && kt == nk - 2 && k2 < 0 && nk >= 3;
             if (touch_here && SC_GEMM_RES_TOUCH == 1) touch_residual();
             else touched = 0;
             // MFMAs of (kt, h0); read (kt, h1); RING3: A pieces of stage kt+2 into the A slot stage kt-1 left free
@@ -546,14 +540,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             rotate_ring();      // sA0 / sW0: where stage nk would go = the next tile's stage 0
         }
         load_bias();    // (measured, round 3: loading them before the last half-step instead -- latency under 32 MFMAs -- costs +1.5 ms per step)
-        f32x4_t c4[4];
-        float2 rs_acc[8];
-        if (EPI == 1) {   // folded-LN operands in the accumulator layout: c for this lane's 16 columns, (mean, rstd) for its 8 rows
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c4[j] = *(const f32x4_t*)(p.ln_c + n0 + wn * 64 + j * 16 + fk * 4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) rs_acc[i] = *(const float2*)(p.ln_stats + 2 * (m0 + wm * 128 + i * 16 + frow));
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         // ---- next tile's first two stages fly during this tile's epilogue (the slots are free after this barrier:
@@ -583,7 +569,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         // row block i + 1's convert / permlane / crossbar shuffles are issued BEFORE row block i's stores, so the shuffle latency hides
         // under the stores and the next tile's LDS-DMA pieces.  sched_barrier between row blocks keeps the issue order of the vector-memory
         // operations what `tail_ops` below counts on.
-        const bool fast_epi = SC_GEMM_FAST_EPI && (!RES || SC_GEMM_FAST_EPI >= 2) && vec_ok && EPI == 0 && nhave && nk >= 2 && emode == 2 && m0 == m_lo && n0 == n_lo;
+        const bool fast_epi = SC_GEMM_FAST_EPI && (!RES || SC_GEMM_FAST_EPI >= 2) && vec_ok && nhave && nk >= 2 && emode == 2 && m0 == m_lo && n0 == n_lo;
         if (fast_epi) {
             bf16_t* Cb = (bf16_t*)p.C + c_off;
             const int srow = lane >> 2, schunk = lane & 3;
@@ -701,25 +687,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             // DMA pieces can only be waited for together with them; four row blocks (8 pieces) later those pieces have long landed.  With two ahead
             // the wait sat right behind fresh pieces, which is why this variant used to issue the whole prologue after the epilogue (emode 3),
             // exposing its latency at the next tile's start.  (All eight up front does not fit: 128 accumulators + 64 residual registers spill.)
-            constexpr int NRES = (RES && EPI == 0) ? 4 : 3;
+            constexpr int NRES = RES ? 4 : 3;
             const int rahead = (NRES == 4 && emode == 2) ? 4 : 2;
             uint4 res[NRES][2];
-            float2 rstat[3];
-            float psum = 0.f, psq = 0.f;
-            f32x4_t rg[2][2], rb[2][2];      // EPI 2: gamma / beta of the residual's LayerNorm for this lane's 2 x 8 columns
-            auto load_rstat = [&](int i) -> float2 {
-                const int64_t m = mrow0 + i * 16;
-                return *(const float2*)(p.res_stats + 2 * m);
-            };
-            if (EPI == 2) {
-#pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    const int n = ncol0 + jp * 32;
-                    rg[jp][0] = *(const f32x4_t*)(p.res_gamma + n); rg[jp][1] = *(const f32x4_t*)(p.res_gamma + n + 4);
-                    rb[jp][0] = *(const f32x4_t*)(p.res_beta + n);  rb[jp][1] = *(const f32x4_t*)(p.res_beta + n + 4);
-                }
-                rstat[0] = load_rstat(0); rstat[1] = load_rstat(1);
-            }
             if (RES) {
                 load_res(0, res[0]); load_res(1, res[1]);
                 if (NRES == 4 && rahead == 4) { load_res(2, res[2]); load_res(3, res[3]); }
@@ -727,15 +697,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int64_t m = mrow0 + i * 16;
-                if (RES && rahead == 2 && i + 2 < 8) { load_res(i + 2, res[(i + 2) % NRES]); if (EPI == 2) rstat[(i + 2) % 3] = load_rstat(i + 2); }
+                if (RES && rahead == 2 && i + 2 < 8) load_res(i + 2, res[(i + 2) % NRES]);
                 uint2 pk[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4_t v4 = acc[i][j];
-                    if (EPI == 1) {   // rstd (acc - mean c)
-                        const float rstd = rs_acc[i].y, nm = -rs_acc[i].x * rs_acc[i].y;
-                        v4 = v4 * rstd + c4[j] * nm;
-                    }
                     v4 += bias4[j];
                     if (ACT == SC_ACT_GELU) {
                         const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
@@ -755,46 +721,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                                          __builtin_amdgcn_ds_bpermute(bperm, r0[1]), __builtin_amdgcn_ds_bpermute(bperm, r1[1]));
                     const int n = ncol0 + jp * 32;
                     if (m >= m_lo && n >= n_lo) {
-                        if (RES && EPI != 2) {
+                        if (RES) {
                             const uint4 rv = res[i % NRES][jp];
                             o.x = pack2bf(lo2f(o.x) + lo2f(rv.x), hi2f(o.x) + hi2f(rv.x));
                             o.y = pack2bf(lo2f(o.y) + lo2f(rv.y), hi2f(o.y) + hi2f(rv.y));
                             o.z = pack2bf(lo2f(o.z) + lo2f(rv.z), hi2f(o.z) + hi2f(rv.z));
                             o.w = pack2bf(lo2f(o.w) + lo2f(rv.w), hi2f(o.w) + hi2f(rv.w));
                         }
-                        if (EPI == 2) {
-                            // residual x = LN(y) rebuilt from the pre-norm row y: x_k = y_k (rstd g_k) + (b_k - mean rstd g_k); the LayerNorm output is
-                            // rounded to bf16 exactly where the separate kernel rounds it, so both paths add the same residual
-                            const uint4 rv = res[i % NRES][jp];
-                            const float mean = rstat[i % 3].x, rstd = rstat[i % 3].y;
-                            const f32x4_t g0 = rg[jp][0] * rstd, g1 = rg[jp][1] * rstd;
-                            const f32x4_t b0 = rb[jp][0] - g0 * mean, b1 = rb[jp][1] - g1 * mean;
-                            auto rnd = [](float v) -> float { return bf2f(f2bf(v)); };
-                            const float x0 = rnd(lo2f(rv.x) * g0[0] + b0[0]), x1 = rnd(hi2f(rv.x) * g0[1] + b0[1]);
-                            const float x2 = rnd(lo2f(rv.y) * g0[2] + b0[2]), x3 = rnd(hi2f(rv.y) * g0[3] + b0[3]);
-                            const float x4 = rnd(lo2f(rv.z) * g1[0] + b1[0]), x5 = rnd(hi2f(rv.z) * g1[1] + b1[1]);
-                            const float x6 = rnd(lo2f(rv.w) * g1[2] + b1[2]), x7 = rnd(hi2f(rv.w) * g1[3] + b1[3]);
-                            o.x = pack2bf(lo2f(o.x) + x0, hi2f(o.x) + x1);
-                            o.y = pack2bf(lo2f(o.y) + x2, hi2f(o.y) + x3);
-                            o.z = pack2bf(lo2f(o.z) + x4, hi2f(o.z) + x5);
-                            o.w = pack2bf(lo2f(o.w) + x6, hi2f(o.w) + x7);
-                            // statistics of the STORED (bf16) values, for the next LayerNorm
-                            const float e0 = lo2f(o.x), e1 = hi2f(o.x), e2 = lo2f(o.y), e3 = hi2f(o.y), e4 = lo2f(o.z), e5 = hi2f(o.z), e6 = lo2f(o.w), e7 = hi2f(o.w);
-                            psum += ((e0 + e1) + (e2 + e3)) + ((e4 + e5) + (e6 + e7));
-                            psq += ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7));
-                        }
                         if (ABL != 3) *(uint4*)(Cb + m * p.ldc + n) = o;
                         else asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
                     }
                 }
                 if (RES && NRES == 4 && rahead == 4 && i + 4 < 8) load_res(i + 4, res[i % NRES]);      // slot i was consumed just above
-                if (EPI == 2) {
-                    // this lane summed 16 of the row's 64 columns in this wave's strip: the other 48 sit in the 3 neighbouring lanes of the quad
-                    psum += __shfl_xor(psum, 1, 64); psq += __shfl_xor(psq, 1, 64);
-                    psum += __shfl_xor(psum, 2, 64); psq += __shfl_xor(psq, 2, 64);
-                    if (schunk == 0 && m >= m_lo) *(float2*)(p.ln_partial + (m * (4 * p.tiles_n) + (tn * 4 + wn)) * 2) = make_float2(psum, psq);
-                    psum = 0.f; psq = 0.f;
-                }
                 if (nhave && emode == 2) { issue_q(2 * i); issue_q(2 * i + 1); }
             }
         } else if (f32_ok) {
@@ -894,9 +832,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             tail_ops = 0;
             if (k_counted_wait && nhave) {
                 tail_ops = nk > 1 ? 8 : 0;
-                // row blocks 4..7 of an interleaved epilogue: 8 stores; the 2-ahead residual ring (EPI 2) also loads blocks 6, 7 there (4 loads),
-                // the 4-ahead ring of the plain residual variant has issued everything by row block 3
-                if (emode == 2 && vec_ok && full_tile_now && nk > 1) tail_ops += (RES && EPI != 0) ? 12 : 8;
+                // row blocks 4..7 of an interleaved epilogue: 8 stores (the 4-ahead ring of the residual variant has issued every load by row block 3)
+                if (emode == 2 && vec_ok && full_tile_now && nk > 1) tail_ops += 8;
             }
         }
         have = nhave;
@@ -917,15 +854,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     }
 }
 
-template <int ABL, bool TRACE, int ACT, bool RES, bool RING3, int EPI = 0, bool BATCH = false>
+template <int ABL, bool TRACE, int ACT, bool RES, bool RING3, bool BATCH = false>
 int launch256_one(const GemmParams& p, int grid, hipStream_t s) {
     constexpr int lds = RING3 ? 5 * 256 * 128 : 2 * SLOT_BYTES;   // 160 KiB (A x3 + W x2) or 128 KiB ([A|W] x2)
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<ABL, TRACE, ACT, RES, RING3, EPI, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<ABL, TRACE, ACT, RES, RING3, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<ABL, TRACE, ACT, RES, RING3, EPI, BATCH>), dim3(grid), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((gemm256_kernel<ABL, TRACE, ACT, RES, RING3, BATCH>), dim3(grid), dim3(512), lds, s, p);
     SC_CHECK_LAUNCH();
     return 0;
 }
@@ -1012,7 +949,7 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
             static int n_cu = 0;
             if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
             const int grid = (int)(t256 < n_cu ? t256 : n_cu);
-            return launch256_one<0, false, SC_ACT_NONE, false, true, 0, true>(p, grid, s);
+            return launch256_one<0, false, SC_ACT_NONE, false, true, true>(p, grid, s);
         }
     }
     if (p.N <= 64) {
@@ -1030,13 +967,18 @@ int sc_vendor_gemm_try(const void* A, int64_t lda, const void* W, int64_t ldw, v
 
 static int g_last_path = 0;   // 0: gemm256_kernel / gemm_bf16_kernel, 1: vendor library, 3: gemm8p_pers_kernel (instrumentation: which kernel a launch hit)
 extern "C" int sc_gemm_last_path(void) { return g_last_path; }
-// gemm8p (gemm8p.hip) selection: -1 the dispatcher's rule (default), 0 never (gemm256_kernel / gemm_bf16_kernel only), 16 whenever the shape allows,
-// 17-25 A/B variants (see the dispatcher below)
+// Kernel choice behind sc_gemm_bf16 (developer / test switch, exported but not part of include/speechclip_hip.h):
+//   -1 the dispatcher's rule (default)   0 gemm256_kernel / gemm_bf16_kernel only   16 gemm8p whenever the shape allows   26 gemm8p with the static tile order
+// The round-5 A/B variants (17 per-tile launch, 19 / 24 / 25 K rotations, 20 tap-paired K walk, 21-23 forced column bands) exist only in a -DSC_LAB=1 build
+// (tools/build_ab.sh); the product library maps them to the default.
+#ifndef SC_LAB
+#define SC_LAB 0
+#endif
 #ifndef SC_GEMM_MODE_DEFAULT
 #define SC_GEMM_MODE_DEFAULT -1
 #endif
 static int g_gemm_mode = SC_GEMM_MODE_DEFAULT;
-extern "C" void sc_debug_set_gemm_mode(int mode) { g_gemm_mode = mode; }
+extern "C" void sc_debug_set_gemm_mode(int mode) { g_gemm_mode = (SC_LAB || mode == -1 || mode == 0 || mode == 16 || mode == 26) ? mode : -1; }
 static unsigned long long* g_gemm_trace = nullptr;
 // per-phase s_memtime stamps of the 256-tile kernel: effective only in the PROBES build (the product library instantiates no TRACE variant)
 extern "C" void sc_debug_set_gemm_trace(void* dev_buf) { g_gemm_trace = SC_PROBES ? (unsigned long long*)dev_buf : nullptr; }
@@ -1049,23 +991,32 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         const int rc = sc_vendor_gemm_try(A, lda, W, ldw, C, ldc, bias, residual, ldr, M, N, K, (flags & SC_GEMM_OUT_F32) ? 1 : 0, (hipStream_t)stream);
         if (rc <= 0) { g_last_path = 1; return rc; }
     }
-    if (g_gemm_mode != 0 && (!g_gemm_trace || g_gemm_mode > 0) && A && W && C && M > 0 && N > 0 && K > 0) {
+    // the argument rules of gemm_dispatch, checked once for every hand-written kernel
+    SC_CHECK_ARG(K > 0 && K % 64 == 0, "sc_gemm: K=%d must be a positive multiple of 64", K);
+    SC_CHECK_ARG(N > 0 && N % 4 == 0, "sc_gemm: N=%d must be a positive multiple of 4", N);
+    SC_CHECK_ARG(M > 0, "sc_gemm: empty problem M=%lld batch=1", (long long)M);
+    SC_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "sc_gemm: lda/ldw must be multiples of 8, ldc of 4");
+    SC_CHECK_ARG(A && W && C, "sc_gemm: null operand");
+    SC_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0, "sc_gemm: A/W/C must be 16-byte aligned");
+    if (g_gemm_mode != 0 && (!g_gemm_trace || g_gemm_mode > 0)) {
         // bf16-output GEMMs with N % 256 == 0: the ping-pong kernel (gemm8p.hip), persistent form, from 128 tiles up (ViT-B/32 at 256 images: 150 tiles,
         // +5 ... +19 % over gemm256_kernel; below that the 128 x 128 kernel's finer grid wins); bf16 or fp32 output
         Gemm8pParams d{};
         d.A = (const bf16_t*)A; d.lda = lda; d.W = (const bf16_t*)W; d.ldw = ldw; d.C = C; d.ldc = ldc; d.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0;
         d.bias = bias; d.residual = residual; d.ldr = ldr; d.M = M; d.N = N; d.K = K;
         d.act = flags & SC_GEMM_ACT_MASK;
-        d.kpair = (g_gemm_mode == 20 && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) ? (int)(lda / 2 / 64) : 0;      // tap-paired K walk: A/B (mode 20)
-        d.esteps = g_gemm_mode == 17 ? 1 : 4;      // 17: gemm8p per-tile kernel
-        d.trace = g_gemm_trace;
-        d.rows = g_gemm_mode == 19 ? 1 : g_gemm_mode == 24 ? 2 : g_gemm_mode == 25 ? 3 : 0;      // 24 / 25: the N tiles of an M panel one / two k-steps apart
-        if (0) d.rows = 0;      // gemm8p: K rotation per M panel (A/B: mode 19)
-        // column-band tile order: wide outputs (>= 16 N tiles: 8192^3 1 444 vs 1 323 TF/s unbanded, gemm256_kernel 1 406; HuBERT-large fc1 +2 %) walk 4 N tiles
-        // at a time; A/B: modes 21-23 force 3 / 4 / 6, mode 16 none
-        d.band = g_gemm_mode == 21 ? 3 : g_gemm_mode == 22 ? 4 : g_gemm_mode == 23 ? 6 : (g_gemm_mode == -1 && N / 256 >= 16) ? 4 : 0;
-        d.sched = g_gemm_mode == 26 ? -1 : 0;      // 26: static tile order (A/B)
-        const bool aligned = ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!residual || ((uintptr_t)residual & 15) == 0);
+        d.esteps = 4; d.trace = g_gemm_trace;
+        // column-band tile order: wide outputs (>= 16 N tiles: 8192^3 1 444 vs 1 323 TF/s unbanded, gemm256_kernel 1 406; HuBERT-large fc1 +2 %) walk 4 N tiles at a time
+        d.band = (g_gemm_mode == -1 && N / 256 >= 16) ? 4 : 0;
+        d.sched = g_gemm_mode == 26 ? -1 : 0;      // 26: static tile order (A/B, and the reference of the dynamic order's bit-identity test)
+#if SC_LAB
+        d.kpair = (g_gemm_mode == 20 && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) ? (int)(lda / 2 / 64) : 0;      // tap-paired K walk
+        if (g_gemm_mode == 17) d.esteps = 1;                                                                                     // per-tile kernel
+        d.rows = g_gemm_mode == 19 ? 1 : g_gemm_mode == 24 ? 2 : g_gemm_mode == 25 ? 3 : 0;                                      // K rotations
+        if (g_gemm_mode >= 21 && g_gemm_mode <= 23) d.band = g_gemm_mode == 21 ? 3 : g_gemm_mode == 22 ? 4 : 6;                  // forced column bands
+#endif
+        // (the kernel copies the bias vector with 16-byte loads and reads the residual in 16-byte pieces)
+        const bool aligned = (!residual || ((uintptr_t)residual & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
         const bool dflt_ok = N % 256 == 0 && N <= 8192 && ((M + 255) / 256) * (int64_t)(N / 256) >= 128;
         if (aligned && (g_gemm_mode > 0 || dflt_ok)) {
             const int rc = sc_gemm8p_try(d, (hipStream_t)stream);
@@ -1096,41 +1047,6 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     static const int k_pair = SC_TUNE_SET("SC_GEMM_NOKPAIR") ? 0 : 1;
     if (k_pair && lda < K && K == 3 * (lda / 2) && (lda / 2) % 64 == 0) p.kpair = (int)(lda / 2 / 64);   // k = 3, stride-2 conv layers of the extractor
     return gemm_dispatch(p, 1, (hipStream_t)stream);
-}
-
-// LayerNorm folded into the GEMMs on both sides of it (eval path of the post-LN transformer layers).  mode 1: A holds PRE-norm rows, W is
-// gamma (.) W, ln_stats [M,2] = (mean, rstd) per row, ln_c [N] = sum_k W'[n,k], bias = W beta + b:  C = act(rstd (A W'^T - mean c) + bias).
-// mode 2: C = A W^T + bias + LN(residual) with the residual's LayerNorm rebuilt per element from res_stats / res_gamma / res_beta, and the
-// per-(row, 64-column strip) partial (sum, sum of squares) of C written to ln_partial [M, N/64, 2] (finished by sc_ln_stats_finalize).
-// Returns 1 (nothing launched) when the shape is outside the 256-tile kernel's rules: the caller then runs the unfused sequence.
-extern "C" int sc_gemm_bf16_ln(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* residual,
-                               int64_t ldr, int64_t M, int N, int K, int flags, int mode, const float* ln_stats, const float* ln_c,
-                               const float* res_stats, const float* res_gamma, const float* res_beta, float* ln_partial, void* stream) {
-    SC_CHECK_ARG(mode == 1 || mode == 2, "sc_gemm_bf16_ln: mode=%d must be 1 (folded input LayerNorm) or 2 (rebuilt residual LayerNorm + output statistics)", mode);
-    SC_CHECK_ARG(A && W && C && bias, "sc_gemm_bf16_ln: null operand");
-    SC_CHECK_ARG(!(flags & SC_GEMM_OUT_F32), "sc_gemm_bf16_ln: bf16 outputs only");
-    if (M < 256 || N < 256 || K <= 0 || K % 64 || N % 8 || ldc % 8 || lda % 8 || ldw % 8 || lda < K) return 1;
-    if (mode == 2 && (N % 256 || !residual || ldr % 8)) return 1;
-    SC_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0, "sc_gemm_bf16_ln: A/W/C must be 16-byte aligned");
-    const int act = flags & SC_GEMM_ACT_MASK;
-    if (mode == 1) SC_CHECK_ARG(ln_stats && ln_c && !residual && (act == SC_ACT_NONE || act == SC_ACT_GELU), "sc_gemm_bf16_ln: mode 1 takes ln_stats + ln_c, no residual, act none / gelu");
-    if (mode == 2) SC_CHECK_ARG(res_stats && res_gamma && res_beta && ln_partial && act == SC_ACT_NONE, "sc_gemm_bf16_ln: mode 2 takes res_stats + res_gamma + res_beta + ln_partial, no activation");
-    g_last_path = 0;
-    GemmParams p{};
-    p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.w_mod = 1;
-    p.C = C; p.ldc = ldc; p.bias = bias; p.residual = residual; p.ldr = ldr;
-    p.M = M; p.N = N; p.K = K; p.act = act; p.out_f32 = 0;
-    p.rot = 1; p.band = 0; p.epi_mode = 2; p.epi_mode_res = 3;
-    p.tiles_m = (int)((M + 255) / 256); p.tiles_n = (N + 255) / 256;
-    p.ln_stats = ln_stats; p.ln_c = ln_c; p.res_stats = res_stats; p.res_gamma = res_gamma; p.res_beta = res_beta; p.ln_partial = ln_partial;
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int grid = ntiles < n_cu ? ntiles : n_cu;
-    hipStream_t s = (hipStream_t)stream;
-    if (mode == 2) return launch256_one<0, false, SC_ACT_NONE, true, false, 2>(p, grid, s);
-    if (act == SC_ACT_GELU) return launch256_one<0, false, SC_ACT_GELU, false, false, 1>(p, grid, s);
-    return launch256_one<0, false, SC_ACT_NONE, false, false, 1>(p, grid, s);
 }
 
 // Two-level batch: product z = zo * inner + zi (zo < outer) reads A at zo*strideA + zi*strideA2, W at zo*strideW + zi*strideW2 and writes C at

@@ -17,10 +17,10 @@ struct Gemm8pParams {
     int kpair;                         // > 0: stride-2 kernel-3 conv as GEMM, walk K as (tap 0, tap 2) chunk pairs (see gemm.hip); A/B only
     int tn;                            // N / 256
     int rows;                          // K-rotation switch (A/B): 0 off, 1 by M panel, 2 / 3 by N tile
-    int64_t units;                     // (unused)
     int esteps;                        // 1 = the per-tile A/B kernel, else the persistent kernel
     int band;                          // gemm8p: N tiles per column band of the tile order (0: all of N)
     int sched;                         // in: >= 0 dynamic tile order allowed, -1 static (A/B); gemm8p.hip replaces it by the launch's counter slot
+    unsigned sched_gen;                // set by gemm8p.hip: the launch's generation of that slot (see g_sched)
     unsigned long long* trace;         // PROBES: per-block cycle stamps
 };
 

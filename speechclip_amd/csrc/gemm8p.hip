@@ -49,11 +49,15 @@ namespace {
 constexpr int HT = 128 * 128;            // one half tile: 128 rows x 128 B = 16 KiB
 constexpr int BUF = 4 * HT;              // A0 A1 B0 B1
 
-// Tile counters of the persistent kernel's dynamic order: one 64-byte slot per launch in flight (the host hands out slots round robin; a launch leaves
-// its slot zeroed): [0..7] next tile of XCD x's chunk (beyond the one tile every block owns by its position), [8] blocks finished.
+// Tile counters of the persistent kernel's dynamic order: one 64-byte slot per launch in flight (the host hands out slots round robin): eight 64-bit words,
+// word x = (launch generation << 32) | next tile of XCD x's chunk (beyond the one tile every block owns by its position).  The generation (launch sequence
+// number / ring size + 1, handed in by the host, monotonic) makes the ring FAULT-TOLERANT: every block raises its XCD's word to (generation << 32) with one
+// atomic max before its first fetch, so whatever an earlier user of the slot left behind -- including a launch that faulted or was torn down mid-flight --
+// is an older generation and is overwritten; a word of the current generation is left alone.  Nothing has to be cleaned up at the end of a launch.
+// (tests/test_gemm8p_gpu.py::test_dynamic_tile_order_survives_a_poisoned_counter_ring fills the ring with "every tile already taken" and compares bits.)
 constexpr int SCHED_RING = 4096;
 constexpr int SCHED_LDS = 2 * BUF + 32752;      // where a block's waves exchange the fetched index (behind the bias vector: dynamic order needs N < 8192)
-__device__ unsigned int g_sched[SCHED_RING * 16];
+__device__ unsigned long long g_sched[SCHED_RING * 8];
 // Where the residual epilogues send the stores of rows that belong to the previous tile (ragged last M panel, tile shifted back): their stores all follow
 // the last residual add, and 8-32 per-lane store predicates held until then cost more registers than the kernel has (spills inside the k-loop);
 // an address select per row block costs none.  Contents are never read.
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
     // (fp32 outputs keep the plain pairing: their epilogues move 512 KiB per tile and are bound by the CU's load / store path -- side by side they
     //  measured 6 % slower (P-large out-proj 740 -> 697 TF/s), one after the other group 0's stores overlap group 1's residual loads)
     constexpr bool PAIR = SC_8P_EPI_PAIR && !F32;
+    static_assert(!(SC_8P_RES_LATE && RES && F32), "SC_8P_RES_LATE (A/B build) re-issues the skipped refill only from the bf16 residual epilogue: not with fp32 outputs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -301,17 +306,10 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
     // tile (behind phase 3's counted wait, so it is the oldest entry of the in-order queue for one k-step only), is covered by k-step 1's wait, goes
     // through LDS to the other waves and is used from k-step nk - 2 on (the refill that crosses into the next tile): nk >= 6, host check.
     const bool dyn = SC_8P_DYN && p.sched >= 0;
-    unsigned int* const sched = g_sched + (dyn ? p.sched : 0) * 16;
-    auto block_done = [&]() {      // the last block out re-arms the slot for the launch that gets it next
-        if (dyn && tid == 0) {
-            const unsigned int d = __hip_atomic_fetch_add(sched + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == (unsigned int)G - 1) {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) __hip_atomic_store(sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    };
-    if (slot_in_xcd >= cnt) { block_done(); return; }
+    unsigned long long* const sched = g_sched + (dyn ? p.sched : 0) * 8;
+    if (slot_in_xcd >= cnt) return;
+    // arm my XCD's counter for this launch's generation (see g_sched); the wait behind the bias staging below covers it, ahead of this block's first fetch
+    if (dyn && tid == 0) (void)__hip_atomic_fetch_max(sched + xcd, (unsigned long long)p.sched_gen << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // Column bands (p.band N tiles, 0 = all of N): the order walks every M panel of a band before the next band, so an XCD has only the band's slice of
     // W (band x 256 x K) in flight: with all of N in flight (QKV 3.5 MiB, fc1 4.7 MiB of W against a 4 MiB L2) W is re-fetched once per tile round.
     const int band = p.band;
@@ -460,7 +458,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
     const bool tracing = SC_PROBES && p.trace;
     if (tracing) tr_t = __builtin_readcyclecounter();
     const unsigned long long tr_begin = tr_t;
-    unsigned int fetched = 0;
+    unsigned long long fetched = 0;
     int n_tiles = 0;
     for (;;) {
         bool have_next = false;
@@ -540,10 +538,10 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             if (dyn && wave == 0 && kt < 2) {
                 if (kt == 0) {      // lane 0 only (exec switched inside the asm: no per-lane select on `fetched`, which is in flight until k-step 1's wait)
                     unsigned long long ex;
-                    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
-                                 : "+v"(fetched), "=&s"(ex) : "v"(sched + xcd), "v"(1u) : "memory");
+                    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add_x2 %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
+                                 : "+v"(fetched), "=&s"(ex) : "v"(sched + xcd), "v"(1ull) : "memory");
                 } else if (lane == 0) {
-                    *(volatile __attribute__((address_space(3))) unsigned int*)(smem + SCHED_LDS) = fetched;      // (k-step 1's wait above covered the fetch)
+                    *(volatile __attribute__((address_space(3))) unsigned int*)(smem + SCHED_LDS) = (unsigned int)fetched;      // low word = the count (k-step 1's wait above covered the fetch)
                 }
             }
             // (residual variants: touching the tile's residual lines two k-steps ahead -- 4-byte LDS-DMA loads into a dummy LDS area, gemm256_kernel's trick --
@@ -777,7 +775,6 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
         cur = nxt; tm = ntm; tn = ntn; ta = ta_n; tw = tw_n; rot = rot_n;
     }
     if (!PAIR && g == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-    block_done();
     if (tracing && lane == 0) {      // per wave: first k-step of every tile / the other k-steps / epilogue issue, block lifetime, tiles
         unsigned long long* tr = p.trace + ((size_t)blockIdx.x * 8 + wave) * 8;
         tr[0] = tr_first; tr[1] = tr_loop; tr[2] = tr_epi; tr[3] = __builtin_readcyclecounter() - tr_begin; tr[4] = n_tiles;
@@ -812,6 +809,14 @@ int launch_one(const Gemm8pParams& p, int grid, hipStream_t s) {
 
 }  // namespace
 
+// Test hook (exported, not part of include/speechclip_hip.h): overwrite the whole counter ring with what a launch that died mid-flight could leave behind --
+// an OLD generation with every tile "already taken".  Synchronous.
+extern "C" int sc_debug_poison_gemm_sched(void) {
+    static unsigned long long junk[SCHED_RING * 8];
+    for (int i = 0; i < SCHED_RING * 8; ++i) junk[i] = 0x000000007fffff00ull + (unsigned)i;      // generation 0, count ~2^31
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sched), junk, sizeof(junk)) == hipSuccess ? 0 : -1;
+}
+
 int sc_gemm8p_try(const Gemm8pParams& pin, hipStream_t s) {
     Gemm8pParams p = pin;
     if (p.N % 256 || p.K % 64 || p.M < 256) return 1;
@@ -830,13 +835,14 @@ int sc_gemm8p_try(const Gemm8pParams& pin, hipStream_t s) {
         // dynamic tile order: a slot of the counter ring per launch (SCHED_RING launches would have to be in flight at once for two to meet).  A launch
         // that is being CAPTURED into a HIP graph keeps the static order: its slot would be frozen into the graph node, and a replay could then run
         // beside an eager launch that the ring has handed the same slot.
-        static std::atomic<unsigned> sched_seq{0};
+        static std::atomic<unsigned long long> sched_seq{0};
         bool dyn = SC_8P_DYN && p.sched >= 0 && p.nk >= 6 && p.N < 8192 && pg >= 8;
         if (dyn) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) dyn = false;
         }
-        p.sched = dyn ? (int)(sched_seq.fetch_add(1) % SCHED_RING) : -1;
+        if (dyn) { const unsigned long long seq = sched_seq.fetch_add(1); p.sched = (int)(seq % SCHED_RING); p.sched_gen = (unsigned)(seq / SCHED_RING + 1); }
+        else p.sched = -1;
         if (p.out_f32) {
             switch (p.act) {
                 case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false, true>(p, pg, s);

@@ -306,66 +306,6 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(const void* __restric
     }
 }
 
-// Layer mix over PRE-LayerNorm rows (the folded-LayerNorm eval path, sc_gemm_bf16_ln): layer 0 is the already normalised state h0, layers
-// 1..n-1 are the pre-norm outputs y_l of the transformer layers; each row's LayerNorm (statistics over D, affine gamma_l / beta_l, output rounded
-// to bf16 -- the value the separate LayerNorm kernel would have stored) is rebuilt here, in the single pass that reads the rows anyway.
-__global__ __launch_bounds__(256) void weighted_sum_ln_kernel(const bf16_t* __restrict__ h0, const bf16_t* __restrict__ ypre, int64_t layer_stride,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ w,
-                                                              bf16_t* __restrict__ out, int n, int64_t rows, int D, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    float mx = -INFINITY;
-    for (int i = 0; i < n; ++i) mx = fmaxf(mx, w[i]);
-    float den = 0.f;
-    for (int i = 0; i < n; ++i) den += __expf(w[i] - mx);
-    float acc[MAXC][4], v[MAXC][4];
-    load_row<false>(h0, row * D, D, lane, v);
-    const float w0 = __expf(w[0] - mx) / den;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[c][k] = w0 * v[c][k];
-    for (int i = 1; i < n; ++i) {
-        const float wi = __expf(w[i] - mx) / den;
-        load_row<false>(ypre, (int64_t)(i - 1) * layer_stride + row * D, D, lane, v);
-        float mean, rstd;
-        row_stats(v, D, lane, eps, mean, rstd);
-        const float* g = gamma + (int64_t)(i - 1) * D;
-        const float* b = beta + (int64_t)(i - 1) * D;
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int e = c * 256 + lane * 4;
-            if (e < D) {
-                const f32x4_t g4 = *(const f32x4_t*)(g + e), b4 = *(const f32x4_t*)(b + e);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[c][k] += wi * bf2f(f2bf((v[c][k] - mean) * rstd * g4[k] + b4[k]));
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        int e = c * 256 + lane * 4;
-        if (e < D) {
-            uint2 pk; pk.x = pack2bf(acc[c][0], acc[c][1]); pk.y = pack2bf(acc[c][2], acc[c][3]);
-            *(uint2*)(out + row * D + e) = pk;
-        }
-    }
-}
-
-// (mean, rstd) per row from the per-strip partial (sum, sum of squares) the mode-2 GEMM epilogue wrote: stats[m] = finish(sum_p partial[m][p])
-__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ stats, int64_t rows,
-                                                                float inv_d, float eps) {
-    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (m >= rows) return;
-    const float2* p = (const float2*)(partial + m * nparts * 2);
-    float s = 0.f, q = 0.f;
-    for (int i = 0; i < nparts; ++i) { const float2 t = p[i]; s += t.x; q += t.y; }
-    const float mean = s * inv_d;
-    const float var = fmaxf(q * inv_d - mean * mean, 0.f);
-    *(float2*)(stats + 2 * m) = make_float2(mean, rsqrtf(var + eps));
-}
-
 template <bool IN_F32>
 __global__ __launch_bounds__(256) void l2norm_kernel(const void* __restrict__ x, int64_t ld_in, float* __restrict__ out, int64_t rows, int D, float norm_floor) {
     const int lane = threadIdx.x & 63;
@@ -513,25 +453,6 @@ extern "C" int sc_unpack_rows(const void* src, int64_t src_layer_stride_bytes, c
     return 0;
 }
 
-extern "C" int sc_weighted_sum_ln_fwd(const void* h0, const void* ypre, int64_t layer_stride, const float* gamma, const float* beta, const float* weights,
-                                      void* out, int n_layers, int64_t rows, int D, float eps, void* stream) {
-    SC_CHECK_ARG(D > 0 && D <= 1024 && D % 4 == 0, "sc_weighted_sum_ln: D=%d must be a multiple of 4, <= 1024", D);
-    SC_CHECK_ARG(n_layers >= 1 && n_layers <= 64 && h0 && out && weights && (n_layers == 1 || (ypre && gamma && beta)), "sc_weighted_sum_ln: bad arguments");
-    if (rows <= 0) return 0;
-    hipLaunchKernelGGL(weighted_sum_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h0, (const bf16_t*)ypre,
-                       layer_stride, gamma, beta, weights, (bf16_t*)out, n_layers, rows, D, eps);
-    SC_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int sc_ln_stats_finalize(const float* partial, int nparts, float* stats, int64_t rows, int D, float eps, void* stream) {
-    SC_CHECK_ARG(partial && stats && nparts >= 1 && nparts <= 64 && D > 0, "sc_ln_stats_finalize: bad arguments");
-    if (rows <= 0) return 0;
-    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, nparts, stats, rows,
-                       1.0f / (float)D, eps);
-    SC_CHECK_LAUNCH();
-    return 0;
-}
 
 // `normalize_hiddenstates` with `normalize_type` method1 / method2 (speech_encoder_plus.py:572-592), IN PLACE on the stacked hidden states
 // x = [n_layers][B][Tp][D] (bf16 post-LN / f32 pre-LN residual stream), as the reference overwrites `layer_results[i]`:

@@ -489,7 +489,9 @@ class KWClip_GeneralTransformer(KWClipBase):
         # the optional MLP projection heads (image_encoder_projection / parallel_branch_projection / ..., kwClip.py:1161-1190 of the
         # reference; no shipped YAML has them) are eval-only here: say so when the optimizer is built, not at the first training forward
         from ..module import MLPLayers
-        heads = [n for n, m in self.named_modules() if isinstance(m, MLPLayers)]
+        # (only the four projection attributes of THIS class, not every MLPLayers nested somewhere in a sub-module -- the cascaded branch's own
+        #  kw_projection MLP has its own check at its training forward)
+        heads = [n for n in ("img_enc_proj_net", "p_branch_proj_net", "c_branch_proj_net") if isinstance(getattr(self, n, None), MLPLayers)]
         if heads:
             raise NotImplementedError(f"training with the MLP projection heads {heads} is not built on the MI355X path (eval / inference only); "
                                       "remove the *_projection sections from the config to train (README: gaps)")

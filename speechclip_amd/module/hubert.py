@@ -218,27 +218,6 @@ class HubertModel(nn.Module):
                 ln2=(w32(lyr.final_layer_norm.weight), w32(lyr.final_layer_norm.bias))))
         return P
 
-    def _pack_fold(self, P, dev):
-        """Folded-LayerNorm operands of the opt-in eval path (sc_gemm_bf16_ln), built on first use: the LayerNorm in FRONT of a GEMM is absorbed as
-          LN(y) W^T + b = rstd (y W'^T - mean c) + (W beta + b),   W' = gamma (.) W,  c_n = sum_k W'[n,k]  (c from the bf16 W' the MFMA multiplies)
-        fc1 absorbs LN1 of its own layer; the QKV projection of layer l absorbs LN2 of layer l-1 (layer 0 reads the normalised state)."""
-        bf, f32 = torch.bfloat16, torch.float32
-
-        def fold(w, b, g, be):
-            wf = w.detach().to(dev, f32)
-            wp = (wf * g.detach().to(dev, f32)[None, :]).to(bf).contiguous()
-            return wp, wp.float().sum(dim=1).contiguous(), (wf @ be.detach().to(dev, f32) + b.detach().to(dev, f32)).contiguous()
-        lys = list(self.encoder.layers)
-        for li, (lyr, L) in enumerate(zip(lys, P["layers"])):
-            L["w1f"], L["c1"], L["d1"] = fold(lyr.fc1.weight, lyr.fc1.bias, lyr.self_attn_layer_norm.weight, lyr.self_attn_layer_norm.bias)
-            if li > 0:
-                prev = lys[li - 1].final_layer_norm
-                a = lyr.self_attn
-                L["wqkvf"], L["cqkv"], L["dqkv"] = fold(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0),
-                                                         torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0), prev.weight, prev.bias)
-        P["ln2_gamma"] = torch.stack([L["ln2"][0] for L in P["layers"]]).contiguous()
-        P["ln2_beta"] = torch.stack([L["ln2"][1] for L in P["layers"]]).contiguous()
-
     def _buf(self, name, shape, dtype, dev, zero=False, cap=False):
         """Workspace tensors, reused across steps.  cap=False: keyed by the exact shape (fixed-shape batches).  cap=True (packed batches, whose
         row count changes every step): ONE flat allocation per (name, dtype) that only grows (in 1/8 steps, zero-filled so rows nobody wrote
@@ -300,24 +279,12 @@ class HubertModel(nn.Module):
         return dict(rows=rows, row_off=off, total=off[-1], rows_max=max(rows), valid=valid, scale0=ds, T0=T0, T=T, padded_rows=len(lens) * Tp)
 
     # ------------------------------------------------------------------ forward
-    def fold_ln_supported(self, B: int, lmax: int) -> bool:
-        """The folded-LayerNorm eval path (no separate LayerNorm pass, hidden states kept PRE-norm) exists for post-LN models whose rows
-        fill the 256 x 256-tile GEMM: B*Tp >= 256 and d a multiple of 256 (HuBERT-base: 768).  OPT-IN (SC_FOLD_LN=1): measured on the B = 256
-        step it removes the 24 LayerNorm launches (2.1 ms at the HBM roofline, 71 us each) but pays them back in epilogue time of the
-        out-proj GEMM (+34 us), statistics finalisation (2 x 8 us per layer) and a VALU-bound layer mix (+0.33 ms), and the HBM-bound
-        LayerNorm phases are where the side-stream image tower overlaps best: 46.5 ms folded vs 46.2 ms unfolded (EXPERIMENTS.md, old section 7)."""
-        if self.cfg.layer_norm_first or os.environ.get("SC_FOLD_LN", "0") != "1":
-            return False
-        d = self.cfg.encoder_embed_dim
-        Tp = self.frame_geometry(lmax)[3]
-        return d % 256 == 0 and B * Tp >= 256 and self.cfg.encoder_ffn_embed_dim >= 256
-
     def dropout_rates(self):
         c = self.cfg
         return dict(features=float(c.dropout_input), hidden=float(c.dropout), attention=float(c.attention_dropout), activation=float(c.activation_dropout))
 
     @torch.no_grad()
-    def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int], fold_ln: bool = False, stop_layer: int = None, drop_layers=(),
+    def extract_all_layers(self, wav: torch.Tensor, lens: Sequence[int], stop_layer: int = None, drop_layers=(),
                            dropout_seed: int = None, pack: dict = None):
         """wav: f32 [B, Lmax] device tensor (right zero-padded); lens: host ints.
         Returns (hidden [n_layers+1, B, Tp, d] (bf16 for post-LN, f32 for pre-LN), T, Tp, valid_frames); with `stop_layer` = L only
@@ -326,8 +293,6 @@ class HubertModel(nn.Module):
         `dropout_seed` (train mode of the FROZEN encoder, post-LN models): the checkpoint's dropouts are applied -- dropout_input on the projected
         features, `dropout` after the positional conv + LayerNorm and after out_proj / fc2 (before the residual add), attention_dropout on the
         probabilities, activation_dropout after the GELU; masks are counter-based, one stream per site derived from the seed.
-        fold_ln (caller checked fold_ln_supported): returns ((h0 [M,d], ypre [n_layers, M, d], gamma2, beta2), T, Tp, valid) instead -- layer 0's
-        normalised state and the PRE-LayerNorm outputs of the layers with the affines of their final LayerNorms (ops.weighted_sum_ln mixes them).
         pack (packed_geometry): the padding-free layout -- every tensor has pack["total"] rows, utterance b at rows pack["row_off"][b] ...;
         returns (hidden [n, total, d], T, None, valid); ops.unpack_rows restores the padded [B, T, d] view where a caller needs it."""
         cfg = self.cfg
@@ -335,9 +300,8 @@ class HubertModel(nn.Module):
 
         def buf(name, shape, dtype, dev_, zero=False):
             # every large workspace is ONE flat allocation per name that only grows: a job whose batch maximum (hence T) differs from step to step
-            # would otherwise keep a full set of buffers per distinct shape (tools/soak_varlen.py: +107 GB over ten distinct T before this).  The few
-            # small constant tables of the folded-LayerNorm path are keyed by shape (their `fresh` initialisation relies on it).
-            return self._buf(name, shape, dtype, dev_, zero=zero, cap=not name.startswith("ln_"))
+            # would otherwise keep a full set of buffers per distinct shape (tools/soak_varlen.py: +107 GB over ten distinct T before this).
+            return self._buf(name, shape, dtype, dev_, zero=zero, cap=True)
         # packed bf16 operands are rebuilt when a load replaced the weights (post-hook) or an optimizer step moved TRAINABLE encoder weights:
         # ops.param_epoch moves on FusedAdam steps (raw-pointer writes), the tensors' own `_version` on any torch optimizer (the fallback of
         # configure_optimizers for optim.name != "Adam" / CPU params) or in-place edit; frozen encoders never repack
@@ -357,7 +321,7 @@ class HubertModel(nn.Module):
             wav = ops.wave_layernorm(wav.contiguous(), lens_i32)
         ln_mode = cfg.extractor_mode == "layer_norm"
         if pack is not None:
-            assert not fold_ln and pack["scale0"] * Tp == P0
+            assert pack["scale0"] * Tp == P0
             off_i32 = ops.dev_ints(pack["row_off"], torch.int32, dev)
             Mt = pack["total"]
             rows_all = pack["scale0"] * Mt            # rows of the whole batch at conv layer 0
@@ -395,7 +359,6 @@ class HubertModel(nn.Module):
         if rates is not None and any(v > 0 for v in rates.values()):
             if cfg.layer_norm_first:
                 raise NotImplementedError("train-mode dropout inside a pre-LN encoder is not built (the released large checkpoint has all rates 0)")
-            assert not fold_ln
         else:
             rates = None
         site = [int(dropout_seed) & 0x7fffffff if dropout_seed is not None else 0]
@@ -413,7 +376,7 @@ class HubertModel(nn.Module):
         nl = cfg.encoder_layers
         pre_ln = cfg.layer_norm_first
         hid_dtype = torch.float32 if pre_ln else bf
-        hidden = buf("hidden0", (1, M, d), hid_dtype, dev) if fold_ln else buf("hidden", (nl + 1, M, d), hid_dtype, dev)
+        hidden = buf("hidden", (nl + 1, M, d), hid_dtype, dev)
         g, bta = (None, None) if pre_ln else P["enc_ln"]
         if pack is not None:
             ops.posconv_packed(xp, valid_i32, off_i32, P["pos_w"], P["pos_b"], g, bta, B, pack["rows_max"], M, d, cfg.conv_pos_groups, cfg.conv_pos,
@@ -429,43 +392,6 @@ class HubertModel(nn.Module):
         ffn = buf("ffn", (M, cfg.encoder_ffn_embed_dim), bf, dev)
         tmp = buf("tmp", (M, d), bf, dev)
         tmp2 = buf("tmp2", (M, d), bf, dev)
-        if fold_ln:
-            assert not pre_ln
-            if "ln2_gamma" not in P:
-                self._pack_fold(P, dev)
-            # LayerNorm folded into the GEMMs around it: per layer  qkv <- LN2_{l-1} folded;  y1 = att Wo + bo + LN2_{l-1}(y2_{l-1}) (+ stats);
-            # ffn = gelu(LN1 folded);  y2 = ffn W2 + b2 + LN1(y1) (+ stats).  Neither LN1's nor LN2's output is ever written.
-            ypre = buf("ypre", (nl, M, d), bf, dev)
-            y1 = tmp
-            npart = d // 64
-            part = buf("ln_part", (M, npart, 2), torch.float32, dev)
-            st1 = buf("ln_st1", (M, 2), torch.float32, dev)
-            st2 = buf("ln_st2", (M, 2), torch.float32, dev)
-            fresh = ("ln_ident", (M, 2), torch.float32) not in self._ws
-            ident = buf("ln_ident", (M, 2), torch.float32, dev)          # (mean, rstd) = (0, 1): layer 0's residual is already normalised
-            ones, zeros = buf("ln_ones", (d,), torch.float32, dev), buf("ln_zeros", (d,), torch.float32, dev, zero=True)
-            if fresh:
-                ident[:, 0] = 0.0
-                ident[:, 1] = 1.0
-                ones.fill_(1.0)
-            for i, L in enumerate(P["layers"]):
-                if i == 0:      # layer 0 reads the normalised state: plain QKV, identity "LayerNorm" on the residual
-                    ops.gemm(hidden[0], L["wqkv"], L["bqkv"], out=qkv)
-                    res, rst, rg, rb = hidden[0], ident, ones, zeros
-                else:
-                    ok = ops.gemm_ln(ypre[i - 1], L["wqkvf"], L["dqkv"], 1, out=qkv, ln_stats=st2, ln_c=L["cqkv"])
-                    assert ok is not None
-                    res, rst, rg, rb = ypre[i - 1], st2, P["layers"][i - 1]["ln2"][0], P["layers"][i - 1]["ln2"][1]
-                ops.attention(qkv, B, Tp, H, valid_i32, out=att)
-                ok = ops.gemm_ln(att, L["wo"], L["bo"], 2, residual=res, out=y1, res_stats=rst, res_gamma=rg, res_beta=rb, ln_partial=part)
-                assert ok is not None
-                ops.ln_stats_finalize(part, d, out=st1)
-                ops.gemm_ln(y1, L["w1f"], L["d1"], 1, ACT_GELU, out=ffn, ln_stats=st1, ln_c=L["c1"])
-                ops.gemm_ln(ffn, L["w2"], L["b2"], 2, residual=y1, out=ypre[i], res_stats=st1, res_gamma=L["ln1"][0], res_beta=L["ln1"][1], ln_partial=part)
-                if i + 1 < nl:
-                    ops.ln_stats_finalize(part, d, out=st2)
-            return (hidden[0], ypre, P["ln2_gamma"], P["ln2_beta"]), T, Tp, valid
-        assert not (fold_ln and drop_layers)
 
         def attn(qkv_, att_):
             if pack is not None:

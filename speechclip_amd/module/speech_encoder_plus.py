@@ -220,21 +220,9 @@ class FairseqSpeechEncoder_Hubert(nn.Module):
         if self.training and os.environ.get("SC_FROZEN_DROPOUT", "1") != "0" and any(v > 0 for v in self.encoder.dropout_rates().values()) \
                 and not self.encoder.cfg.layer_norm_first:
             drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-        # Eval fast path: nobody asked for the hidden states themselves (only their mix), so the LayerNorms are folded into the GEMMs around
-        # them and the layer mix rebuilds each state from its pre-norm rows (module/hubert.py: fold_ln).  The states are materialised when they
-        # are returned, selected by index, or needed by the training tail's layer-mix gradient.
-        mix_only = (feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE and not return_hidden_states
-                    and not (torch.is_grad_enabled() and self.weightedsum_layer.weights.requires_grad)
-                    and not self.weightedsum_layer.normalize_features and norm_method is None)
         if drop and feat_select_idx == FEAT_SELECT_IDX_WEIGHTED_SUM_MODE:
             # WeightedSumLayer.forward asserts one weight per hidden state (weighted_sum.py:36): the reference fails here too
             raise AssertionError(self.upstream_model_hiddenstates_len - len(drop))
-        if mix_only and not drop and drop_seed is None and self.encoder.fold_ln_supported(padded.shape[0], padded.shape[1]):
-            (h0, ypre, g2, b2), T, Tp, _valid = self.encoder.extract_all_layers(padded, lens, fold_ln=True)
-            B_, d_ = padded.shape[0], h0.shape[-1]
-            mixed = ops.weighted_sum_ln(h0, ypre, g2, b2, self.weightedsum_layer.weights.detach().float()).view(B_, Tp, d_)[:, :T]
-            feat_len = ops.dev_ints([min(round(l / self.downsample_rate), T) for l in lens], torch.long, dev).clone()
-            return (mixed, feat_len)
         if self.train_layers and torch.is_grad_enabled():
             if norm_method is not None:
                 raise NotImplementedError("fine-tuning the encoder under normalize_type method1 / method2 is not built (no shipped config uses them)")

@@ -126,58 +126,6 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
-def gemm_ln(a, w, bias, mode, act=ACT_NONE, residual=None, out=None, ln_stats=None, ln_c=None, res_stats=None, res_gamma=None, res_beta=None,
-            ln_partial=None):
-    """sc_gemm_bf16_ln (LayerNorm folded into the GEMMs around it).  mode 1: a = pre-norm rows, w = gamma (.) W, ln_stats [M,2], ln_c [N];
-    mode 2: residual = pre-norm rows with res_stats / res_gamma / res_beta, ln_partial [M, N/64, 2] receives the output's partial statistics.
-    Returns the output, or None when the shape is outside the fused kernel's rules (the caller then runs layernorm + gemm)."""
-    _need_cuda(a, w)
-    assert a.dtype == bf16 and w.dtype == bf16 and a.dim() == 2 and a.stride(1) == 1 and w.is_contiguous()
-    M, K = a.shape
-    N = w.shape[0]
-    assert w.shape[1] == K
-    if out is None:
-        out = torch.empty(M, N, device=a.device, dtype=bf16)
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    rc = lib().sc_gemm_bf16_ln(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), ptr(bias), ptr(residual),
-                               residual.stride(0) if residual is not None else 0, M, N, K, act, mode, ptr(ln_stats), ptr(ln_c), ptr(res_stats),
-                               ptr(res_gamma), ptr(res_beta), ptr(ln_partial), stream())
-    if rc == 1:
-        return None
-    check(rc, "sc_gemm_bf16_ln")
-    if PROFILE is not None:
-        e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, act, residual is not None, False, 0), torch.cuda.current_stream().cuda_stream, PROFILE_TAG))
-    return out
-
-
-def ln_stats_finalize(partial, D, eps=1e-5, out=None):
-    """partial f32 [M, P, 2] (sum, sum of squares per 64-column strip) -> stats f32 [M, 2] = (mean, rstd)."""
-    _need_cuda(partial)
-    M, P, _ = partial.shape
-    assert partial.dtype == torch.float32 and partial.is_contiguous()
-    if out is None:
-        out = torch.empty(M, 2, device=partial.device, dtype=torch.float32)
-    check(lib().sc_ln_stats_finalize(ptr(partial), P, ptr(out), M, D, eps, stream()), "sc_ln_stats_finalize")
-    return out
-
-
-def weighted_sum_ln(h0, ypre, gamma, beta, weights, eps=1e-5):
-    """h0 bf16 [rows, D] (normalised layer-0 state); ypre bf16 [n-1, rows, D] pre-LayerNorm outputs of layers 1..n-1; gamma/beta f32 [n-1, D]
-    (their LayerNorm affines); weights f32 [n] (pre-softmax).  -> bf16 [rows, D] = sum_l softmax(w)_l * (l == 0 ? h0 : bf16(LN_l(ypre_l)))."""
-    _need_cuda(h0, ypre, weights)
-    rows, D = h0.shape
-    n = weights.shape[0]
-    assert h0.dtype == bf16 and h0.is_contiguous() and ypre.dtype == bf16 and ypre.is_contiguous() and ypre.shape == (n - 1, rows, D)
-    assert gamma.shape == (n - 1, D) and beta.shape == (n - 1, D) and gamma.is_contiguous() and beta.is_contiguous() and weights.dtype == torch.float32
-    out = torch.empty(rows, D, device=h0.device, dtype=bf16)
-    check(lib().sc_weighted_sum_ln_fwd(ptr(h0), ptr(ypre), rows * D, ptr(gamma), ptr(beta), ptr(weights), ptr(out), n, rows, D, eps, stream()),
-          "sc_weighted_sum_ln_fwd")
-    return out
-
-
 def gemm_batched(a, lda, stride_a, w, stride_w, w_mod, out, ldc, stride_c, bias, M, N, K, batch, act=ACT_NONE, ldw=None):
     """`batch` products out_z[M,N] = a_z[M,K] w_{z % w_mod}[N,K]^T (+ bias); operand z at base + z * stride (elements); `a`, `w`, `out` may be
     views whose data_ptr is operand 0.  out dtype f32 => fp32 outputs."""

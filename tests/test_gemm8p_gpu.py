@@ -92,9 +92,9 @@ def test_gemm8p_operands_beyond_32bit_offsets(force_8p):
 
 
 def test_gemm8p_dynamic_tile_order_equals_static_and_survives_ring_reuse():
-    """The persistent kernel takes its tiles from per-XCD counters (one 64-byte slot of a 4096-slot ring per launch, re-armed by the launch's last block;
+    """The persistent kernel takes its tiles from per-XCD counters (one 64-byte slot of a 4096-slot ring per launch, words tagged with the launch's generation;
     gemm8p.hip, K >= 384).  Mode 26 = the static stride order.  Same tiles, same arithmetic per tile -> bit-identical outputs; more launches than ring
-    slots, half of them racing on a second stream, must leave every slot armed."""
+    slots, half of them racing on a second stream, must find every slot usable."""
     from speechclip_amd import ops
     from speechclip_amd._lib import lib
     g = torch.Generator().manual_seed(11)
@@ -131,7 +131,7 @@ def test_gemm8p_dynamic_tile_order_equals_static_and_survives_ring_reuse():
 
 
 def test_gelu_epilogue_every_bf16_input():
-    """The fused-GELU epilogue (packed-half polynomial, common.h gelu_poly2_x8) on EVERY finite bf16 pre-activation with |x| <= 60000, each fed through the
+    """The fused-GELU epilogue (packed-half polynomial -- degree 4 since round 6 --, common.h gelu_poly2_x8) on EVERY finite bf16 pre-activation with |x| <= 60000, each fed through the
     kernel exactly (one non-zero per A row against an identity W): against exact erf-GELU within bf16 rounding + the polynomial's 3.2e-3, and saturated
     exactly (y == x / y == 0) beyond |x| = 5.5 -- the region where only the clamp of Phi keeps the un-clamped polynomial argument in check.
     Reference arithmetic: torch.nn.functional.gelu (fairseq TransformerSentenceEncoderLayer activation_fn, speech_encoder_plus.py:49-56 [3P])."""

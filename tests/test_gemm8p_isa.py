@@ -40,12 +40,23 @@ def test_no_variant_spills(kernels):
 
 def test_tile_counter_result_register_is_untouched_while_in_flight(kernels):
     for name, body in kernels.items():
-        m = re.search(r"global_atomic_add (v\d+), v\[\d+:\d+\], v\d+, off sc0", body)
+        # (round 6: 64-bit counter words, generation in the high half: global_atomic_add_x2 into a register PAIR; the low register goes to LDS)
+        m = re.search(r"global_atomic_add_x2 v\[(\d+):(\d+)\], v\[\d+:\d+\], v\[\d+:\d+\], off sc0", body)
         assert m, name
-        reg = m.group(1)
-        uses = [l.strip() for l in body.splitlines() if re.search(r"\b" + reg + r"\b", l) and not l.strip().startswith(";")]
+        lo, hi = int(m.group(1)), int(m.group(2))
+        assert hi == lo + 1
+
+        def touches(line):
+            if re.search(r"\bv%d\b|\bv%d\b" % (lo, hi), line):
+                return True
+            for a, b in re.findall(r"v\[(\d+):(\d+)\]", line):
+                if int(a) <= hi and int(b) >= lo:
+                    return True
+            return False
+        uses = [l.strip() for l in body.splitlines() if not l.strip().startswith(";") and touches(l)]
         kinds = [u.split()[0] for u in uses]
-        assert kinds == ["v_mov_b32_e32", "global_atomic_add", "ds_write_b32"], (name, uses)
+        assert kinds.count("global_atomic_add_x2") == 1 and kinds[-1] == "ds_write_b32" and kinds[-2] == "global_atomic_add_x2", (name, uses)
+        assert all(k in ("v_mov_b32_e32", "v_mov_b64_e32") for k in kinds[:-2]) and 1 <= len(kinds[:-2]) <= 2, (name, uses)
 
 
 def test_residual_epilogues_wait_by_count_only(kernels):

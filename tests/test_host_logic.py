@@ -749,6 +749,21 @@ def test_mlp_layers_state_dict_layout_is_the_references():
     assert isinstance(br.linear_proj, MLPLayers) and "linear_proj.sequential.3.weight" in br.state_dict()
 
 
+def test_trainable_params_refuse_projection_heads_but_not_nested_mlps():
+    """getTrainableParams refuses the optional *_projection MLP heads of the model (kwClip.py:1161-1190: eval-only here, README gaps) when the optimizer
+    is built -- and ONLY those four attributes: a kw_projection MLP nested inside the cascaded branch must not trip it (that path has its own check)."""
+    from speechclip_amd.base import OrderedNamespace
+    from speechclip_amd.module import MLPLayers
+    model = _tiny_model()
+    assert len(model.getTrainableParams()) > 0
+    d = model.config.model_settings.cascaded_branch.transformer_args.d_model
+    model.cascaded_branch.linear_proj = MLPLayers(units=[d, 48, model.subword_embd_dim], dropout=0.1)       # nested MLP: allowed to build an optimizer
+    assert len(model.getTrainableParams()) > 0
+    model.img_enc_proj_net = MLPLayers(units=[16, 16], dropout=0.0)
+    with pytest.raises(NotImplementedError, match="img_enc_proj_net"):
+        model.getTrainableParams()
+
+
 def test_collate_general_matches_reference_golden():
     """speechclip_amd.data.collate_general vs the reference's collate_general on the same ragged rows (tests/golden/small_ops.npz)."""
     from speechclip_amd.data import collate_general

@@ -19,6 +19,5 @@ for i in $(seq $P); do
     run "band=3" SC_GEMM_BAND=3
     run "min_tiles=160 (ViT out/fc2 on 128^2)" SC_GEMM_MIN_TILES=160
     run "min_tiles=460 (+ ViT QKV)" SC_GEMM_MIN_TILES=460
-    run "SC_FOLD_LN=1" SC_FOLD_LN=1
     run "SC_OVERLAP_VIT=0 (serial towers)" SC_OVERLAP_VIT=0
 done
