@@ -27,7 +27,19 @@
 #include <thread>
 #include <vector>
 
+#ifdef PROBE_F16      // same probe on v_mfma_f32_*_f16 (operands reinterpreted as half: random bf16 bit patterns are random, mostly tiny, halves -- so the fill below is re-made as half)
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;
+#define MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define MFMA32 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define MN16 "v_mfma_f32_16x16x32_f16"
+#define MN32 "v_mfma_f32_32x32x16_f16"
+#else
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+#define MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MFMA32 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define MN16 "v_mfma_f32_16x16x32_bf16"
+#define MN32 "v_mfma_f32_32x32x16_bf16"
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
@@ -86,8 +98,8 @@ __global__ __launch_bounds__(WPS * 256) void probe(const bf16x8_t* __restrict__ 
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[h][j]), "v"(fa[h][i]));
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[h][j], fa[h][i], acc[i][j], 0, 0, 0);
+                        if constexpr (AGPR) asm volatile(MN16 " %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[h][j]), "v"(fa[h][i]));
+                        else acc[i][j] = MFMA16(fb[h][j], fa[h][i], acc[i][j], 0, 0, 0);
                     }
                 if constexpr (LDS) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -141,8 +153,8 @@ __global__ __launch_bounds__(WPS * 256) void probe(const bf16x8_t* __restrict__ 
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[s][j]), "v"(fa[s][i]));
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);
+                        if constexpr (AGPR) asm volatile(MN32 " %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[s][j]), "v"(fa[s][i]));
+                        else acc[i][j] = MFMA32(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);
                     }
                 if constexpr (LDS) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -261,7 +273,12 @@ int main(int argc, char** argv) {
         unsigned long long s = 0x9E3779B97F4A7C15ull;
         auto u = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0; };
         for (auto& x : h) { const double g = (u() + u() + u() + u() - 2.0) * 0.866;      // ~N(0, 0.25): sigma 0.5
-            float f = (float)g; unsigned int b; memcpy(&b, &f, 4); x = (unsigned short)((b + 0x7fff + ((b >> 16) & 1)) >> 16); }
+            float f = (float)g;
+#ifdef PROBE_F16
+            _Float16 hf = (_Float16)f; memcpy(&x, &hf, 2); }
+#else
+            unsigned int b; memcpy(&b, &f, 4); x = (unsigned short)((b + 0x7fff + ((b >> 16) & 1)) >> 16); }
+#endif
         HIPCHECK(hipMemcpy(rnd, h.data(), h.size() * 2, hipMemcpyHostToDevice));
         HIPCHECK(hipMemset(zero, 0, 65536 * 16));
     }
