@@ -130,6 +130,64 @@ def test_gemm8p_dynamic_tile_order_equals_static_and_survives_ring_reuse():
     torch.testing.assert_close(y_dyn.float(), _ref(a, w, bias, 1, r), atol=2e-2, rtol=2e-2)
 
 
+def test_dynamic_tile_order_survives_a_poisoned_counter_ring():
+    """a launch that faults or is torn down mid-flight leaves its slot of the tile-counter ring dirty; the launch that gets the slot next must
+    not read it as "tiles already taken" (silently skipped tiles).  Counter words carry the launch generation and every block raises its word to its own
+    generation before the first fetch (gemm8p.hip, g_sched).  Here: the WHOLE ring is overwritten with an old generation whose counts say every tile is gone
+    (sc_debug_poison_gemm_sched), on an output buffer pre-filled with NaN: the result must be bit-identical to the static order's, every time."""
+    from speechclip_amd import ops
+    from speechclip_amd._lib import lib
+    g = torch.Generator().manual_seed(13)
+    M, N, K = 256 * 70 + 36, 1024, 512                        # 284 tiles on 256 blocks, ragged last panel
+    a = (0.5 * torch.randn(M, K, generator=g)).to("cuda", torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16)
+    bias = torch.randn(N, generator=g).cuda()
+    try:
+        lib().sc_debug_set_gemm_mode(26)
+        y_static = ops.gemm(a, w, bias, 0)
+        lib().sc_debug_set_gemm_mode(16)
+        for _ in range(3):
+            torch.cuda.synchronize()
+            assert lib().sc_debug_poison_gemm_sched() == 0
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            y = ops.gemm(a, w, bias, 0, out=out)
+            assert lib().sc_gemm_last_path() == 3
+            assert torch.equal(y, y_static)
+    finally:
+        lib().sc_debug_set_gemm_mode(-1)
+
+
+@pytest.mark.parametrize("sigma,mean_tol,binned_tol", [(0.55, 1.6e-4, 3.5e-4), (1.0, 1.6e-4, 5.9e-4)])
+def test_gelu_epilogue_systematic_error(sigma, mean_tol, binned_tol):
+    """What the every-input test below cannot see: the SYSTEMATIC part of the polynomial's error.  Rounding noise averages out over the K sum of the next GEMM, an
+    approximation error (a smooth function of x) adds up coherently -- a minimax degree-4 fit passed every per-element tolerance and still moved the bench line's
+    centred cosine from 0.9966 to 0.9943 (EXPERIMENTS.md R6-3).  1 M pre-activations x ~ N(0, sigma^2) (the conv stack's and fc1's range) through the kernel (identity W):
+    the MEAN error and the density-weighted rms of the per-bin mean error (64 bins) must stay at the shipped fit's level.  float16 simulation of the instruction
+    sequence, sigma 0.55 / 1.0 -- mean: shipped fit -8.7e-5 / -5.7e-5, degree 6 -4.9e-5 / -4e-6, the rejected minimax fit -3.8e-4 / -2.9e-4;
+    binned rms: 2.2e-4 / 4.9e-4, 1.7e-4 / 4.3e-4, 5.5e-4 / 6.9e-4 (its floor is the half-precision rounding of Phi, deterministic per bf16 input value)."""
+    from speechclip_amd import ops
+    from speechclip_amd._lib import lib
+    g = torch.Generator().manual_seed(17)
+    a = (sigma * torch.randn(4096, 256, generator=g)).to(torch.bfloat16)
+    w = torch.eye(256, dtype=torch.bfloat16)
+    try:
+        lib().sc_debug_set_gemm_mode(16)
+        y = ops.gemm(a.cuda(), w.cuda(), None, 1).float().cpu()
+        assert lib().sc_gemm_last_path() == 3
+    finally:
+        lib().sc_debug_set_gemm_mode(-1)
+    x = a.double()
+    err = (y.double() - torch.nn.functional.gelu(x)).flatten()
+    assert abs(err.mean().item()) <= mean_tol, err.mean().item()
+    edges = torch.linspace(-4 * sigma, 4 * sigma, 65, dtype=torch.float64)
+    idx = torch.bucketize(x.flatten(), edges).clamp(1, 64) - 1
+    cnt = torch.zeros(64, dtype=torch.float64).index_add_(0, idx, torch.ones_like(err))
+    sm = torch.zeros(64, dtype=torch.float64).index_add_(0, idx, err)
+    bias = sm / cnt.clamp(min=1)
+    binned = torch.sqrt((cnt * bias * bias).sum() / cnt.sum()).item()
+    assert binned <= binned_tol, binned
+
+
 def test_gelu_epilogue_every_bf16_input():
     """The fused-GELU epilogue (packed-half polynomial -- degree 4 since round 6 --, common.h gelu_poly2_x8) on EVERY finite bf16 pre-activation with |x| <= 60000, each fed through the
     kernel exactly (one non-zero per A row against an identity W): against exact erf-GELU within bf16 rounding + the polynomial's 3.2e-3, and saturated

@@ -53,10 +53,19 @@ def test_tile_counter_result_register_is_untouched_while_in_flight(kernels):
                 if int(a) <= hi and int(b) >= lo:
                     return True
             return False
-        uses = [l.strip() for l in body.splitlines() if not l.strip().startswith(";") and touches(l)]
-        kinds = [u.split()[0] for u in uses]
-        assert kinds.count("global_atomic_add_x2") == 1 and kinds[-1] == "ds_write_b32" and kinds[-2] == "global_atomic_add_x2", (name, uses)
-        assert all(k in ("v_mov_b32_e32", "v_mov_b64_e32") for k in kinds[:-2]) and 1 <= len(kinds[:-2]) <= 2, (name, uses)
+        lines = [l.strip() for l in body.splitlines() if l.strip() and not l.strip().startswith(";")]
+        at = [k for k, l in enumerate(lines) if l.startswith("global_atomic_add_x2")]
+        assert len(at) == 1, name
+        at = at[0]
+        # forward: nothing touches the pair until the ds_write_b32 that hands the low word to the other waves
+        fwd = [l for l in lines[at + 1:] if touches(l)]
+        assert fwd and fwd[0].startswith("ds_write_b32"), (name, fwd[:3])
+        # backward: the nearest instructions touching the pair are its initialisation (one v_mov_b64 or two v_mov_b32), nothing between them and the atomic
+        back = [l for l in reversed(lines[:at]) if touches(l)][:2]
+        kinds = [l.split()[0] for l in back]
+        assert kinds and kinds[0] in ("v_mov_b32_e32", "v_mov_b64_e32"), (name, back)
+        if kinds[0] == "v_mov_b32_e32":
+            assert len(kinds) == 2 and kinds[1] == "v_mov_b32_e32", (name, back)
 
 
 def test_residual_epilogues_wait_by_count_only(kernels):
