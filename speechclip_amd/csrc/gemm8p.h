@@ -20,7 +20,6 @@ struct Gemm8pParams {
     int esteps;                        // 1 = the per-tile A/B kernel, else the persistent kernel
     int band;                          // gemm8p: N tiles per column band of the tile order (0: all of N)
     int sched;                         // in: >= 0 dynamic tile order allowed, -1 static (A/B); gemm8p.hip replaces it by the launch's counter slot
-    int stagger;                       // set by gemm8p.hip: start delay (cycles) of every second block of an XCD (fp32-output launches of few tile rounds), 0 = none
     unsigned sched_gen;                // set by gemm8p.hip: the launch's generation of that slot (see g_sched)
     unsigned long long* trace;         // PROBES: per-block cycle stamps
 };

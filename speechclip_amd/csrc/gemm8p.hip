@@ -40,9 +40,6 @@
 #ifndef SC_8P_BIAS_INIT       // 1: a tile's accumulators start from the bias (read from LDS in the first k-step's memory intervals) instead of zero: no bias add in the epilogue
 #define SC_8P_BIAS_INIT 1
 #endif
-#ifndef SC_8P_STAGGER_F32_PCT      // default start delay of every second block in fp32-output launches of 1.2 .. 4 tile rounds, percent of a tile's time (0 = off)
-#define SC_8P_STAGGER_F32_PCT 0
-#endif
 #ifndef SC_8P_DYN             // 1: the persistent kernel takes its tiles from per-XCD counters (Gemm8pParams::sched >= 0) instead of a fixed stride
 #define SC_8P_DYN 1
 #endif
@@ -284,6 +281,9 @@ template <int ACT, bool RES, bool F32>
 __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
     // (fp32 outputs keep the plain pairing: their epilogues move 512 KiB per tile and are bound by the CU's load / store path -- side by side they
     //  measured 6 % slower (P-large out-proj 740 -> 697 TF/s), one after the other group 0's stores overlap group 1's residual loads)
+    // (round 6: starting every second block of an XCD 25 / 50 / 75 % of a tile late in the ~2-round fp32-epilogue launches of P-large, to take the CUs out of lock step --
+    //  k-loops with HBM idle, then 512 KiB epilogues with the matrix pipes idle, all at once: out-proj 745 -> 740 / 697 / 662 TF/s, fc2 1 113 -> 1 085 / 1 025 / 992, P-large step
+    //  40.3 -> 40.4 / 40.8 / 41.1 ms.  The delay simply adds: the epilogues are not slowed by each other.  profiles/r06_fp32_epilogue_stagger_ab.txt.  Removed.)
     constexpr bool PAIR = SC_8P_EPI_PAIR && !F32;
     static_assert(!(SC_8P_RES_LATE && RES && F32), "SC_8P_RES_LATE (A/B build) re-issues the skipped refill only from the bf16 residual epilogue: not with fp32 outputs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -390,12 +390,6 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
         const int k0 = kofs(0, rot), k1 = kofs(1, rot);
         stage_a(ta, 0, k0, b0); stage_a(ta, 1, k0, b0); stage_b(tw, 0, k0, b0); stage_b(tw, 1, k0, b0);
         stage_b(tw, 0, k1, b1); stage_b(tw, 1, k1, b1); stage_a(ta, 0, k1, b1); stage_a(ta, 1, k1, b1);          // nk >= 2 (host check)
-        // Stagger (p.stagger > 0: launches of few tile rounds with fp32 epilogues): every second block of an XCD starts that many cycles late.  With ~2 rounds of
-        // equal tiles all 256 CUs otherwise sit in their k-loops (HBM idle) and then in their 512 KiB epilogues (matrix pipes idle) at the same time.
-        if (p.stagger > 0 && (slot_in_xcd & 1)) {
-            const unsigned long long t0 = __builtin_readcyclecounter();
-            while (__builtin_readcyclecounter() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(32);
-        }
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -853,10 +847,6 @@ int sc_gemm8p_try(const Gemm8pParams& pin, hipStream_t s) {
         if (dyn) { const unsigned long long seq = sched_seq.fetch_add(1); p.sched = (int)(seq % SCHED_RING); p.sched_gen = (unsigned)(seq / SCHED_RING + 1); }
         else p.sched = -1;
         if (p.out_f32) {
-            // (A/B knob of round 6: SC_GEMM_STAGGER_F32 = percent of one tile's time -- nk k-steps + an fp32 epilogue -- that odd blocks start late; launches of < 4 tile rounds)
-            static const int stagger_pct = getenv("SC_GEMM_STAGGER_F32") ? atoi(getenv("SC_GEMM_STAGGER_F32")) : SC_8P_STAGGER_F32_PCT;
-            const double rounds = (double)grid / pg;
-            p.stagger = (stagger_pct > 0 && rounds > 1.2 && rounds < 4.0) ? (int)((p.nk * 2900.0 + (res ? 22000.0 : 9000.0)) * stagger_pct / 100.0) : 0;
             switch (p.act) {
                 case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false, true>(p, pg, s);
                 case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true, true>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false, true>(p, pg, s);
