@@ -13,33 +13,36 @@ namespace {
 
 constexpr int CK = 10, CS = 5;        // conv0 kernel / stride
 constexpr int NSTAT = CK + CK * (CK + 1) / 2;  // 65
-constexpr int NSPLIT = 8;
+constexpr int NSPLIT = 16;
 
+// (round 6: products and the per-thread / per-wave partial sums in fp32 -- a thread sees <= 8 frames, a wave 512: ~1e-7 relative --, fp64 only across waves, splits and
+//  in conv0_coef_kernel where the variance's cancellation happens; 16 instead of 8 splits per utterance.  The all-fp64 form spent half its time in 65 double-precision wave
+//  reductions and ran at 0.12 of the HBM roofline as the first, un-overlapped kernel of the step.)
 __global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restrict__ wav, int64_t ld, int T0, double* __restrict__ partial) {
     __shared__ double red[4][NSTAT];
     const int b = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* x = wav + (int64_t)b * ld;
     const int per = (T0 + NSPLIT - 1) / NSPLIT;
     const int t_lo = sp * per, t_hi = min(T0, t_lo + per);
-    double acc[NSTAT];
+    float acc[NSTAT];
 #pragma unroll
-    for (int i = 0; i < NSTAT; ++i) acc[i] = 0.0;
+    for (int i = 0; i < NSTAT; ++i) acc[i] = 0.f;
     for (int t = t_lo + tid; t < t_hi; t += 256) {
-        double xv[CK];
+        float xv[CK];
 #pragma unroll
-        for (int j = 0; j < CK; ++j) xv[j] = (double)x[(int64_t)CS * t + j];
+        for (int j = 0; j < CK; ++j) xv[j] = x[(int64_t)CS * t + j];
         int idx = CK;
 #pragma unroll
         for (int j = 0; j < CK; ++j) {
             acc[j] += xv[j];
 #pragma unroll
-            for (int k = j; k < CK; ++k) acc[idx++] += xv[j] * xv[k];
+            for (int k = j; k < CK; ++k) { acc[idx] = fmaf(xv[j], xv[k], acc[idx]); ++idx; }
         }
     }
 #pragma unroll
     for (int i = 0; i < NSTAT; ++i) {
-        double r = wave_sum_d(acc[i]);
-        if (lane == 0) red[wv][i] = r;
+        const float r = wave_sum(acc[i]);
+        if (lane == 0) red[wv][i] = (double)r;
     }
     __syncthreads();
     if (tid < NSTAT) partial[((int64_t)b * NSPLIT + sp) * NSTAT + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];

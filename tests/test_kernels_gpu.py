@@ -164,12 +164,14 @@ def test_cls_attention(NQ, H, hd, T):
     torch.testing.assert_close(y.float(), ref, atol=2e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("C,L", [(512, 16000), (32, 8000), (512, 4000)])
-def test_conv0_groupnorm_gelu(C, L):
+@pytest.mark.parametrize("C,L,dc", [(512, 16000, 0.01), (32, 8000, 0.01), (512, 4000, 0.01), (512, 160000, 0.5)])
+def test_conv0_groupnorm_gelu(C, L, dc):
+    """(dc = 0.5 at 10 s: a wave with a DC offset 2.5 x its own deviation -- the GroupNorm variance is then a small difference of large sums, which the statistics kernel's
+    fp32-inside-a-wave / fp64-across partial sums must survive; round 6)"""
     from speechclip_amd import ops
     g = _g(C + L)
     B = 3
-    wav = torch.randn(B, L, generator=g) * 0.2 + 0.01
+    wav = torch.randn(B, L, generator=g) * 0.2 + dc
     wav[1, L // 2:] = 0
     w = torch.randn(C, 10, generator=g) * 0.4
     gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
