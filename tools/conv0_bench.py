@@ -22,3 +22,14 @@ for _ in range(5):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print(f"conv0 (stats + coef + fwd): {ms:.3f} ms  {B * P * C * 2 / ms / 1e9:.2f} TB/s written")
+# (round 6) the same launch without GroupNorm + GELU (conv + bias only): how far the GELU / normalise vector work keeps the kernel from the write ceiling
+bias = torch.zeros(C).cuda()
+for _ in range(2):
+    ops.conv0(wav, w, T0, P, bias=bias, out=out)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(5):
+    ops.conv0(wav, w, T0, P, bias=bias, out=out)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+print(f"conv0 raw (W fragments + forward, bias, no GELU): {ms:.3f} ms  {B * P * C * 2 / ms / 1e9:.2f} TB/s written")
