@@ -14,6 +14,12 @@ namespace {
 constexpr int CK = 10, CS = 5;        // conv0 kernel / stride
 constexpr int NSTAT = CK + CK * (CK + 1) / 2;  // 65
 constexpr int NSPLIT = 16;
+#ifndef SC_CONV0_FB_DEFAULT
+#define SC_CONV0_FB_DEFAULT 512
+#endif
+#ifndef SC_CONV0_THREADS_DEFAULT
+#define SC_CONV0_THREADS_DEFAULT 512      // 8 waves share one 32 KiB copy of the W fragments: 6 instead of 4 waves per SIMD fit (LDS was the limit); -0.17 ms, profiles/r06_conv0_ab.txt
+#endif
 
 // (round 6: products and the per-thread / per-wave partial sums in fp32 -- a thread sees <= 8 frames, a wave 512: ~1e-7 relative --, fp64 only across waves, splits and
 //  in conv0_coef_kernel where the variance's cancellation happens; 16 instead of 8 splits per utterance.  The all-fp64 form spent half its time in 65 double-precision wave
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256) void conv0_wfrag_kernel(const float* __restric
     }
 }
 template <int FB>   // frames per block
-__global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict__ wav, int64_t ld, int64_t L, const bf16x8_t* __restrict__ wfrag,
+__global__ __launch_bounds__(512) void conv0_mfma_kernel(const float* __restrict__ wav, int64_t ld, int64_t L, const bf16x8_t* __restrict__ wfrag,
                                                          const float* __restrict__ bias, const float2* __restrict__ coef, bf16_t* __restrict__ out,
                                                          int C, int T0, int P_uniform, int mode, const int32_t* __restrict__ row_off, int row_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_c0[];
@@ -182,18 +188,19 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
     if (t0 >= P) return;
     const float* x = wav + (int64_t)b * ld;
     const int nfr = min(FB, P - t0);
-    for (int i = tid; i < nfr * CS + CK; i += 256) {
+    const int nthr = blockDim.x, nwav = nthr >> 6;      // 256 or 512 threads (the W fragments in LDS are shared by all waves of the block)
+    for (int i = tid; i < nfr * CS + CK; i += nthr) {
         const int64_t si = (int64_t)t0 * CS + i;
         xs[i] = si < L ? x[si] : 0.f;
     }
-    for (int i = tid; i < 32 * 64; i += 256) wl[i] = wfrag[(int64_t)b * 32 * 64 + i];
+    for (int i = tid; i < 32 * 64; i += nthr) wl[i] = wfrag[(int64_t)b * 32 * 64 + i];
     const int frow = lane & 15, fk = lane >> 4;
     const int ncb = C / 16;
     const int srow = lane >> 2, schunk = lane & 3;       // epilogue lane geometry (as gemm256_kernel)
     const int bperm = ((((schunk & 1) << 1) | (schunk >> 1)) * 16 + srow) << 2;
     __syncthreads();
     const int ngroups = nfr / 16;                         // P is a multiple of 64
-    for (int gidx = wave; gidx < ngroups; gidx += 4) {
+    for (int gidx = wave; gidx < ngroups; gidx += nwav) {
         const int tg = t0 + gidx * 16;                    // first frame of the group
         // X fragment: frame tg + frow, slots fk*8..+7 (0-9 x_hi, 10-19 x_lo, 20-29 x_hi, 30-31 one: the shift's slots)
         bf16x8_t xf;
@@ -207,6 +214,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
             xf[sidx] = (kind == 1 && slot < 30) ? (__bf16)(xv - (float)hi) : hi;
         }
         const bool live_row = (tg + srow) < T0;           // frames in [T0, P) are written as zeros
+        const bool all_live = tg + 16 <= T0;              // (wave-uniform: only an utterance's last group has dead frames)
         bf16_t* orow = out + (orow0 + tg + srow) * C + schunk * 8;
         f32x4_t acc[2][4];                                // two 64-channel chunks in flight: MFMAs of chunk q+1 issue before the epilogue of q
 #pragma unroll
@@ -220,15 +228,23 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
                     acc[(q + 1) & 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[((q + 1) * 4 + j) * 64 + lane], xf, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             }
             uint2 pk[4];
+            if (mode == 0) {      // all 8 value pairs of the chunk side by side (gelu_poly2_x8: the per-pair Horner chain is latency-bound -- one hazard s_nop per v_pk_fma_f16)
+                f32x2_t xs8[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4_t v4 = acc[q & 1][j];
-                if (mode == 0) {
-                    const f32x2_t g0 = gelu_poly2((f32x2_t){v4[0], v4[1]}), g1 = gelu_poly2((f32x2_t){v4[2], v4[3]});
-                    v4 = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4_t v4 = acc[q & 1][j];
+                    xs8[2 * j] = (f32x2_t){v4[0], v4[1]}; xs8[2 * j + 1] = (f32x2_t){v4[2], v4[3]};
                 }
-                pk[j].x = pack2bf(v4[0], v4[1]);
-                pk[j].y = pack2bf(v4[2], v4[3]);
+                gelu_poly2_x8(xs8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { pk[j].x = pack2bf(xs8[2 * j][0], xs8[2 * j][1]); pk[j].y = pack2bf(xs8[2 * j + 1][0], xs8[2 * j + 1][1]); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4_t v4 = acc[q & 1][j];
+                    pk[j].x = pack2bf(v4[0], v4[1]);
+                    pk[j].y = pack2bf(v4[2], v4[3]);
+                }
             }
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
                 const auto r1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp].y, pk[2 * jp + 1].y, false, false);
                 uint4 o = make_uint4(__builtin_amdgcn_ds_bpermute(bperm, r0[0]), __builtin_amdgcn_ds_bpermute(bperm, r1[0]),
                                      __builtin_amdgcn_ds_bpermute(bperm, r0[1]), __builtin_amdgcn_ds_bpermute(bperm, r1[1]));
-                if (!live_row) o = make_uint4(0, 0, 0, 0);
+                if (!all_live && !live_row) o = make_uint4(0, 0, 0, 0);
 #if defined(SC_CONV0_NT) && SC_CONV0_NT      // build option for A/B runs: streaming policy on the 8.4 GB output
                 typedef unsigned __attribute__((ext_vector_type(4))) u32x4_nt_t;
                 __builtin_nontemporal_store((u32x4_nt_t){o.x, o.y, o.z, o.w}, (u32x4_nt_t*)(orow + q * 64 + jp * 32));
@@ -422,11 +438,12 @@ static int conv0_fwd_impl(const float* wav, int64_t ld, int64_t L, const float* 
         SC_CHECK_ARG(wfrag_ws != nullptr, "sc_conv0_fwd: the matrix-core form needs the W-fragment workspace (sc_conv0_wfrag_workspace_bytes)");
         hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, w, (const float2*)coef, bias, (bf16x8_t*)wfrag_ws, C, mode);
         SC_CHECK_LAUNCH();
-        static const int fb = getenv("SC_CONV0_FB") ? atoi(getenv("SC_CONV0_FB")) : 256;   // measured 128..2048: 256 is the fastest
+        static const int fb = getenv("SC_CONV0_FB") ? atoi(getenv("SC_CONV0_FB")) : SC_CONV0_FB_DEFAULT;   // frames per block
+        static const int thr = getenv("SC_CONV0_THREADS") ? atoi(getenv("SC_CONV0_THREADS")) : SC_CONV0_THREADS_DEFAULT;   // 256 or 512 threads per block
 #define CONV0_LAUNCH(FB_) do {                                                                                                                   \
         const int lds = 32 * 64 * 16 + (FB_ * CS + 16) * 4;                                                                                  \
         (void)hipFuncSetAttribute((const void*)conv0_mfma_kernel<FB_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                           \
-        hipLaunchKernelGGL(conv0_mfma_kernel<FB_>, dim3((P + FB_ - 1) / FB_, B), dim3(256), lds, (hipStream_t)stream, wav, ld, L,                  \
+        hipLaunchKernelGGL(conv0_mfma_kernel<FB_>, dim3((P + FB_ - 1) / FB_, B), dim3(thr == 512 ? 512 : 256), lds, (hipStream_t)stream, wav, ld, L,                  \
                            (const bf16x8_t*)wfrag_ws, bias, (const float2*)coef, (bf16_t*)out, C, T0, P, mode, row_off, row_scale); } while (0)
         if (fb == 128) CONV0_LAUNCH(128); else if (fb == 512) CONV0_LAUNCH(512); else if (fb == 1024) CONV0_LAUNCH(1024); else CONV0_LAUNCH(256);
 #undef CONV0_LAUNCH
