@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) void posconv_pack_kernel(const bf16_t* __restr
 }
 
 // out[b,t,:] = [LN]( mask(x)[b,t,:] + gelu(cg_out[b,g,t,c] + bias) )
-template <bool OUT_F32>
+// CG: channels per group as a compile-time constant (48: HuBERT-base 768 / 16, 64: HuBERT-large 1024 / 16; 0 = runtime): the per-chunk `e / cg` was a ~25-instruction
+// integer division sequence, four times per row, in a kernel that is bound by vector issue (1 140 instructions per 768-element row; round 6).
+template <bool OUT_F32, int CG>
 __global__ __launch_bounds__(256) void posconv_finish_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ valid, const bf16_t* __restrict__ conv,
                                                              const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              void* __restrict__ out, int B, int Tp, int D, int G, float eps,
@@ -299,27 +301,36 @@ __global__ __launch_bounds__(256) void posconv_finish_kernel(const bf16_t* __res
         int lo = 0, hi = B;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)row_off[mid] <= row) lo = mid; else hi = mid; }
         b = lo; t = (int)(row - row_off[b]); Tp = row_off[b + 1] - row_off[b]; conv_row0 = (int64_t)row_off[b] * G;
-    } else { b = (int)(row / Tp); t = (int)(row - (int64_t)b * Tp); conv_row0 = (int64_t)b * G * Tp; }
-    const int cg = D / G;
+    } else { b = (int)((unsigned)row / (unsigned)Tp); t = (int)(row - (int64_t)b * Tp); conv_row0 = (int64_t)b * G * Tp; }      // (rows < 2^31: host check)
+    const int cg = CG ? CG : D / G;
     const bool live = t < valid[b];
+    // (round 6: 16-byte loads of bias / gamma / beta instead of one dword per element, the GELU as the packed-half polynomial of the GEMM epilogues for all value pairs
+    //  of the row side by side -- the result is rounded to bf16 behind the LayerNorm anyway --: ~1 140 -> ~520 vector / scalar instructions per row)
     float v[4][4];
+    f32x2_t gp[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int e = c * 256 + lane * 4;
+        gp[2 * c] = gp[2 * c + 1] = (f32x2_t){0.f, 0.f};
+        if (e < D) {
+            const int g = e / cg, ci = e - g * cg;  // cg % 4 == 0 so the 4 elements stay in one group
+            const uint2 cv = *(const uint2*)(conv + (conv_row0 + (int64_t)g * Tp + t) * cg + ci);
+            const f32x4_t b4 = *(const f32x4_t*)(bias + e);
+            gp[2 * c] = (f32x2_t){lo2f(cv.x) + b4[0], hi2f(cv.x) + b4[1]};
+            gp[2 * c + 1] = (f32x2_t){lo2f(cv.y) + b4[2], hi2f(cv.y) + b4[3]};
+        }
+    }
+    gelu_poly2_x8(gp);
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int e = c * 256 + lane * 4;
         v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
         if (e < D) {
-            const int g = e / cg, ci = e - g * cg;  // cg % 4 == 0 so the 4 elements stay in one group
-            const uint2 cv = *(const uint2*)(conv + (conv_row0 + (int64_t)g * Tp + t) * cg + ci);
-            float xv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (live) {
-                const uint2 xx = *(const uint2*)(x + row * D + e);
-                xv[0] = lo2f(xx.x); xv[1] = hi2f(xx.x); xv[2] = lo2f(xx.y); xv[3] = hi2f(xx.y);
-            }
-            v[c][0] = xv[0] + gelu_erf(lo2f(cv.x) + bias[e]);
-            v[c][1] = xv[1] + gelu_erf(hi2f(cv.x) + bias[e + 1]);
-            v[c][2] = xv[2] + gelu_erf(lo2f(cv.y) + bias[e + 2]);
-            v[c][3] = xv[3] + gelu_erf(hi2f(cv.y) + bias[e + 3]);
+            uint2 xx = make_uint2(0u, 0u);
+            if (live) xx = *(const uint2*)(x + row * D + e);
+            v[c][0] = lo2f(xx.x) + gp[2 * c][0]; v[c][1] = hi2f(xx.x) + gp[2 * c][1];
+            v[c][2] = lo2f(xx.y) + gp[2 * c + 1][0]; v[c][3] = hi2f(xx.y) + gp[2 * c + 1][1];
             s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
         }
     }
@@ -341,10 +352,12 @@ __global__ __launch_bounds__(256) void posconv_finish_kernel(const bf16_t* __res
     for (int c = 0; c < 4; ++c) {
         const int e = c * 256 + lane * 4;
         if (e < D) {
-            float o[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = gamma ? (v[c][i] - mean) * rstd * gamma[e + i] + beta[e + i] : v[c][i];
-            if (OUT_F32) *(f32x4_t*)((float*)out + row * D + e) = (f32x4_t){o[0], o[1], o[2], o[3]};
+            f32x4_t o = {v[c][0], v[c][1], v[c][2], v[c][3]};
+            if (gamma) {
+                const f32x4_t g4 = *(const f32x4_t*)(gamma + e), be4 = *(const f32x4_t*)(beta + e);
+                o = (o - mean) * rstd * g4 + be4;
+            }
+            if (OUT_F32) *(f32x4_t*)((float*)out + row * D + e) = o;
             else { uint2 p; p.x = pack2bf(o[0], o[1]); p.y = pack2bf(o[2], o[3]); *(uint2*)((bf16_t*)out + row * D + e) = p; }
         }
     }
@@ -481,9 +494,13 @@ extern "C" int sc_posconv_pack(const void* x, const int32_t* valid, void* xg, in
 static int posconv_finish_impl(const void* x, const int32_t* valid, const void* conv, const float* bias, const float* gamma, const float* beta,
                                void* out, int B, int Tp, int D, int G, int out_f32, float eps, void* stream, const int32_t* row_off, int64_t rows) {
     SC_CHECK_ARG(D <= 1024 && D % G == 0 && (D / G) % 4 == 0, "sc_posconv_finish: D<=1024 and D/G multiple of 4 required");
+    SC_CHECK_ARG(rows > 0 && rows < 0x7fffffffLL, "sc_posconv_finish: rows=%lld out of range", (long long)rows);
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (out_f32) hipLaunchKernelGGL((posconv_finish_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, valid, (const bf16_t*)conv, bias, gamma, beta, out, B, Tp, D, G, eps, row_off, rows);
-    else hipLaunchKernelGGL((posconv_finish_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, valid, (const bf16_t*)conv, bias, gamma, beta, out, B, Tp, D, G, eps, row_off, rows);
+    const int cgv = D / G;
+#define PF_LAUNCH(F32_, CG_) hipLaunchKernelGGL((posconv_finish_kernel<F32_, CG_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, valid, (const bf16_t*)conv, bias, gamma, beta, out, B, Tp, D, G, eps, row_off, rows)
+    if (out_f32) { if (cgv == 64) PF_LAUNCH(true, 64); else if (cgv == 48) PF_LAUNCH(true, 48); else PF_LAUNCH(true, 0); }
+    else { if (cgv == 64) PF_LAUNCH(false, 64); else if (cgv == 48) PF_LAUNCH(false, 48); else PF_LAUNCH(false, 0); }
+#undef PF_LAUNCH
     SC_CHECK_LAUNCH();
     return 0;
 }
