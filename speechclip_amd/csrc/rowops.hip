@@ -218,6 +218,50 @@ __global__ __launch_bounds__(256) void layernorm1024f_kernel(const float* __rest
 // Fast path for the HuBERT-large feature extractor (extractor_mode = layer_norm: LayerNorm over the 512 channels + GELU after every conv,
 // 8.3 GB per 64-utterance step): D = 512 bf16 -> bf16, a row is exactly one 16-byte chunk per lane; a wave owns four consecutive rows and
 // issues their loads up front.
+// fp32 rows of 768 (the pre-LN residual stream of CLIP ViT-B: ln_1 / ln_2 / ln_post read it, the GEMMs behind them take bf16): two rows per wave, 16-byte loads
+// (lane owns columns q * 256 + lane * 4 .. + 3, q = 0..2), 8-byte bf16 stores.  The generic kernel spent ~1 450 instructions per row pair on this shape (round 6).
+__global__ __launch_bounds__(256) void layernorm768f_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            bf16_t* __restrict__ out, int64_t rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= rows) return;
+    const bool two = row0 + 1 < rows;
+    f32x4_t v[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float* xr = x + (row0 + (two ? r : 0)) * 768 + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[r][q] = *(const f32x4_t*)(xr + q * 256);
+    }
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s += (v[r][q][0] + v[r][q][1]) + (v[r][q][2] + v[r][q][3]);
+        mean[r] = wave_sum(s) * (1.0f / 768.0f);
+        float qq = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float d = v[r][q][i] - mean[r]; qq += d * d; }
+        rstd[r] = rsqrtf(wave_sum(qq) * (1.0f / 768.0f) + eps);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int col = q * 256 + lane * 4;
+        const f32x4_t g4 = *(const f32x4_t*)(gamma + col), b4 = *(const f32x4_t*)(beta + col);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r && !two) continue;
+            const f32x4_t o = (v[r][q] - mean[r]) * rstd[r] * g4 + b4;
+            uint2 u;
+            u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
+            *(uint2*)(out + (row0 + r) * 768 + col) = u;
+        }
+    }
+}
+
 template <bool GELU>
 __global__ __launch_bounds__(256) void layernorm512_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            bf16_t* __restrict__ out, int64_t rows, float eps) {
@@ -382,6 +426,11 @@ extern "C" int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, co
     const bool in32 = flags & SC_LN_IN_F32, out32 = flags & SC_LN_OUT_F32;
     if (D == 1024 && in32 && !out32 && !gelu && gamma && ld_in == 1024 && ld_out == 1024 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
         hipLaunchKernelGGL(layernorm1024f_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const float*)x, gamma, beta, (bf16_t*)out, rows, eps);
+        SC_CHECK_LAUNCH();
+        return 0;
+    }
+    if (D == 768 && in32 && !out32 && !gelu && gamma && ld_in == 768 && ld_out == 768 && (((uintptr_t)x & 15) | ((uintptr_t)out & 7)) == 0) {
+        hipLaunchKernelGGL(layernorm768f_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const float*)x, gamma, beta, (bf16_t*)out, rows, eps);
         SC_CHECK_LAUNCH();
         return 0;
     }

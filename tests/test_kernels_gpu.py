@@ -68,6 +68,18 @@ def test_layernorm_1024_f32_fast_path():
         torch.testing.assert_close(y.float(), F.layer_norm(x, (1024,), gamma, beta, 1e-5), atol=2e-2, rtol=2e-2)
 
 
+def test_layernorm_768_f32_fast_path():
+    """The pre-LN residual stream of CLIP ViT-B/32: fp32 [rows, 768] -> bf16 (layernorm768f_kernel, round 6); ragged row counts, odd tails."""
+    from speechclip_amd import ops
+    g = _g(768)
+    for rows in (1, 2, 7, 8, 9, 12800 + 3):
+        x = (torch.randn(rows, 768, generator=g) * 3 - 1).cuda()
+        gamma, beta = (1 + 0.3 * torch.randn(768, generator=g)).cuda(), (0.3 * torch.randn(768, generator=g)).cuda()
+        y = ops.layernorm(x, gamma, beta)
+        assert y.dtype == BF and y.shape == x.shape
+        torch.testing.assert_close(y.float(), F.layer_norm(x, (768,), gamma, beta, 1e-5), atol=2e-2, rtol=2e-2)
+
+
 def test_layernorm_strided_rows():
     from speechclip_amd import ops
     x = torch.randn(6, 5, 768, generator=_g(1)).cuda()
