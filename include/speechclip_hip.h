@@ -114,7 +114,7 @@ int sc_splitk_reduce_f32(const float* partials, int nsplit, int64_t M, int N, co
 
 /* ---- Per-utterance wave layer-norm -- speech_encoder_plus.py:507-508 (task.cfg.normalize) -----
  * out[b,:len_b] = layer_norm(wav[b,:len_b]); out[b,len_b:] = 0.  wav/out are [B, ld] f32. */
-int sc_wave_layernorm(const float* wav, float* out, const int32_t* lens, int B, int64_t ld, float eps, void* stream);
+int sc_wave_layernorm(const float* wav, float* out, const int32_t* lens, int B, int64_t ld, float eps, void* stream);   /* `out` must not alias `wav` (several blocks per utterance read the whole row) */
 
 /* ---- Attention ---------------------------------------------------------------------------------
  * Flash-style forward, head_dim 64, per-utterance key lengths (klens[b] keys valid; NULL = T).
@@ -187,7 +187,9 @@ int sc_cls_pool_fwd_split(const void* x, int64_t ld_x, const void* cls_tok, cons
  * (P >= T0 rows per utterance; rows >= T0 are written as zeros).
  * sc_conv0_gn_coef: per-(b,c) GroupNorm scale/shift from the 10x10 sample autocorrelation
  * (fp64) -- the statistics are over all T0 frames of the padded batch, as in the reference.
- * sc_conv0_fwd mode 0: conv -> GroupNorm(coef) -> GELU; mode 1: conv + bias (no norm, no act). */
+ * sc_conv0_fwd mode 0: conv -> GroupNorm(coef) -> GELU; mode 1: conv + bias (no norm, no act); mode 2: conv + bias -> LayerNorm over the C channels of every
+ * frame -> GELU (the first layer of an extractor_mode = "layer_norm" feature extractor, HuBERT-large: fairseq ConvFeatureExtractionModel [3P] via
+ * speech_encoder_plus.py:75) with `coef` = gamma[C] | beta[C] | eps (2 C + 1 floats); C % 64 == 0 and P % 64 == 0. */
 int64_t sc_conv0_stats_workspace_bytes(int B);
 int sc_conv0_gn_coef(const float* wav, int64_t ld, const float* w, const float* gamma, const float* beta, void* workspace,
                      float* coef, int B, int C, int T0, float eps, void* stream);

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void conv0_wfrag_kernel(const float* __restric
         const int cb = i >> 6, lane = i & 63, frow = lane & 15, fk = lane >> 4;
         const int c = cb * 16 + frow;
         const float scl = (cb < ncb) ? (mode == 0 ? coef[(int64_t)b * C + c].x : 1.0f) : 0.f;
-        const float shift = (cb < ncb) ? (mode == 0 ? coef[(int64_t)b * C + c].y : (bias ? bias[c] : 0.f)) : 0.f;
+        const float shift = (cb < ncb) ? (mode == 0 ? coef[(int64_t)b * C + c].y : (bias ? bias[c] : 0.f)) : 0.f;      // (mode 2: conv + bias here, LayerNorm in the forward kernel)
         const __bf16 shift_hi = (__bf16)shift;
         bf16x8_t f;
 #pragma unroll
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(512) void conv0_mfma_kernel(const float* __restrict
                                                          int C, int T0, int P_uniform, int mode, const int32_t* __restrict__ row_off, int row_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_c0[];
     bf16x8_t* wl = (bf16x8_t*)smem_c0;                    // [32][64] W fragments (32 KiB)
-    float* xs = (float*)(smem_c0 + 32 * 64 * 16);         // FB * 5 + 8 samples
+    float* lnp = (float*)(smem_c0 + 32 * 64 * 16);        // mode 2: LayerNorm gamma[512] | beta[512] of the extractor's layer 0 (HuBERT-large: extractor_mode "layer_norm")
+    float* xs = lnp + 1024;                               // FB * 5 + 8 samples
     const int b = blockIdx.y, t0 = blockIdx.x * FB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // packed batches: utterance b owns output rows [row_scale * row_off[b], row_scale * row_off[b + 1]) (row_off counts transformer frames,
     // row_scale = the conv stack's total stride after layer 0); frames >= T0 are written as zeros as in the uniform layout
@@ -194,6 +195,12 @@ __global__ __launch_bounds__(512) void conv0_mfma_kernel(const float* __restrict
         xs[i] = si < L ? x[si] : 0.f;
     }
     for (int i = tid; i < 32 * 64; i += nthr) wl[i] = wfrag[(int64_t)b * 32 * 64 + i];
+    float ln_eps = 0.f;
+    if (mode == 2) {      // coef = gamma[C] | beta[C] | eps (floats)
+        const float* lp = (const float*)coef;
+        for (int c = tid; c < 1024; c += nthr) lnp[c] = (c & 511) < C ? lp[(c >> 9) * C + (c & 511)] : 0.f;
+        ln_eps = lp[2 * C];
+    }
     const int frow = lane & 15, fk = lane >> 4;
     const int ncb = C / 16;
     const int srow = lane >> 2, schunk = lane & 3;       // epilogue lane geometry (as gemm256_kernel)
@@ -216,6 +223,29 @@ __global__ __launch_bounds__(512) void conv0_mfma_kernel(const float* __restrict
         const bool live_row = (tg + srow) < T0;           // frames in [T0, P) are written as zeros
         const bool all_live = tg + 16 <= T0;              // (wave-uniform: only an utterance's last group has dead frames)
         bf16_t* orow = out + (orow0 + tg + srow) * C + schunk * 8;
+        // mode 2 (conv + bias -> LayerNorm over the C channels of every frame -> GELU): a first pass over the chunks for the per-frame sums (a lane's 4 x 4 values of
+        // a chunk all belong to frame lane & 15; the 4 lane groups of a frame meet by two shuffles), then the same MFMAs again for the output -- the kernel is bound by
+        // its stores, the matrix work is ~1 % of it.  Saves the separate LayerNorm + GELU pass over the largest activation of the extractor (4.2 GB of traffic at B = 64).
+        float ln_a = 1.f, ln_b = 0.f;                     // y_norm = y * ln_a + ln_b (then * gamma + beta per channel)
+        if (mode == 2) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q * 4 >= ncb) break;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4_t a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[(q * 4 + j) * 64 + lane], xf, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    s1 += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+                    s2 += (a4[0] * a4[0] + a4[1] * a4[1]) + (a4[2] * a4[2] + a4[3] * a4[3]);
+                }
+            }
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            const float mean = s1 / (float)C;
+            const float var = fmaxf(s2 / (float)C - mean * mean, 0.f);
+            ln_a = rsqrtf(var + ln_eps);
+            ln_b = -mean * ln_a;
+        }
         f32x4_t acc[2][4];                                // two 64-channel chunks in flight: MFMAs of chunk q+1 issue before the epilogue of q
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j * 64 + lane], xf, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -228,7 +258,14 @@ __global__ __launch_bounds__(512) void conv0_mfma_kernel(const float* __restrict
                     acc[(q + 1) & 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[((q + 1) * 4 + j) * 64 + lane], xf, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             }
             uint2 pk[4];
-            if (mode == 0) {      // all 8 value pairs of the chunk side by side (gelu_poly2_x8: the per-pair Horner chain is latency-bound -- one hazard s_nop per v_pk_fma_f16)
+            if (mode == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4_t g4 = *(const f32x4_t*)(lnp + (q * 4 + j) * 16 + fk * 4), b4 = *(const f32x4_t*)(lnp + 512 + (q * 4 + j) * 16 + fk * 4);
+                    acc[q & 1][j] = (acc[q & 1][j] * ln_a + ln_b) * g4 + b4;
+                }
+            }
+            if (mode != 1) {      // all 8 value pairs of the chunk side by side (gelu_poly2_x8: the per-pair Horner chain is latency-bound -- one hazard s_nop per v_pk_fma_f16)
                 f32x2_t xs8[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -444,17 +481,19 @@ static int conv0_fwd_impl(const float* wav, int64_t ld, int64_t L, const float* 
                           int C, int T0, int P, int mode, void* wfrag_ws, void* stream, const int32_t* row_off, int row_scale) {
     SC_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= 512, "sc_conv0_fwd: C=%d must be a multiple of 8, <= 512", C);
     SC_CHECK_ARG(row_off == nullptr || (C % 64 == 0 && P % 64 == 0 && row_scale % 64 == 0), "sc_conv0_fwd_packed: needs C %% 64 == 0 and row_scale %% 64 == 0");
-    SC_CHECK_ARG(mode == 1 || coef != nullptr, "sc_conv0_fwd: GroupNorm mode needs coef");
+    SC_CHECK_ARG(mode == 0 || mode == 1 || mode == 2, "sc_conv0_fwd: mode=%d must be 0 (GroupNorm + GELU), 1 (conv + bias) or 2 (conv + bias + LayerNorm + GELU)", mode);
+    SC_CHECK_ARG(mode == 1 || coef != nullptr, "sc_conv0_fwd: GroupNorm mode needs coef, LayerNorm mode gamma | beta | eps");
+    SC_CHECK_ARG(mode != 2 || (C % 64 == 0 && P % 64 == 0), "sc_conv0_fwd: the LayerNorm mode exists in the matrix-core form only (C %% 64 == 0, P %% 64 == 0)");
     SC_CHECK_ARG((P >= T0 || row_off) && B > 0 && B <= 65535, "sc_conv0_fwd: need P >= T0 and 0 < B <= 65535");
     static const bool force_valu = getenv("SC_CONV0_VALU") != nullptr;
-    if (C % 64 == 0 && P % 64 == 0 && (!force_valu || row_off)) {      // matrix-core form (every shipped config: C = 512)
+    if (C % 64 == 0 && P % 64 == 0 && (!force_valu || row_off || mode == 2)) {      // matrix-core form (every shipped config: C = 512)
         SC_CHECK_ARG(wfrag_ws != nullptr, "sc_conv0_fwd: the matrix-core form needs the W-fragment workspace (sc_conv0_wfrag_workspace_bytes)");
         hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, w, (const float2*)coef, bias, (bf16x8_t*)wfrag_ws, C, mode);
         SC_CHECK_LAUNCH();
         static const int fb = getenv("SC_CONV0_FB") ? atoi(getenv("SC_CONV0_FB")) : SC_CONV0_FB_DEFAULT;   // frames per block
         static const int thr = getenv("SC_CONV0_THREADS") ? atoi(getenv("SC_CONV0_THREADS")) : SC_CONV0_THREADS_DEFAULT;   // 256 or 512 threads per block
 #define CONV0_LAUNCH(FB_) do {                                                                                                                   \
-        const int lds = 32 * 64 * 16 + (FB_ * CS + 16) * 4;                                                                                  \
+        const int lds = 32 * 64 * 16 + (1024 + FB_ * CS + 16) * 4;                                                                                  \
         (void)hipFuncSetAttribute((const void*)conv0_mfma_kernel<FB_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                           \
         hipLaunchKernelGGL(conv0_mfma_kernel<FB_>, dim3((P + FB_ - 1) / FB_, B), dim3(thr == 512 ? 512 : 256), lds, (hipStream_t)stream, wav, ld, L,                  \
                            (const bf16x8_t*)wfrag_ws, bias, (const float2*)coef, (bf16_t*)out, C, T0, P, mode, row_off, row_scale); } while (0)

@@ -33,6 +33,10 @@ STAGE_HOOK = None
 CONV_LAYERS = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2
 
 
+# SC_CONV0_LN_FUSED=0 (A/B): conv layer 0 of a "layer_norm" extractor as conv + bias, then a separate LayerNorm + GELU pass (rounds 1-5)
+_CONV0_LN_FUSED = os.environ.get("SC_CONV0_LN_FUSED", "1") != "0"
+
+
 @dataclass
 class HubertConfig:
     extractor_mode: str = "default"      # "default": GroupNorm on conv layer 0 (base); "layer_norm": LN on every layer (large)
@@ -218,6 +222,14 @@ class HubertModel(nn.Module):
                 ln2=(w32(lyr.final_layer_norm.weight), w32(lyr.final_layer_norm.bias))))
         return P
 
+    @staticmethod
+    def _conv0_ln_coef(P):
+        """gamma | beta | eps of the extractor's first LayerNorm as ONE f32 tensor (the `coef` operand of sc_conv0_fwd mode 2), built once per packed weight set."""
+        if "conv0_ln_coef" not in P:
+            g, b = P["conv_ln"][0]
+            P["conv0_ln_coef"] = torch.cat([g.float().flatten(), b.float().flatten(), g.new_tensor([1e-5], dtype=torch.float32)]).contiguous()
+        return P["conv0_ln_coef"]
+
     def _buf(self, name, shape, dtype, dev, zero=False, cap=False):
         """Workspace tensors, reused across steps.  cap=False: keyed by the exact shape (fixed-shape batches).  cap=True (packed batches, whose
         row count changes every step): ONE flat allocation per (name, dtype) that only grows (in 1/8 steps, zero-filled so rows nobody wrote
@@ -330,11 +342,15 @@ class HubertModel(nn.Module):
         # ---- conv layer 0
         x = buf("conv0", (rows_all + 8, C), bf, dev, zero=True)
         if pack is not None:
-            if ln_mode:
+            if ln_mode and C % 64 == 0 and _CONV0_LN_FUSED:      # conv + bias + LayerNorm + GELU in one kernel (sc_conv0_fwd mode 2)
+                ops.conv0_packed(wav, P["conv0_w"], T0, off_i32, pack["scale0"], pack["rows_max"], Mt, bias=P["conv0_b"], out=x, ln_coef=self._conv0_ln_coef(P))
+            elif ln_mode:
                 ops.conv0_packed(wav, P["conv0_w"], T0, off_i32, pack["scale0"], pack["rows_max"], Mt, bias=P["conv0_b"], out=x)
                 ops.layernorm(x[:rows_all], *P["conv_ln"][0], gelu=True, out=x[:rows_all])
             else:
                 ops.conv0_packed(wav, P["conv0_w"], T0, off_i32, pack["scale0"], pack["rows_max"], Mt, gn_gamma=P["gn"][0], gn_beta=P["gn"][1], out=x)
+        elif ln_mode and C % 64 == 0 and P0 % 64 == 0 and _CONV0_LN_FUSED:
+            ops.conv0(wav, P["conv0_w"], T0, P0, bias=P["conv0_b"], out=x, ln_coef=self._conv0_ln_coef(P))
         elif ln_mode:
             ops.conv0(wav, P["conv0_w"], T0, P0, bias=P["conv0_b"], out=x)
             ops.layernorm(x[: B * P0], *P["conv_ln"][0], gelu=True, out=x[: B * P0])

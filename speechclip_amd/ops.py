@@ -346,8 +346,9 @@ def cls_pool(x_rows, cls16, scores, cls_scores, lens_i32, B, T, NQ, R, D, split=
     return xbar
 
 
-def conv0(wav, w, T0, P, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5, out=None):
-    """HuBERT conv layer 0.  wav f32 [B, L]; w f32 [C, 10].  GroupNorm+GELU if gn_gamma given, else raw conv + bias.
+def conv0(wav, w, T0, P, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5, out=None, ln_coef=None):
+    """HuBERT conv layer 0.  wav f32 [B, L]; w f32 [C, 10].  GroupNorm+GELU if gn_gamma given, else raw conv + bias -- followed, when ln_coef
+    (f32 [2 C + 1] = gamma | beta | eps) is given, by the LayerNorm over the channels + GELU of a "layer_norm" extractor in the same kernel.
     Returns channels-last bf16 [B, P, C] (+ (k-s) slack rows so the next conv-as-GEMM may over-read)."""
     _need_cuda(wav, w)
     B, L = wav.shape
@@ -364,8 +365,9 @@ def conv0(wav, w, T0, P, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5, out=N
         with _HbmSpan("conv0", B * L * 4 + B * P * C * 2):
             check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), None, ptr(coef), ptr(buf), B, C, T0, P, 0, ptr(wfrag), stream()), "sc_conv0_fwd")
     else:
+        assert ln_coef is None or (ln_coef.dtype == torch.float32 and ln_coef.numel() == 2 * C + 1 and ln_coef.is_contiguous())
         with _HbmSpan("conv0", B * L * 4 + B * P * C * 2):
-            check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), ptr(bias), None, ptr(buf), B, C, T0, P, 1, ptr(wfrag), stream()), "sc_conv0_fwd")
+            check(lib().sc_conv0_fwd(ptr(wav), L, L, ptr(w), ptr(bias), ptr(ln_coef), ptr(buf), B, C, T0, P, 1 if ln_coef is None else 2, ptr(wfrag), stream()), "sc_conv0_fwd")
     return buf
 
 
@@ -390,7 +392,7 @@ def posconv(x, valid_i32, wg, bias, gamma, beta, B, Tp, D, G, Kw, out=None, out_
 
 # ---------------------------------------------------------------------------------------------- padding-free (packed) batches
 # Utterance b owns rows [row_off[b], row_off[b + 1]) of every transformer-level tensor (module/hubert.py: extract_all_layers_packed).
-def conv0_packed(wav, w, T0, row_off_i32, row_scale, rows_max, total_rows, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5, out=None):
+def conv0_packed(wav, w, T0, row_off_i32, row_scale, rows_max, total_rows, gn_gamma=None, gn_beta=None, bias=None, eps=1e-5, out=None, ln_coef=None):
     """ops.conv0 writing utterance b at rows row_scale * row_off[b] ...; the GroupNorm statistics are those of the padded length T0."""
     _need_cuda(wav, w, row_off_i32)
     B, L = wav.shape
@@ -404,9 +406,13 @@ def conv0_packed(wav, w, T0, row_off_i32, row_scale, rows_max, total_rows, gn_ga
         coef = torch.empty(B, C, 2, device=wav.device, dtype=torch.float32)
         with _HbmSpan("conv0_gn_stats", B * L * 4):
             check(lib().sc_conv0_gn_coef(ptr(wav), L, ptr(w), ptr(gn_gamma), ptr(gn_beta), ptr(ws), ptr(coef), B, C, T0, eps, stream()), "sc_conv0_gn_coef")
+    mode = 0 if gn_gamma is not None else 1
+    if ln_coef is not None:      # conv + bias -> LayerNorm over the channels -> GELU in the same kernel (sc_conv0_fwd mode 2)
+        assert gn_gamma is None and ln_coef.dtype == torch.float32 and ln_coef.numel() == 2 * C + 1 and ln_coef.is_contiguous()
+        coef, mode = ln_coef, 2
     with _HbmSpan("conv0", row_scale * total_rows * (5 * 4 + C * 2)):
         check(lib().sc_conv0_fwd_packed(ptr(wav), L, L, ptr(w), None if gn_gamma is not None else ptr(bias), ptr(coef), ptr(out), B, C, T0,
-                                        ptr(row_off_i32), row_scale, row_scale * rows_max, 0 if gn_gamma is not None else 1, ptr(wfrag), stream()),
+                                        ptr(row_off_i32), row_scale, row_scale * rows_max, mode, ptr(wfrag), stream()),
               "sc_conv0_fwd_packed")
     return out
 

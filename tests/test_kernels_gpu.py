@@ -109,15 +109,16 @@ def test_l2norm_and_wave_layernorm():
     torch.testing.assert_close(ops.l2norm(x), x / x.norm(dim=-1, keepdim=True), atol=1e-6, rtol=1e-5)
     xb = x.to(BF)
     torch.testing.assert_close(ops.l2norm(xb), xb.float() / xb.float().norm(dim=-1, keepdim=True), atol=1e-6, rtol=1e-5)
-    wav = torch.randn(3, 5000, generator=_g(3)) * 0.1 + 0.02
-    lens = torch.tensor([5000, 1234, 1], dtype=torch.int32)
-    for i, l in enumerate(lens):
-        wav[i, l:] = 0
-    y = ops.wave_layernorm(wav.cuda(), lens.cuda())
-    for i, l in enumerate(lens.tolist()):
-        ref = F.layer_norm(wav[i, :l], (l,))
-        torch.testing.assert_close(y[i, :l].cpu(), ref, atol=2e-5, rtol=1e-4)
-        assert torch.all(y[i, l:] == 0)
+    for L, all_lens in ((5000, [5000, 1234, 1]), (5001, [5001, 4999, 7]), (160000, [160000, 96001, 48000])):      # (odd row pitch: the scalar path; 10 s: 8 blocks per utterance)
+        wav = torch.randn(3, L, generator=_g(3)) * 0.1 + 0.02
+        lens = torch.tensor(all_lens, dtype=torch.int32)
+        for i, l in enumerate(lens):
+            wav[i, l:] = 0
+        y = ops.wave_layernorm(wav.cuda(), lens.cuda())
+        for i, l in enumerate(lens.tolist()):
+            ref = F.layer_norm(wav[i, :l], (l,))
+            torch.testing.assert_close(y[i, :l].cpu(), ref, atol=2e-5, rtol=1e-4)
+            assert torch.all(y[i, l:] == 0)
 
 
 def _attn_ref(qkv, B, T, H, klens):
@@ -193,6 +194,30 @@ def test_conv0_groupnorm_gelu(C, L, dc):
     ref = F.gelu(F.group_norm(F.conv1d(wav[:, None], w[:, None], stride=5), C, gamma, beta, 1e-5)).transpose(1, 2)
     torch.testing.assert_close(y[:, :T0].float().cpu(), ref, atol=2e-2, rtol=2e-2)
     assert torch.all(y[:, T0:] == 0)
+
+
+@pytest.mark.parametrize("L,dc", [(16000, 0.0), (4000, 0.3)])
+def test_conv0_bias_layernorm_gelu_fused(L, dc):
+    """sc_conv0_fwd mode 2 (round 6): the first layer of a "layer_norm" feature extractor (HuBERT-large) -- Conv1d(1, 512, 10, 5) + bias -> LayerNorm over the 512
+    channels of every frame -> GELU -- in ONE kernel, against torch fp32 and against the two-kernel sequence it replaces (conv + bias, then sc_layernorm with GELU)."""
+    from speechclip_amd import ops
+    g = _g(7 + L)
+    B, C = 3, 512
+    wav = torch.randn(B, L, generator=g) * 0.3 + dc
+    wav[2, L // 3:] = 0
+    w = torch.randn(C, 10, generator=g) * 0.4
+    bias = 0.2 * torch.randn(C, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    T0 = (L - 10) // 5 + 1
+    P = (T0 + 63) // 64 * 64
+    coef = torch.cat([gamma, beta, torch.tensor([1e-5])]).cuda()
+    y = ops.conv0(wav.cuda(), w.cuda(), T0, P, bias=bias.cuda(), ln_coef=coef)[: B * P].view(B, P, C)
+    ref = F.gelu(F.layer_norm(F.conv1d(wav[:, None], w[:, None], bias, stride=5).transpose(1, 2), (C,), gamma, beta, 1e-5))
+    torch.testing.assert_close(y[:, :T0].float().cpu(), ref, atol=2e-2, rtol=2e-2)
+    assert torch.all(y[:, T0:] == 0)
+    two = ops.conv0(wav.cuda(), w.cuda(), T0, P, bias=bias.cuda())
+    two = ops.layernorm(two[: B * P], gamma.cuda(), beta.cuda(), gelu=True).view(B, P, C)
+    torch.testing.assert_close(y[:, :T0].float(), two[:, :T0].float(), atol=2e-2, rtol=2e-2)
 
 
 def test_conv0_raw_bias():
