@@ -312,6 +312,9 @@ def other_config(kind, dev, batch=None, steps=5, warmup=2):
     out = {"ms_per_step": round(dt / steps * 1e3, 3), "pairs_per_s": round(pps, 2), "pairs_per_gpu": B, "steps": steps, "warmup": warmup,
            "algorithmic_gflop_per_pair": round(gf, 2), "e2e_tflops": round(gf * pps / 1e3, 1), "e2e_frac": round(gf * pps / 1e3 / PEAK_BF16_TFLOPS, 4),
            "audio_samples_mean": int(sum(eff) / B), "loss": round(float(loss), 5)}
+    if large:      # the pre-LN speech tower's layers take IEEE-half GEMM / attention operands (module/hubert.py _PRELN_F16; same dense MFMA peak as bf16)
+        from speechclip_amd.module import hubert as _hb
+        out["layer_operands"] = "f16" if _hb._PRELN_F16 else "bf16"
     del model
     torch.cuda.empty_cache()
     return out
@@ -830,7 +833,8 @@ def main():
                            "CUs inside their event windows); peak 8000 GB/s (datasheet), ~6300 GB/s is what a copy reaches")
         out = {"metric": "speech-image pairs/sec/node (%s)" % ("Cascaded SpeechCLIP base" if casc else "Parallel SpeechCLIP %s" % args.model), "value": round(pairs_per_s, 2), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16",
+               "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+               "dtype": ("bf16 (f16 operands in the pre-LN HuBERT-large layers, fp32 accumulate and residual stream)" if large and os.environ.get("SC_PRELN_F16", "1") != "0" else "bf16"),
                "data": "synthetic" if not args.share_gpu else "synthetic; TEST HOOK --share-gpu: all ranks on one GPU over gloo, not a scaling measurement",
                "config": {"workload": ("Cascaded SpeechCLIP base (HuBERT-base + ViT-B/32 + CLIP text tower; flop model = the encoders' GEMMs, the keyword head adds < 1 %)" if casc else
                                        "Parallel SpeechCLIP large (HuBERT-large + ViT-L/14)" if large else "Parallel SpeechCLIP base (HuBERT-base + ViT-B/32)")

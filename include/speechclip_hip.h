@@ -47,6 +47,9 @@ const char* sc_last_error(void);
 #define SC_ACT_QUICKGELU 2  /* x*sigmoid(1.702x) (openai CLIP) */
 #define SC_GEMM_ACT_MASK 0x3
 #define SC_GEMM_OUT_F32 0x10      /* C (and residual, if given) are f32 instead of bf16 */
+#define SC_GEMM_F16 0x20          /* A, W -- and C / residual unless SC_GEMM_OUT_F32 -- are IEEE half instead of bf16 (`v_mfma_f32_16x16x32_f16`, RNE on the way out).  The
+                                   * frozen pre-LN encoder layers of HuBERT-large run in this format: 11 significand bits in the GEMM / attention operands, the precision the
+                                   * reference runs these models at on a GPU (fp16 autocast, config/speechCLIP/model_large/coco/spchclp_p.yaml:122) */
 #define SC_GEMM_RES_AFTER_ACT 0x0 /* residual is always added after the activation */
 
 int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -83,6 +86,7 @@ int sc_gemm_bf16_batched2(const void* A, int64_t lda, int64_t strideA, int64_t s
 #define SC_LN_IN_F32 0x1
 #define SC_LN_OUT_F32 0x2
 #define SC_LN_GELU 0x4
+#define SC_LN_OUT_F16 0x8         /* with SC_LN_IN_F32, 16-bit output: IEEE half instead of bf16 (the operand format of SC_GEMM_F16) */
 int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, const float* beta, void* out, int64_t ld_out,
                  int64_t rows, int D, float eps, int flags, void* stream);
 
@@ -122,9 +126,13 @@ int sc_wave_layernorm(const float* wav, float* out, const int32_t* lens, int B, 
  * is at column offset h*64.  Replaces fairseq MultiheadAttention (key_padding_mask -> -inf) inside
  * TransformerSentenceEncoderLayer (speech_encoder_plus.py:52) and CLIP's nn.MultiheadAttention
  * in ResidualAttentionBlock (clip_official.py:209; causal != 0 adds the text tower's build_attention_mask,
- * clip_official.py:249-262).  out: bf16 [B*T, H*64] rows of stride ld_out. */
+ * clip_official.py:249-262).  out: bf16 [B*T, H*64] rows of stride ld_out.
+ * `flags`: SC_ATTN_CAUSAL (= 1, what a boolean `causal` used to pass) | SC_ATTN_F16: q / k / v / out are IEEE half instead of bf16 (the probabilities
+ * are rounded to half too; scores, running maxima and sums stay fp32) -- the operand format of SC_GEMM_F16. */
+#define SC_ATTN_CAUSAL 0x1
+#define SC_ATTN_F16 0x2
 int sc_attention_fwd(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H,
-                     int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, int causal, void* stream);
+                     int T, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, int flags, void* stream);
 
 /* Train-mode dropouts of the FROZEN encoder: Lightning's model.train() re-enables them while the reference trains the pooling heads
  * (avssl/module/speech_encoder_plus.py:42 F.dropout after the positional conv, :87 dropout_input; [3P fairseq] TransformerSentenceEncoderLayer
@@ -401,7 +409,7 @@ int sc_posconv_finish_packed(const void* x, const int32_t* valid, const int32_t*
                              const float* beta, void* out, int B, int64_t total_rows, int D, int G, int out_f32, float eps, void* stream);
 int sc_attention_fwd_packed(const void* q, const void* k, const void* v, void* out, const int32_t* klens, const int32_t* row_off, int B, int H,
                             int Tmax, int64_t total_rows, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, float drop_p, uint32_t seed,
-                            void* stream);
+                            int flags /* SC_ATTN_F16 or 0 */, void* stream);
 int sc_unpack_rows(const void* src, int64_t src_layer_stride_bytes, const int32_t* row_off, void* out, int64_t out_layer_stride_bytes, int n_layers,
                    int B, int T_out, int row_bytes, int halo, void* stream);
 #ifdef __cplusplus

@@ -15,6 +15,8 @@ LIB_PATH = os.environ.get("SPEECHCLIP_HIP_LIB") or os.path.join(_HERE, "libspeec
 
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 GEMM_OUT_F32 = 0x10
+GEMM_F16 = 0x20          # SC_GEMM_F16: IEEE-half operands (and 16-bit outputs)
+ATTN_CAUSAL, ATTN_F16 = 0x1, 0x2
 
 _lib = None
 
@@ -97,7 +99,7 @@ def _declare(L):
         "sc_conv0_fwd_packed": ([P, L64, L64, P, P, P, P, I, I, I, P, I, I, I, P, P], c_int),
         "sc_posconv_conv_packed": ([P, P, P, P, P, I, I, I, I, I, P], c_int),
         "sc_posconv_finish_packed": ([P, P, P, P, P, P, P, P, I, L64, I, I, I, F, P], c_int),
-        "sc_attention_fwd_packed": ([P, P, P, P, P, P, I, I, I, L64, I, L64, L64, F, F, U32, P], c_int),
+        "sc_attention_fwd_packed": ([P, P, P, P, P, P, I, I, I, L64, I, L64, L64, F, F, U32, I, P], c_int),
         "sc_unpack_rows": ([P, L64, P, P, L64, I, I, I, I, I, P], c_int),
         "sc_image_normalize_u8": ([P, P, I, I, I, P, P, P], c_int),
         "sc_vit_patchify": ([P, P, I, I, I, I, P], c_int),

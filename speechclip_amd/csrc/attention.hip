@@ -67,7 +67,7 @@ __device__ __forceinline__ int swz_k(int row) { return SC_ATTN_KSWZ ? ((row >> 1
 
 __device__ unsigned long long* g_attn_trace = nullptr;   // debug: per-block phase cycles (sc_debug_set_attn_trace)
 
-template <int NW, bool TRACE, bool DROP = false, int QB = 1>   // QB: 32-row query blocks per wave (2: every K / V fragment read feeds two MFMAs, 256 registers, two waves per SIMD)
+template <int NW, bool TRACE, bool DROP = false, int QB = 1, bool F16 = false>   // F16: q / k / v / out (and P) are IEEE half instead of bf16 (SC_ATTN_F16)   // QB: 32-row query blocks per wave (2: every K / V fragment read feeds two MFMAs, 256 registers, two waves per SIMD)
    // DROP: attention-probability dropout (train-mode frozen encoder, sc_attention_fwd_dropout); waves per block: NW x 32 query rows share one K/V ring (4: 128 rows, 8: 256 rows -- half the K/V traffic, 4 waves per SIMD)
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1 ? 4 : 2))) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
 #else
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
-                s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, t), qf[qb][c], s[qb][kb], 0, 0, 0);
+                s[qb][kb] = mfma_32x32x16<F16>(__builtin_bit_cast(bf16x8_t, t), qf[qb][c], s[qb][kb]);
 #endif
         };
         {
@@ -362,9 +362,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
                     const uint32_t hbits = hash_pair(drop_seed, drop_row[qb] * drop_pairs + (key >> 1));
                     const float d0 = (hbits & 0xffffu) >= drop_thresh_ ? p2[0] * drop_keep_scale : 0.f;
                     const float d1 = (hbits >> 16) >= drop_thresh_ ? p2[1] * drop_keep_scale : 0.f;
-                    ppk[qb][kb][r >> 1] = pack2bf(d0, d1);
+                    ppk[qb][kb][r >> 1] = pack2x<F16>(d0, d1);
                 } else
-                ppk[qb][kb][r >> 1] = pack2bf(p2[0], p2[1]);       // P leaves the fp32 registers right here: 16 VGPRs instead of 32 through the PV phase
+                ppk[qb][kb][r >> 1] = pack2x<F16>(p2[0], p2[1]);       // P leaves the fp32 registers right here: 16 VGPRs instead of 32 through the PV phase
 #if SC_ATTN_SCALAR & 2      // row sums as single f32 adds (two chains)
                 asm("v_add_f32 %0, %1, %2" : "=v"(psum2[0]) : "v"(psum2[0]), "v"(p2[0]));
                 asm("v_add_f32 %0, %1, %2" : "=v"(psum2[1]) : "v"(psum2[1]), "v"(p2[1]));
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
 #else
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
-                    o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, both), pf[qb], o[qb][db], 0, 0, 0);
+                    o[qb][db] = mfma_32x32x16<F16>(__builtin_bit_cast(bf16x8_t, both), pf[qb], o[qb][db]);
 #endif
             }
         };
@@ -463,8 +463,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
                 const int ra = (2 * kp) * 4, rb = (2 * kp + 1) * 4;
-                const unsigned ax = pack2bf(o[qb][db][ra + 0] * inv, o[qb][db][ra + 1] * inv), ay = pack2bf(o[qb][db][ra + 2] * inv, o[qb][db][ra + 3] * inv);
-                const unsigned bx = pack2bf(o[qb][db][rb + 0] * inv, o[qb][db][rb + 1] * inv), by = pack2bf(o[qb][db][rb + 2] * inv, o[qb][db][rb + 3] * inv);
+                const unsigned ax = pack2x<F16>(o[qb][db][ra + 0] * inv, o[qb][db][ra + 1] * inv), ay = pack2x<F16>(o[qb][db][ra + 2] * inv, o[qb][db][ra + 3] * inv);
+                const unsigned bx = pack2x<F16>(o[qb][db][rb + 0] * inv, o[qb][db][rb + 1] * inv), by = pack2x<F16>(o[qb][db][rb + 2] * inv, o[qb][db][rb + 3] * inv);
                 const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
                 if (qrow[qb] < T) *(uint4*)(orow + db * 32 + kp * 16 + g * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
@@ -664,8 +664,12 @@ extern "C" void sc_debug_set_attn_trace(void* dev_buf) {     // per-block [8] u6
 }
 
 static int attention_fwd_impl(const void* q, const void* k, const void* v, void* out, const int32_t* klens, int B, int H, int T, int head_dim,
-                              int64_t ld_qkv, int64_t ld_out, float scale, int causal, float drop_p, uint32_t seed, void* stream,
+                              int64_t ld_qkv, int64_t ld_out, float scale, int flags, float drop_p, uint32_t seed, void* stream,
                               const int32_t* row_off = nullptr, int64_t total_rows = 0) {
+    const int causal = flags & SC_ATTN_CAUSAL;
+    const bool f16 = (flags & SC_ATTN_F16) != 0;
+    SC_CHECK_ARG((flags & ~(SC_ATTN_CAUSAL | SC_ATTN_F16)) == 0, "sc_attention_fwd: unknown flag bits 0x%x", flags);
+    SC_CHECK_ARG(!f16 || drop_p == 0.f, "sc_attention_fwd: SC_ATTN_F16 has no dropout form (the frozen pre-LN encoder's rates are 0)");
     SC_CHECK_ARG(head_dim == 64, "sc_attention_fwd: head_dim=%d unsupported (64 only; use sc_cls_attention_fwd for pooling heads)", head_dim);
     SC_CHECK_ARG(ld_qkv % 8 == 0 && ld_out % 8 == 0, "sc_attention_fwd: ld_qkv and ld_out must be multiples of 8 (16-byte rows)");
     SC_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "sc_attention_fwd: misaligned pointers");
@@ -677,7 +681,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
     static const int force_nw = SC_ATTN_ENV_INT("SC_ATTN_NW", 0);
     // SC_ATTN_QB=2 (A/B): 4 waves x 64 query rows instead of 8 waves x 32 for the long-sequence form
     static const int qb_env = SC_ATTN_ENV_INT("SC_ATTN_QB", 1);
-    const bool qb2 = (qb_env == 2 || qb_env == 3) && T > 128 && !force_nw && drop_p == 0.f && !g_attn_trace_host;
+    const bool qb2 = (qb_env == 2 || qb_env == 3) && T > 128 && !force_nw && drop_p == 0.f && !g_attn_trace_host && !f16;
     const int nw = force_nw ? force_nw : (qb2 ? (qb_env == 3 ? 8 : 4) : (T > 128 ? 8 : 4));
     const int lds = ((SC_ATTN_PP && nw == 8) ? 4 : NSTAGE) * STAGE_BYTES;
     const int rows = nw * 32 * (qb2 ? 2 : 1);
@@ -699,6 +703,8 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
                            (const bf16_t*)v, (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq, n_ids, ipb, \
                            seed, th, ks, row_off);                                                                                          \
     } while (0)
+    if (f16) { if (nw == 8) ATTN_LAUNCH(8, false, false, 1, true); else ATTN_LAUNCH(4, false, false, 1, true); }
+    else
 #if SC_PROBES
     if (qb2) { if (nw == 8) ATTN_LAUNCH(8, false, false, 2); else ATTN_LAUNCH(4, false, false, 2); }
     else
@@ -730,9 +736,10 @@ extern "C" int sc_attention_fwd_dropout(const void* q, const void* k, const void
 // rows per utterance <= Tmax); klens[b] <= its row count.  drop_p > 0: the train-mode form.
 extern "C" int sc_attention_fwd_packed(const void* q, const void* k, const void* v, void* out, const int32_t* klens, const int32_t* row_off, int B, int H,
                                        int Tmax, int64_t total_rows, int head_dim, int64_t ld_qkv, int64_t ld_out, float scale, float drop_p, uint32_t seed,
-                                       void* stream) {
+                                       int flags, void* stream) {
+    SC_CHECK_ARG((flags & SC_ATTN_CAUSAL) == 0, "sc_attention_fwd_packed: no causal form");
     SC_CHECK_ARG(row_off != nullptr && klens != nullptr, "sc_attention_fwd_packed: row_off and klens are required");
-    return attention_fwd_impl(q, k, v, out, klens, B, H, Tmax, head_dim, ld_qkv, ld_out, scale, 0, drop_p, seed, stream, row_off, total_rows);
+    return attention_fwd_impl(q, k, v, out, klens, B, H, Tmax, head_dim, ld_qkv, ld_out, scale, flags, drop_p, seed, stream, row_off, total_rows);
 }
 
 extern "C" int sc_cls_attention_fwd(const void* cls_qkv, const void* kv_x, int64_t ld_kv, const int32_t* lens, void* out, int B, int T,

@@ -24,6 +24,33 @@ __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
 __device__ __forceinline__ float lo2f(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi2f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
+// IEEE half as the second 16-bit operand format (round 6): the pre-LN encoder layers of HuBERT-large keep their GEMM / attention operands in f16 (11 significand
+// bits instead of bf16's 8: the reference's own GPU precision for these models is fp16 autocast, config/speechCLIP/model_large/coco/spchclp_p.yaml:122).  The
+// kernels that take both formats are templates on F16; everything format-dependent goes through these four helpers (conversion: v_cvt_pk_f16_f32, RNE).
+typedef _Float16 sc_half2v_t __attribute__((ext_vector_type(2)));
+typedef _Float16 sc_half8v_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {
+    sc_half2v_t v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <bool F16> __device__ __forceinline__ uint32_t pack2x(float a, float b) {
+    if constexpr (F16) return pack2h(a, b); else return pack2bf(a, b);
+}
+template <bool F16> __device__ __forceinline__ float lo2fx(uint32_t u) {
+    if constexpr (F16) return (float)__builtin_bit_cast(sc_half2v_t, u)[0]; else return lo2f(u);
+}
+template <bool F16> __device__ __forceinline__ float hi2fx(uint32_t u) {
+    if constexpr (F16) return (float)__builtin_bit_cast(sc_half2v_t, u)[1]; else return hi2f(u);
+}
+template <bool F16> __device__ __forceinline__ f32x4_t mfma_16x16x32(bf16x8_t a, bf16x8_t b, f32x4_t c) {      // operands as raw 16-bit x 8 registers
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_half8v_t, a), __builtin_bit_cast(sc_half8v_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ f32x16_t mfma_32x32x16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sc_half8v_t, a), __builtin_bit_cast(sc_half8v_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp + a handful of FMAs.
 __device__ __forceinline__ float fast_erf(float x) {
     float ax = fabsf(x);
@@ -128,6 +155,9 @@ __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
 // Eight pairs at once, every Horner step issued for all eight before the next step: identical arithmetic to gelu_poly2 per pair (bit-identical results),
 // but the dependent v_pk_fma_f16 chain of one pair (latency + a hazard nop per step) is hidden behind the seven other pairs.  hipcc schedules the per-pair
 // form one or two chains at a time: the GELU epilogue of a 256 x 256 tile was latency-bound (512 v_pk_fma_f16 + 372 s_nop per wave), round 5.
+// XF32 (the f16-output epilogues): the last product takes the ORIGINAL fp32 x instead of its truncated half copy -- a result that keeps 11 significand bits would
+// otherwise carry the systematic -1/2 ulp of the round-toward-zero conversion (invisible behind a bf16 rounding, not behind an f16 one).
+template <bool XF32 = false>
 __device__ __forceinline__ void gelu_poly2_x8(f32x2_t (&x)[8]) {
     const sc_half2_t one = {(_Float16)1.0f, (_Float16)1.0f}, zero = {(_Float16)0.0f, (_Float16)0.0f};
     sc_half2_t h[8], t[8], g[8];
@@ -161,8 +191,13 @@ __device__ __forceinline__ void gelu_poly2_x8(f32x2_t (&x)[8]) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+        if constexpr (XF32) {
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(x[i][0]) : "v"(x[i][0]), "v"(g[i]));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(x[i][1]) : "v"(x[i][1]), "v"(g[i]));
+        } else {
         asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,1,0]" : "=v"(x[i][0]) : "v"(h[i]), "v"(g[i]));
         asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(x[i][1]) : "v"(h[i]), "v"(g[i]));
+        }
     }
 }
 #endif

@@ -29,6 +29,7 @@ struct GemmParams {
     int64_t M; int N; int K;
     int tiles_m; int tiles_n;
     int act; int out_f32;
+    int f16;                     // operands (and 16-bit outputs / residuals) are IEEE half instead of bf16: gemm_bf16_kernel<.., true> only (SC_GEMM_F16)
     unsigned long long* trace;   // debug: per-block s_memtime stamps (sc_debug_set_gemm_trace)
     int rot;                     // rotate the K loop per block (L2 channel de-correlation)
     int band;                    // N-tiles per column band of the persistent tile order (0/>=tiles_n: M-panel-major over all of N)
@@ -89,7 +90,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_16x16x32<F16>(bfr[j], af[i], acc[i][j]);
         }
     }
 
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
             }
             if (p.act == SC_ACT_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v4[r] = p.out_f32 ? gelu_erf_precise(v4[r]) : gelu_erf(v4[r]);   // f32 consumers get the 1.5e-7 erf path
+                for (int r = 0; r < 4; ++r) v4[r] = (p.out_f32 || F16) ? gelu_erf_precise(v4[r]) : gelu_erf(v4[r]);   // f32 consumers get the 1.5e-7 erf path
             } else if (p.act == SC_ACT_QUICKGELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
@@ -187,11 +188,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
             } else {
                 if (p.residual) {
                     const uint2 rr = *(const uint2*)((const bf16_t*)p.residual + m * p.ldr + n);
-                    v4[0] += lo2f(rr.x); v4[1] += hi2f(rr.x); v4[2] += lo2f(rr.y); v4[3] += hi2f(rr.y);
+                    v4[0] += lo2fx<F16>(rr.x); v4[1] += hi2fx<F16>(rr.x); v4[2] += lo2fx<F16>(rr.y); v4[3] += hi2fx<F16>(rr.y);
                 }
                 uint2 o;
-                o.x = pack2bf(v4[0], v4[1]);
-                o.y = pack2bf(v4[2], v4[3]);
+                o.x = pack2x<F16>(v4[0], v4[1]);
+                o.y = pack2x<F16>(v4[2], v4[3]);
                 *(uint2*)((bf16_t*)Cb + m * p.ldc + n) = o;
             }
         }
@@ -908,16 +909,16 @@ int launch256(const GemmParams& p, hipStream_t s) {
     return launch256_var<0, false, true>(p, grid, s);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool F16 = false>
 int launch(const GemmParams& p, int batch, hipStream_t s) {
     constexpr int lds = 2 * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, batch);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, F16>), grid, dim3(256), lds, s, p);
     SC_CHECK_LAUNCH();
     return 0;
 }
@@ -929,6 +930,12 @@ int gemm_dispatch(GemmParams p, int batch, hipStream_t s) {
     SC_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0 && p.ldc % 4 == 0, "sc_gemm: lda/ldw must be multiples of 8, ldc of 4");
     SC_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && ((uintptr_t)p.C & 15) == 0,
                  "sc_gemm: A/W/C must be 16-byte aligned");
+    if (p.f16) {       // half operands: the shapes gemm8p_pers_kernel does not take (few rows, N % 256 != 0) run on the 128-row kernel
+        p.tiles_m = (int)((p.M + 127) / 128);
+        if (p.N <= 64) { p.tiles_n = (p.N + 63) / 64; return launch<128, 64, true>(p, batch, s); }
+        p.tiles_n = (p.N + 127) / 128;
+        return launch<128, 128, true>(p, batch, s);
+    }
     if (batch == 1 && p.N >= 256 && p.M >= 256 && p.K % 64 == 0) {
         const int64_t t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         static const int min_tiles = SC_TUNE_INT("SC_GEMM_MIN_TILES", 100);
@@ -986,7 +993,8 @@ extern "C" void sc_debug_set_gemm_trace(void* dev_buf) { g_gemm_trace = SC_PROBE
 extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                             const float* bias, const void* residual, int64_t ldr, int64_t M, int N, int K,
                             int flags, void* stream) {
-    if ((flags & SC_GEMM_ACT_MASK) == 0 && lda >= K && !g_gemm_trace && A && W && C && M > 0 && N > 0 && K > 0 && K % 64 == 0) {
+    const int f16 = (flags & SC_GEMM_F16) ? 1 : 0;
+    if (!f16 && (flags & SC_GEMM_ACT_MASK) == 0 && lda >= K && !g_gemm_trace && A && W && C && M > 0 && N > 0 && K > 0 && K % 64 == 0) {
         // plain GEMM (+ bias, + residual; bf16 or fp32 out): the vendor library's kernel when a workspace is registered (vendor_gemm.hip)
         const int rc = sc_vendor_gemm_try(A, lda, W, ldw, C, ldc, bias, residual, ldr, M, N, K, (flags & SC_GEMM_OUT_F32) ? 1 : 0, (hipStream_t)stream);
         if (rc <= 0) { g_last_path = 1; return rc; }
@@ -1004,7 +1012,7 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         Gemm8pParams d{};
         d.A = (const bf16_t*)A; d.lda = lda; d.W = (const bf16_t*)W; d.ldw = ldw; d.C = C; d.ldc = ldc; d.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0;
         d.bias = bias; d.residual = residual; d.ldr = ldr; d.M = M; d.N = N; d.K = K;
-        d.act = flags & SC_GEMM_ACT_MASK;
+        d.act = flags & SC_GEMM_ACT_MASK; d.f16 = f16;
         d.esteps = 4; d.trace = g_gemm_trace;
         // column-band tile order: wide outputs (>= 16 N tiles: 8192^3 1 444 vs 1 323 TF/s unbanded, gemm256_kernel 1 406; HuBERT-large fc1 +2 %) walk 4 N tiles at a time
         d.band = (g_gemm_mode == -1 && N / 256 >= 16) ? 4 : 0;
@@ -1030,7 +1038,7 @@ extern "C" int sc_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     p.C = C; p.ldc = ldc; p.strideC = 0;
     p.bias = bias; p.residual = residual; p.ldr = ldr;
     p.M = M; p.N = N; p.K = K;
-    p.act = flags & SC_GEMM_ACT_MASK; p.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0;
+    p.act = flags & SC_GEMM_ACT_MASK; p.out_f32 = (flags & SC_GEMM_OUT_F32) ? 1 : 0; p.f16 = f16;
     p.trace = g_gemm_trace;
     // the measured best (A/B knobs of the PROBES build: SC_GEMM_NOROT, SC_GEMM_BAND, SC_GEMM_EPI, SC_GEMM_EPI_RES, SC_GEMM_NOKPAIR)
     static const int k_rot = SC_TUNE_SET("SC_GEMM_NOROT") ? 0 : 1;

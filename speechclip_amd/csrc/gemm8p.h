@@ -11,6 +11,7 @@ struct Gemm8pParams {
     const float* bias;                 // may be null
     const void* residual; int64_t ldr;   // same element type as C
     int out_f32;
+    int f16;                           // A, W (and C / residual unless out_f32) are IEEE half instead of bf16 (SC_GEMM_F16; persistent kernel only)
     int64_t M; int N; int K;
     int act;                           // SC_ACT_*
     int nk;                            // K / 64

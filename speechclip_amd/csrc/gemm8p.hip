@@ -277,7 +277,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(Gemm8pParams p) {
 // quadrant Q_p of the next tile -- was built and measured in round 5: 3-7 % SLOWER than even the per-tile kernel on the K = 768 shapes.  The CU's
 // store path moves 24-36 B/clk; 16 KiB of stores per group and interval stretch each of the 8 intervals of that k-step far beyond the 256 cycles
 // of the MFMA cluster they were meant to hide under.  EXPERIMENTS.md, round 5.)
-template <int ACT, bool RES, bool F32>
+// F16 (round 6): A, W and the 16-bit outputs / residuals are IEEE half instead of bf16 (SC_GEMM_F16; the pre-LN encoder layers of HuBERT-large): the f16 MFMA opcode of the
+// same shape, RNE conversion on the way out; everything else -- LDS image, schedule, fp32 accumulators, fp32 outputs -- is format-blind.
+template <int ACT, bool RES, bool F32, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
     // (fp32 outputs keep the plain pairing: their epilogues move 512 KiB per tile and are bound by the CU's load / store path -- side by side they
     //  measured 6 % slower (P-large out-proj 740 -> 697 TF/s), one after the other group 0's stores overlap group 1's residual loads)
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (SC_8P_ABL != 3) acc[a * 4 + i][b * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[b][j][h], af[i][h], acc[a * 4 + i][b * 2 + j], 0, 0, 0);
+                    if (SC_8P_ABL != 3) acc[a * 4 + i][b * 2 + j] = mfma_16x16x32<F16>(bf_[b][j][h], af[i][h], acc[a * 4 + i][b * 2 + j]);
                     else asm volatile("" : "+v"(acc[a * 4 + i][b * 2 + j]) : "v"(bf_[b][j][h]), "v"(af[i][h]));
                 }
         if (SC_8P_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -688,9 +690,9 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                         const f32x4_t v4 = biased(acc[i][j], j);
                         xs[2 * j] = (f32x2_t){v4[0], v4[1]}; xs[2 * j + 1] = (f32x2_t){v4[2], v4[3]};
                     }
-                    gelu_poly2_x8(xs);
+                    gelu_poly2_x8<F16>(xs);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { pk[j].x = pack2bf(xs[2 * j][0], xs[2 * j][1]); pk[j].y = pack2bf(xs[2 * j + 1][0], xs[2 * j + 1][1]); }
+                    for (int j = 0; j < 4; ++j) { pk[j].x = pack2x<F16>(xs[2 * j][0], xs[2 * j][1]); pk[j].y = pack2x<F16>(xs[2 * j + 1][0], xs[2 * j + 1][1]); }
                 } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -699,8 +701,8 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[r] = quick_gelu(v4[r]);
                     }
-                    pk[j].x = pack2bf(v4[0], v4[1]);
-                    pk[j].y = pack2bf(v4[2], v4[3]);
+                    pk[j].x = pack2x<F16>(v4[0], v4[1]);
+                    pk[j].y = pack2x<F16>(v4[2], v4[3]);
                 }
                 }
 #pragma unroll
@@ -732,10 +734,10 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                     for (int jp = 0; jp < 2; ++jp) {
                         uint4 o = ov[i][jp];
                         const uint4 r4 = make_uint4(rv[i & 3][jp][0], rv[i & 3][jp][1], rv[i & 3][jp][2], rv[i & 3][jp][3]);
-                        o.x = pack2bf(lo2f(o.x) + lo2f(r4.x), hi2f(o.x) + hi2f(r4.x));
-                        o.y = pack2bf(lo2f(o.y) + lo2f(r4.y), hi2f(o.y) + hi2f(r4.y));
-                        o.z = pack2bf(lo2f(o.z) + lo2f(r4.z), hi2f(o.z) + hi2f(r4.z));
-                        o.w = pack2bf(lo2f(o.w) + lo2f(r4.w), hi2f(o.w) + hi2f(r4.w));
+                        o.x = pack2x<F16>(lo2fx<F16>(o.x) + lo2fx<F16>(r4.x), hi2fx<F16>(o.x) + hi2fx<F16>(r4.x));
+                        o.y = pack2x<F16>(lo2fx<F16>(o.y) + lo2fx<F16>(r4.y), hi2fx<F16>(o.y) + hi2fx<F16>(r4.y));
+                        o.z = pack2x<F16>(lo2fx<F16>(o.z) + lo2fx<F16>(r4.z), hi2fx<F16>(o.z) + hi2fx<F16>(r4.z));
+                        o.w = pack2x<F16>(lo2fx<F16>(o.w) + lo2fx<F16>(r4.w), hi2fx<F16>(o.w) + hi2fx<F16>(r4.w));
                         ov[i][jp] = o;
                     }
                     if (i + 4 < 8) load_rv(i + 4);
@@ -760,10 +762,10 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
                     uint4 o = oc[i & 1][jp];
                     if (RES) {
                         const uint4 rv = res[i & 3][jp];
-                        o.x = pack2bf(lo2f(o.x) + lo2f(rv.x), hi2f(o.x) + hi2f(rv.x));
-                        o.y = pack2bf(lo2f(o.y) + lo2f(rv.y), hi2f(o.y) + hi2f(rv.y));
-                        o.z = pack2bf(lo2f(o.z) + lo2f(rv.z), hi2f(o.z) + hi2f(rv.z));
-                        o.w = pack2bf(lo2f(o.w) + lo2f(rv.w), hi2f(o.w) + hi2f(rv.w));
+                        o.x = pack2x<F16>(lo2fx<F16>(o.x) + lo2fx<F16>(rv.x), hi2fx<F16>(o.x) + hi2fx<F16>(rv.x));
+                        o.y = pack2x<F16>(lo2fx<F16>(o.y) + lo2fx<F16>(rv.y), hi2fx<F16>(o.y) + hi2fx<F16>(rv.y));
+                        o.z = pack2x<F16>(lo2fx<F16>(o.z) + lo2fx<F16>(rv.z), hi2fx<F16>(o.z) + hi2fx<F16>(rv.z));
+                        o.w = pack2x<F16>(lo2fx<F16>(o.w) + lo2fx<F16>(rv.w), hi2fx<F16>(o.w) + hi2fx<F16>(rv.w));
                     }
                     if (i * 16 >= skip) *(uint4*)(cptr + i * cstep + jp * 32) = o;
                 }
@@ -784,15 +786,15 @@ __global__ __launch_bounds__(512) void gemm8p_pers_kernel(Gemm8pParams p) {
     }
 }
 
-template <int ACT, bool RES, bool F32>
+template <int ACT, bool RES, bool F32, bool F16 = false>
 int launch_pers(const Gemm8pParams& p, int grid, hipStream_t s) {
     constexpr int lds = 2 * BUF + 32768;   // 128 KiB of operands + the bias vector
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm8p_pers_kernel<ACT, RES, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm8p_pers_kernel<ACT, RES, F32, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm8p_pers_kernel<ACT, RES, F32>), dim3(grid), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((gemm8p_pers_kernel<ACT, RES, F32, F16>), dim3(grid), dim3(512), lds, s, p);
     SC_CHECK_LAUNCH();
     return 0;
 }
@@ -846,20 +848,18 @@ int sc_gemm8p_try(const Gemm8pParams& pin, hipStream_t s) {
         }
         if (dyn) { const unsigned long long seq = sched_seq.fetch_add(1); p.sched = (int)(seq % SCHED_RING); p.sched_gen = (unsigned)(seq / SCHED_RING + 1); }
         else p.sched = -1;
-        if (p.out_f32) {
-            switch (p.act) {
-                case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, true>(p, pg, s) : launch_pers<SC_ACT_GELU, false, true>(p, pg, s);
-                case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true, true>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false, true>(p, pg, s);
-                default: return res ? launch_pers<SC_ACT_NONE, true, true>(p, pg, s) : launch_pers<SC_ACT_NONE, false, true>(p, pg, s);
-            }
+        // (ACT x RES x F32 x F16 as template arguments: one switch over the packed key)
+#define SC_8P_CASE(A_, R_, F_, H_) case ((A_) | ((R_) << 2) | ((F_) << 3) | ((H_) << 4)): return launch_pers<A_, R_ != 0, F_ != 0, H_ != 0>(p, pg, s);
+#define SC_8P_CASES(R_, F_, H_) SC_8P_CASE(SC_ACT_NONE, R_, F_, H_) SC_8P_CASE(SC_ACT_GELU, R_, F_, H_) SC_8P_CASE(SC_ACT_QUICKGELU, R_, F_, H_)
+        switch ((p.act & 3) | ((res ? 1 : 0) << 2) | ((p.out_f32 ? 1 : 0) << 3) | ((p.f16 ? 1 : 0) << 4)) {
+            SC_8P_CASES(0, 0, 0) SC_8P_CASES(1, 0, 0) SC_8P_CASES(0, 1, 0) SC_8P_CASES(1, 1, 0)
+            SC_8P_CASES(0, 0, 1) SC_8P_CASES(1, 0, 1) SC_8P_CASES(0, 1, 1) SC_8P_CASES(1, 1, 1)
+            default: return 1;
         }
-        switch (p.act) {
-            case SC_ACT_GELU: return res ? launch_pers<SC_ACT_GELU, true, false>(p, pg, s) : launch_pers<SC_ACT_GELU, false, false>(p, pg, s);
-            case SC_ACT_QUICKGELU: return res ? launch_pers<SC_ACT_QUICKGELU, true, false>(p, pg, s) : launch_pers<SC_ACT_QUICKGELU, false, false>(p, pg, s);
-            default: return res ? launch_pers<SC_ACT_NONE, true, false>(p, pg, s) : launch_pers<SC_ACT_NONE, false, false>(p, pg, s);
-        }
+#undef SC_8P_CASES
+#undef SC_8P_CASE
     }
-    if (p.out_f32) return 1;
+    if (p.out_f32 || p.f16) return 1;
     switch (p.act) {
         case SC_ACT_GELU: return res ? launch_one<SC_ACT_GELU, true>(p, grid, s) : launch_one<SC_ACT_GELU, false>(p, grid, s);
         case SC_ACT_QUICKGELU: return res ? launch_one<SC_ACT_QUICKGELU, true>(p, grid, s) : launch_one<SC_ACT_QUICKGELU, false>(p, grid, s);

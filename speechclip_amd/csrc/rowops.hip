@@ -46,7 +46,7 @@ __device__ __forceinline__ void row_stats(const float (&v)[MAXC][4], int D, int 
 // out = [gelu]( (x - mean) * rstd * gamma + beta ).  Each wave owns RPW rows and issues all their loads up front
 // (more bytes in flight per CU: a single 1.5 KB row per wave leaves the HBM pipe half empty).
 constexpr int RPW = 2;
-template <bool IN_F32, bool OUT_F32>
+template <bool IN_F32, bool OUT_F32, bool OUT_F16 = false>     // OUT_F16: the 16-bit output is IEEE half (SC_LN_OUT_F16)
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, int64_t ld_in, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ out, int64_t ld_out,
                                                         int64_t rows, int D, float eps, int gelu) {
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
                 if (OUT_F32) {
                     *(f32x4_t*)((float*)out + row * ld_out + e) = (f32x4_t){o[0], o[1], o[2], o[3]};
                 } else {
-                    uint2 p; p.x = pack2bf(o[0], o[1]); p.y = pack2bf(o[2], o[3]);
+                    uint2 p; p.x = pack2x<OUT_F16>(o[0], o[1]); p.y = pack2x<OUT_F16>(o[2], o[3]);
                     *(uint2*)((bf16_t*)out + row * ld_out + e) = p;
                 }
             }
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const bf16_t* __restr
 // Fast path for the pre-LN models' residual streams (HuBERT-large, ViT-L/14: fp32 [rows, 1024] -> bf16, affine; 99 launches per P-large step): a lane owns 8
 // consecutive columns of each 512-column half (two 16-byte loads per half, ONE 16-byte store per half -- the generic kernel's 4-column ownership stores 8
 // bytes per lane), a wave owns two consecutive rows and issues all eight loads up front.
+template <bool OUT_F16>
 __global__ __launch_bounds__(256) void layernorm1024f_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              bf16_t* __restrict__ out, int64_t rows, float eps) {
     const int lane = threadIdx.x & 63;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void layernorm1024f_kernel(const float* __rest
             if (r && !two) continue;
             const f32x4_t o0 = (v[r][h][0] - mean[r]) * rstd[r] * g0 + b0, o1 = (v[r][h][1] - mean[r]) * rstd[r] * g1 + b1;
             uint4 u;
-            u.x = pack2bf(o0[0], o0[1]); u.y = pack2bf(o0[2], o0[3]); u.z = pack2bf(o1[0], o1[1]); u.w = pack2bf(o1[2], o1[3]);
+            u.x = pack2x<OUT_F16>(o0[0], o0[1]); u.y = pack2x<OUT_F16>(o0[2], o0[3]); u.z = pack2x<OUT_F16>(o1[0], o1[1]); u.w = pack2x<OUT_F16>(o1[2], o1[3]);
             *(uint4*)(out + (row0 + r) * 1024 + col) = u;
         }
     }
@@ -431,6 +432,8 @@ extern "C" int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, co
     dim3 grid((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int gelu = (flags & SC_LN_GELU) ? 1 : 0;
+    const bool out16h = flags & SC_LN_OUT_F16;
+    SC_CHECK_ARG(!out16h || ((flags & SC_LN_IN_F32) && !(flags & SC_LN_OUT_F32)), "sc_layernorm: SC_LN_OUT_F16 goes with SC_LN_IN_F32 and a 16-bit output (the pre-LN residual stream)");
     if (D == 768 && flags == 0 && gamma && ld_in == 768 && ld_out == 768 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
         hipLaunchKernelGGL((layernorm768_kernel<false>), dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, rows, eps,
                            (const bf16_t*)nullptr, 0u, 0u, 1.0f);
@@ -446,16 +449,18 @@ extern "C" int sc_layernorm(const void* x, int64_t ld_in, const float* gamma, co
     }
     const bool in32 = flags & SC_LN_IN_F32, out32 = flags & SC_LN_OUT_F32;
     if (D == 1024 && in32 && !out32 && !gelu && gamma && ld_in == 1024 && ld_out == 1024 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
-        hipLaunchKernelGGL(layernorm1024f_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const float*)x, gamma, beta, (bf16_t*)out, rows, eps);
+        if (out16h) hipLaunchKernelGGL(layernorm1024f_kernel<true>, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const float*)x, gamma, beta, (bf16_t*)out, rows, eps);
+        else hipLaunchKernelGGL(layernorm1024f_kernel<false>, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const float*)x, gamma, beta, (bf16_t*)out, rows, eps);
         SC_CHECK_LAUNCH();
         return 0;
     }
-    if (D == 768 && in32 && !out32 && !gelu && gamma && ld_in == 768 && ld_out == 768 && (((uintptr_t)x & 15) | ((uintptr_t)out & 7)) == 0) {
+    if (D == 768 && in32 && !out32 && !out16h && !gelu && gamma && ld_in == 768 && ld_out == 768 && (((uintptr_t)x & 15) | ((uintptr_t)out & 7)) == 0) {
         hipLaunchKernelGGL(layernorm768f_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const float*)x, gamma, beta, (bf16_t*)out, rows, eps);
         SC_CHECK_LAUNCH();
         return 0;
     }
     if (in32 && out32) hipLaunchKernelGGL((layernorm_kernel<true, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
+    else if (in32 && out16h) hipLaunchKernelGGL((layernorm_kernel<true, false, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
     else if (in32) hipLaunchKernelGGL((layernorm_kernel<true, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
     else if (out32) hipLaunchKernelGGL((layernorm_kernel<false, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);
     else hipLaunchKernelGGL((layernorm_kernel<false, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, ld_out, rows, D, eps, gelu);

@@ -35,6 +35,12 @@ CONV_LAYERS = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2
 
 # SC_CONV0_LN_FUSED=0 (A/B): conv layer 0 of a "layer_norm" extractor as conv + bias, then a separate LayerNorm + GELU pass (rounds 1-5)
 _CONV0_LN_FUSED = os.environ.get("SC_CONV0_LN_FUSED", "1") != "0"
+# Operand format of the frozen PRE-LN transformer layers (HuBERT-large): IEEE half (default) -- LayerNorm outputs, q|k|v, attention probabilities and outputs, GELU
+# outputs and the layer weights carry 11 significand bits instead of bf16's 8; the residual stream is fp32 either way.  This is the precision the reference runs
+# these models at on a GPU (fp16 autocast: config/speechCLIP/model_large/coco/spchclp_p.yaml:122); 24 layers of bf16 operand rounding were what held the
+# P-large parity floor at 0.985.  SC_PRELN_F16=0 (A/B): bf16 operands, rounds 1-5.  Post-LN models (HuBERT-base) keep bf16: their residual
+# stream itself is 16-bit, and bf16's range is what that needs.
+_PRELN_F16 = os.environ.get("SC_PRELN_F16", "1") != "0"
 
 
 @dataclass
@@ -211,14 +217,18 @@ class HubertModel(nn.Module):
         P["pos_b"] = w32(pc.bias)
         P["enc_ln"] = (w32(self.encoder.layer_norm.weight), w32(self.encoder.layer_norm.bias))
         P["layers"] = []
+        P["layer_dtype"] = lw = torch.float16 if (cfg.layer_norm_first and _PRELN_F16) else bf      # operand format of the transformer layers (see _PRELN_F16)
+
+        def wl(t):
+            return t.detach().to(dev, lw).contiguous()
         for lyr in self.encoder.layers:
             a = lyr.self_attn
             P["layers"].append(dict(
-                wqkv=w16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)),
+                wqkv=wl(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)),
                 bqkv=w32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)),
-                wo=w16(a.out_proj.weight), bo=w32(a.out_proj.bias),
+                wo=wl(a.out_proj.weight), bo=w32(a.out_proj.bias),
                 ln1=(w32(lyr.self_attn_layer_norm.weight), w32(lyr.self_attn_layer_norm.bias)),
-                w1=w16(lyr.fc1.weight), b1=w32(lyr.fc1.bias), w2=w16(lyr.fc2.weight), b2=w32(lyr.fc2.bias),
+                w1=wl(lyr.fc1.weight), b1=w32(lyr.fc1.bias), w2=wl(lyr.fc2.weight), b2=w32(lyr.fc2.bias),
                 ln2=(w32(lyr.final_layer_norm.weight), w32(lyr.final_layer_norm.bias))))
         return P
 
@@ -403,11 +413,12 @@ class HubertModel(nn.Module):
             ops.dropout_bf16(hidden[0], rates["hidden"], next_seed(), out=hidden[0])            # F.dropout before the layers (:42); layer_results[0] is the dropped state
         # ---- transformer layers
         H = cfg.encoder_attention_heads
-        qkv = buf("qkv", (M, 3 * d), bf, dev)
-        att = buf("att", (M, d), bf, dev)
-        ffn = buf("ffn", (M, cfg.encoder_ffn_embed_dim), bf, dev)
-        tmp = buf("tmp", (M, d), bf, dev)
-        tmp2 = buf("tmp2", (M, d), bf, dev)
+        lw = P["layer_dtype"]                      # bf16, or IEEE half for pre-LN models (_PRELN_F16): every 16-bit tensor inside a layer
+        qkv = buf("qkv", (M, 3 * d), lw, dev)
+        att = buf("att", (M, d), lw, dev)
+        ffn = buf("ffn", (M, cfg.encoder_ffn_embed_dim), lw, dev)
+        tmp = buf("tmp", (M, d), lw, dev)
+        tmp2 = buf("tmp2", (M, d), lw, dev)
 
         def attn(qkv_, att_):
             if pack is not None:

@@ -8,7 +8,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, GEMM_OUT_F32, check, lib, ptr, stream
+from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, ATTN_CAUSAL, ATTN_F16, GEMM_F16, GEMM_OUT_F32, check, lib, ptr, stream
 
 bf16 = torch.bfloat16
 
@@ -101,18 +101,21 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + residual.  `M/K/lda` override the logical A view
     (overlapping rows: conv-as-GEMM)."""
     _need_cuda(a, w)
-    assert a.dtype == bf16 and w.dtype == bf16 and w.dim() == 2 and w.is_contiguous()
+    # operand format: bf16, or IEEE half for both operands (SC_GEMM_F16: the frozen pre-LN encoder layers; 16-bit outputs / residuals are half too)
+    f16 = a.dtype == torch.float16
+    op16 = torch.float16 if f16 else bf16
+    assert a.dtype == op16 and w.dtype == op16 and w.dim() == 2 and w.is_contiguous(), (a.dtype, w.dtype)
     N, Kw = w.shape
     if M is None:
         assert a.dim() == 2 and a.stride(1) == 1
         M, K, lda = a.shape[0], a.shape[1], a.stride(0)
     assert K == Kw, (K, Kw)
     if out is None:
-        out = torch.empty(M, N, device=a.device, dtype=torch.float32 if out_f32 else bf16)
-    assert out.stride(-1) == 1 and out.dtype == (torch.float32 if out_f32 else bf16)
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32 if out_f32 else op16)
+    assert out.stride(-1) == 1 and out.dtype == (torch.float32 if out_f32 else op16)
     if residual is not None:
         assert residual.dtype == out.dtype and residual.stride(-1) == 1
-    flags = act | (GEMM_OUT_F32 if out_f32 else 0)
+    flags = act | (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_F16 if f16 else 0)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -143,7 +146,7 @@ def gemm_batched(a, lda, stride_a, w, stride_w, w_mod, out, ldc, stride_c, bias,
     return out
 
 
-LN_IN_F32, LN_OUT_F32, LN_GELU = 1, 2, 4
+LN_IN_F32, LN_OUT_F32, LN_GELU, LN_OUT_F16 = 1, 2, 4, 8
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None, out_f32=False, gelu=False, rows=None, D=None, ld_in=None):
@@ -160,7 +163,10 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, out_f32=False, gelu=False, row
     if out is None:
         out = torch.empty(shape, device=x.device, dtype=torch.float32 if out_f32 else bf16)
     flags = (LN_IN_F32 if x.dtype == torch.float32 else 0) | (LN_OUT_F32 if out.dtype == torch.float32 else 0) | (LN_GELU if gelu else 0)
-    assert x.dtype in (bf16, torch.float32)
+    if out.dtype == torch.float16:           # IEEE-half operand format of the pre-LN encoder layers (fp32 residual stream in)
+        assert x.dtype == torch.float32
+        flags |= LN_OUT_F16
+    assert x.dtype in (bf16, torch.float32) and out.dtype in (bf16, torch.float16, torch.float32)
     with _HbmSpan("layernorm", rows * D * (x.element_size() + out.element_size())):
         check(lib().sc_layernorm(ptr(x), ld_in, ptr(gamma), ptr(beta), ptr(out), D, rows, D, eps, flags, stream()), "sc_layernorm")
     return out
@@ -226,15 +232,17 @@ def wave_layernorm(wav, lens_i32, eps=1e-5):
 
 
 def attention(qkv, B, T, H, klens_i32=None, out=None, scale=None, causal=False):
-    """qkv: bf16 [B*T, 3*H*64] packed (q|k|v); returns bf16 [B*T, H*64]."""
+    """qkv: bf16 (or IEEE half: SC_ATTN_F16) [B*T, 3*H*64] packed (q|k|v); returns the same format [B*T, H*64]."""
     _need_cuda(qkv)
     D = H * 64
-    assert qkv.dtype == bf16 and qkv.shape == (B * T, 3 * D) and qkv.is_contiguous()
+    assert qkv.dtype in (bf16, torch.float16) and qkv.shape == (B * T, 3 * D) and qkv.is_contiguous()
     if out is None:
-        out = torch.empty(B * T, D, device=qkv.device, dtype=bf16)
+        out = torch.empty(B * T, D, device=qkv.device, dtype=qkv.dtype)
+    assert out.dtype == qkv.dtype
     esz = 2
     check(lib().sc_attention_fwd(qkv.data_ptr(), qkv.data_ptr() + D * esz, qkv.data_ptr() + 2 * D * esz, ptr(out), ptr(klens_i32),
-                                 B, H, T, 64, 3 * D, D, 0.125 if scale is None else scale, int(causal), stream()), "sc_attention_fwd")
+                                 B, H, T, 64, 3 * D, D, 0.125 if scale is None else scale, (ATTN_CAUSAL if causal else 0) | (ATTN_F16 if qkv.dtype == torch.float16 else 0),
+                                 stream()), "sc_attention_fwd")
     return out
 
 
@@ -438,11 +446,13 @@ def attention_packed(qkv, B, rows_max, H, klens_i32, row_off_i32, out=None, drop
     _need_cuda(qkv, klens_i32, row_off_i32)
     D = H * 64
     total = qkv.shape[0]
-    assert qkv.dtype == bf16 and qkv.shape == (total, 3 * D) and qkv.is_contiguous()
+    assert qkv.dtype in (bf16, torch.float16) and qkv.shape == (total, 3 * D) and qkv.is_contiguous()
     if out is None:
-        out = torch.empty(total, D, device=qkv.device, dtype=bf16)
+        out = torch.empty(total, D, device=qkv.device, dtype=qkv.dtype)
+    assert out.dtype == qkv.dtype
     check(lib().sc_attention_fwd_packed(qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2, ptr(out), ptr(klens_i32), ptr(row_off_i32),
-                                        B, H, rows_max, total, 64, 3 * D, D, 0.125, float(drop_p), int(seed) & 0xffffffff, stream()), "sc_attention_fwd_packed")
+                                        B, H, rows_max, total, 64, 3 * D, D, 0.125, float(drop_p), int(seed) & 0xffffffff,
+                                        ATTN_F16 if qkv.dtype == torch.float16 else 0, stream()), "sc_attention_fwd_packed")
     return out
 
 

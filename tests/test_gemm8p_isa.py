@@ -26,7 +26,7 @@ def kernels(tmp_path_factory):
     for part in re.split(r"\n(?=_ZN12_GLOBAL__N_118gemm8p_pers_kernel\S+:)", txt)[1:]:
         name = part.split(":", 1)[0]
         ks[name] = part.split(".end_amdhsa_kernel")[0]
-    assert len(ks) == 12, sorted(ks)                       # ACT x RES x F32
+    assert len(ks) == 24, sorted(ks)                       # ACT x RES x F32 x F16
     return ks
 
 
@@ -72,9 +72,11 @@ def test_residual_epilogues_wait_by_count_only(kernels):
     """Behind the last MFMA of a residual variant: the explicit residual loads, then waits vmcnt(6 6 6 6 6 4 2 0) (bf16: 4 row blocks x 2 loads in flight) or
     vmcnt(4 x 7, 0) (fp32: 2 row blocks x 4 loads), then the stores -- and no other vmcnt wait in between."""
     for name, body in kernels.items():
-        if "ELb1ELb" not in name:                           # RES == false
+        m = re.search(r"ILi(\d)ELb([01])ELb([01])ELb([01])EEEv12Gemm8pParams$", name)      # <ACT, RES, F32, F16>
+        assert m, name
+        if m.group(2) != "1":                               # RES == false
             continue
-        f32 = name.endswith("ELb1ELb1EEEv12Gemm8pParams")
+        f32 = m.group(3) == "1"
         tail = body[body.rfind("v_mfma"):]
         first_store = tail.find("global_store_dwordx4")
         waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", tail[:first_store])]

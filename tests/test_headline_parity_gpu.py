@@ -168,7 +168,9 @@ def test_p_large_b64_ragged_vs_oracle():
         o_par = l2_normalize(ref.parallel_branch(feat, o_flen))
     ref_loss = ref.compute_loss({"parallel_audio_feat": o_par, "image_feat": o_img, "id": sub["id"]})["loss"].item()
     _check_subset("P-large B=64 ragged", idx, flen, last, lf, "parallel_audio_feat", o_par, o_flen, hidden[-1], o_img, sub["id"].cuda(), inv_t,
-                  lambda a, i, ids: ops.infonce(a, i, ids, inv_temperature=inv_t)[0].item(), ref_loss, min_ccos=0.985)
+                  lambda a, i, ids: ops.infonce(a, i, ids, inv_temperature=inv_t)[0].item(), ref_loss, min_ccos=0.99)
+    # (round 6: the suite-wide floor.  Rounds 4-5 asserted 0.985 here -- 24 pre-LN layers of bf16 GEMM / attention operands measured 0.9899-0.9901 -- until the
+    #  layers moved to IEEE-half operands, the reference's own GPU precision for this model (spchclp_p.yaml:122): 0.9960 on this batch; SC_PRELN_F16=0 restores bf16.)
 
 
 def test_c_base_b256_vs_oracle():
