@@ -21,7 +21,8 @@ from torch import nn
 from .. import ops, parallel
 
 _OVERLAP_IMAGE_TOWER = os.environ.get("SC_OVERLAP_VIT", "1") != "0"
-_VIT_START = os.environ.get("SC_VIT_START", "")       # "" = the image tower starts with the step; "extractor" / "layer<i>": behind that stage of the speech tower (A/B)
+_VIT_START = os.environ.get("SC_VIT_START", "")       # "" = the image tower starts with the step; "extractor" / "layer<i>": behind that stage of the speech tower (A/B);
+                                                       # "head": behind the whole speech tower, beside the pooling / keyword head (the cascaded head is ~2.5 ms of small kernels)
 _SIDE_STREAMS = {}
 from ..base import OrderedNamespace
 from ..module import ClipModel, FairseqSpeechEncoder_Hubert, MLPLayers, S3prlSpeechEncoderPlus, losses, mutualRetrieval
@@ -560,6 +561,7 @@ class KWClip_GeneralTransformer(KWClipBase):
     def forward(self, batch) -> tuple:
         wav, wav_len, image, ids = batch["wav"], batch["wav_len"], batch["image"], batch["id"]
         self.clip.update_device(self.device)
+        branches = None
         if _OVERLAP_IMAGE_TOWER and image.is_cuda:
             # The frozen image tower does not depend on the speech tower: it runs on a side HIP stream and fills the CUs the speech tower's
             # kernels leave idle (GEMM tails, HBM-bound conv0 / LayerNorm phases): 45.9 -> 44.7 ms per B = 256 step.  SC_OVERLAP_VIT=0: serial.
@@ -581,7 +583,14 @@ class KWClip_GeneralTransformer(KWClipBase):
                         w1.record()
                         ops.PROFILE_SIDE.append((w0, w1))
                 return feat
-            if not _VIT_START:
+            # Where the image tower enters the launch sequence.  Parallel-only models: with the step (it hides in the speech tower's HBM-bound phases and GEMM tails;
+            # every later start measured worse, EXPERIMENTS.md R5-3b).  Models with a CASCADED branch: behind the speech tower, beside the keyword head + VQ + CLIP text
+            # tower -- ~2.5 ms of small, serially dependent kernels that leave most CUs idle: 44.50 -> 44.00 ms per C-base step in 3 of 3 interleaved passes
+            # (profiles/r06_vit_beside_cascaded_head_ab.txt; the same placement costs the parallel model +1.6 ms).  SC_VIT_START overrides ("step" = with the step).
+            vit_start = _VIT_START or ("head" if self.cascaded_branch is not None else "")
+            if vit_start == "step":
+                vit_start = ""
+            if not vit_start:
                 image_feat = launch_image()
                 audio_feat, audio_len = self.forward_audio(wav, wav_len)
             else:                                  # A/B: the image tower enters the launch sequence behind a stage of the speech tower (module/hubert.py STAGE_HOOK)
@@ -589,7 +598,7 @@ class KWClip_GeneralTransformer(KWClipBase):
                 box = []
 
                 def hook(name):
-                    if name == _VIT_START and not box:
+                    if name == vit_start and not box:
                         box.append(launch_image())
                 _hubert.STAGE_HOOK = hook
                 try:
@@ -597,6 +606,10 @@ class KWClip_GeneralTransformer(KWClipBase):
                 finally:
                     _hubert.STAGE_HOOK = None
                 image_feat = box[0] if box else launch_image()
+            if vit_start == "head":               # the head's kernels are enqueued first; the main stream joins the side stream in front of the first use of image_feat
+                ops.PROFILE_TAG = "head"
+                branches = self._branches(audio_feat, audio_len)
+                ops.PROFILE_TAG = "speech"
             cur.wait_stream(side)
             image_feat.record_stream(cur)
         else:
@@ -606,9 +619,11 @@ class KWClip_GeneralTransformer(KWClipBase):
             ops.PROFILE_TAG = "speech"
         if self.img_enc_proj_net is not None:
             image_feat = self.img_enc_proj_net(image_feat)
-        ops.PROFILE_TAG = "head"
-        c_feat, p_feat, vq, kw = self._branches(audio_feat, audio_len)
-        ops.PROFILE_TAG = "speech"
+        if branches is None:
+            ops.PROFILE_TAG = "head"
+            branches = self._branches(audio_feat, audio_len)
+            ops.PROFILE_TAG = "speech"
+        c_feat, p_feat, vq, kw = branches
         image_feat = ops.l2norm(image_feat)
         loss_feats = {"id": ids, "image_feat": image_feat}
         log_metrics = {}
