@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
     const int id = (blockIdx.x >> 3) * (8 * ipb) + it * 8 + (blockIdx.x & 7);
     if (id >= n_ids) break;
     const int unit = ((id >> 3) / nq) * 8 + (id & 7);
-    const int qblk = (id >> 3) % nq;
+    int qblk = (id >> 3) % nq;
     if (unit >= H * B) continue;
     const int b = unit / H, h = unit - b * H;
     int lane_i = lane;
@@ -103,13 +103,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
     // (wave-uniform scalar loads).  row_off == nullptr: the uniform layout, T rows per utterance.
     const int T = row_off ? row_off[b + 1] - row_off[b] : T_uniform;
     const int64_t row_base = row_off ? (int64_t)row_off[b] : (int64_t)b * T;
+    // Query-row split of the 8-wave form (host: attention_fwd_impl).  A last block with <= 128 valid rows computes 256 -- every wave runs the full key loop on
+    // clamped rows: T = 257 (ViT-L/14) and T = 319 (the training crop) paid two blocks for 1.004 / 1.25 blocks of rows, packed utterances half a block each on
+    // average.  q_mode 1 (the NW == 8 launch) leaves such a block to a second launch of 4-wave blocks, q_mode 2 (NW == 4: ROWS == 128), one id per (b, h).
+    const int q_mode = causal >> 1;
+    if (q_mode == 2) {
+        const int rem = T & 255;
+        if (rem == 0 || rem > 128) continue;
+        qblk = (T >> 8) * 2;
+    }
     if (qblk * ROWS >= T) continue;
+    if (q_mode == 1 && T - qblk * ROWS <= 128) continue;
     const int hoff = h * 64;
 
     int klen = klens ? klens[b] : T;
     klen = klen < 0 ? 0 : (klen > T ? T : klen);
     int nkv = (klen + KV - 1) / KV;
-    if (causal) {  // keys beyond the block's last query are never needed
+    if (causal & 1) {  // keys beyond the block's last query are never needed
         const int last_q = min(T, qblk * ROWS + ROWS);
         nkv = min(nkv, (last_q + KV - 1) / KV);
     }
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
 #endif
         if (SC_ATTN_VEARLY && !PP) issue_v(I0{});
         const int kv0 = j * KV;
-        const bool partial = (kv0 + KV > klen) || causal;
+        const bool partial = (kv0 + KV > klen) || (causal & 1);
         unsigned ppk[QB][2][8];
 #if defined(SC_ATTN_ABL) && SC_ATTN_ABL == 2
 #pragma unroll
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 1
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                     float t = s[qb][kb][r] * scale_log2e;
-                    t = (key < klen && (!causal || key <= qrow[qb])) ? t : -INFINITY;
+                    t = (key < klen && (!(causal & 1) || key <= qrow[qb])) ? t : -INFINITY;
                     s[qb][kb][r] = t;
                     mx = fmaxf(mx, t);
                 }
@@ -683,38 +693,55 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
     static const int qb_env = SC_ATTN_ENV_INT("SC_ATTN_QB", 1);
     const bool qb2 = (qb_env == 2 || qb_env == 3) && T > 128 && !force_nw && drop_p == 0.f && !g_attn_trace_host && !f16;
     const int nw = force_nw ? force_nw : (qb2 ? (qb_env == 3 ? 8 : 4) : (T > 128 ? 8 : 4));
-    const int lds = ((SC_ATTN_PP && nw == 8) ? 4 : NSTAGE) * STAGE_BYTES;
-    const int rows = nw * 32 * (qb2 ? 2 : 1);
-    const int nq = (T + rows - 1) / rows;
     const int64_t units8 = ((int64_t)H * B + 7) / 8;
-    SC_CHECK_ARG(units8 * 8 * nq < 0x7fffffff, "sc_attention_fwd: grid too large");
-    const int n_ids = (int)(units8 * 8 * nq);
     static const int ipb_env = SC_ATTN_ENV_INT("SC_ATTN_IPB", 0);
     int ipb = ipb_env > 0 ? ipb_env : 1;
     ipb = ipb < 1 ? 1 : (ipb > 16 ? 16 : ipb);
-    const int groups8 = (n_ids / 8 + ipb - 1) / ipb;           // n_ids is a multiple of 8
-    dim3 grid((unsigned)(groups8 * 8));
     const uint32_t th = drop_thresh16(drop_p);         // 16 random bits per probability: see hash_pair (common.h)
     const float ks = 1.0f / (1.0f - drop_p);
+    // Query-row split (see q_mode in the kernel): the 8-wave launch keeps the blocks with more than 128 valid rows, a second launch of 4-wave blocks takes every
+    // last block with <= 128.  Uniform T only, when T % 256 is in [1, 128] (T = 499 / 500, the headline, is one launch as before): training step (T = 319) 33.41 -> 32.86 ms in
+    // 3 of 3 interleaved passes, P-large (ViT-L/14, T = 257) +-0.1 ms.  PACKED batches keep one launch: the per-utterance form of the same split (kernel side kept, q_mode 1 / 2
+    // with row_off) measured +0.25 ms on the ragged P-base step (27.55 vs 27.29 ms) -- the 4-wave tail blocks re-read K / V that the 8-wave block shares.
+    // profiles/r06_attention_query_split_ab.txt.  SC_ATTN_SPLIT=0: one launch (A/B).
+    static const int split_env = getenv("SC_ATTN_SPLIT") ? atoi(getenv("SC_ATTN_SPLIT")) : 1;
+    const bool split = split_env && nw == 8 && !causal && !qb2 && !g_attn_trace_host && !force_nw && !row_off && (T & 255) >= 1 && (T & 255) <= 128;
+    int rc_launch = 0;
+    auto launch = [&](int nw_, int nq, int q_mode) {
+        if (nq <= 0) return;
+        const int lds = ((SC_ATTN_PP && nw_ == 8) ? 4 : NSTAGE) * STAGE_BYTES;
+        if (units8 * 8 * nq >= 0x7fffffff) { sc_set_error("sc_attention_fwd: grid too large"); rc_launch = -1; return; }
+        const int n_ids = (int)(units8 * 8 * nq);
+        const int groups8 = (n_ids / 8 + ipb - 1) / ipb;           // n_ids is a multiple of 8
+        dim3 grid((unsigned)(groups8 * 8));
+        const int cflag = causal | (q_mode << 1);
 #define ATTN_LAUNCH(NW_, TR_, DR_, ...)                                                                                                     \
     do {                                                                                                                                    \
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NW_, TR_, DR_, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);            \
         hipLaunchKernelGGL((attn_fwd_kernel<NW_, TR_, DR_, ##__VA_ARGS__>), grid, dim3(NW_ * 64), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, \
-                           (const bf16_t*)v, (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, causal, B, H, nq, n_ids, ipb, \
+                           (const bf16_t*)v, (bf16_t*)out, klens, T, ld_qkv, ld_out, scale * 1.44269504088896341f, cflag, B, H, nq, n_ids, ipb, \
                            seed, th, ks, row_off);                                                                                          \
     } while (0)
-    if (f16) { if (nw == 8) ATTN_LAUNCH(8, false, false, 1, true); else ATTN_LAUNCH(4, false, false, 1, true); }
-    else
+        if (f16) { if (nw_ == 8) ATTN_LAUNCH(8, false, false, 1, true); else ATTN_LAUNCH(4, false, false, 1, true); }
+        else
 #if SC_PROBES
-    if (qb2) { if (nw == 8) ATTN_LAUNCH(8, false, false, 2); else ATTN_LAUNCH(4, false, false, 2); }
-    else
+        if (qb2) { if (nw_ == 8) ATTN_LAUNCH(8, false, false, 2); else ATTN_LAUNCH(4, false, false, 2); }
+        else
 #endif
-    if (th) { if (nw == 8) ATTN_LAUNCH(8, false, true); else ATTN_LAUNCH(4, false, true); }
+        if (th) { if (nw_ == 8) ATTN_LAUNCH(8, false, true); else ATTN_LAUNCH(4, false, true); }
 #if SC_PROBES
-    else if (g_attn_trace_host) { if (nw == 8) ATTN_LAUNCH(8, true, false); else ATTN_LAUNCH(4, true, false); }
+        else if (g_attn_trace_host) { if (nw_ == 8) ATTN_LAUNCH(8, true, false); else ATTN_LAUNCH(4, true, false); }
 #endif
-    else if (nw == 8) ATTN_LAUNCH(8, false, false);
-    else ATTN_LAUNCH(4, false, false);
+        else if (nw_ == 8) ATTN_LAUNCH(8, false, false);
+        else ATTN_LAUNCH(4, false, false);
+    };
+    const int rows = nw * 32 * (qb2 ? 2 : 1);
+    if (!split) launch(nw, (T + rows - 1) / rows, 0);
+    else {
+        launch(8, T / 256, 1);      // the full 256-row blocks
+        launch(4, 1, 2);
+    }
+    if (rc_launch) return rc_launch;
 #undef ATTN_LAUNCH
     SC_CHECK_LAUNCH();
     return 0;

@@ -457,3 +457,60 @@ def test_flash_attention_creeping_and_jumping_maxima():
     ref = _attn_ref(qkv, B, T, H, lens.cuda())
     valid = torch.cat([torch.arange(T) < n for n in lens.tolist()])
     torch.testing.assert_close(y.float()[valid.cuda()], ref[valid.cuda()], atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("T", [257, 319, 300, 384, 385, 129, 256, 512 + 17])
+@pytest.mark.parametrize("half", [False, True])
+def test_attention_query_row_split_uniform(T, half):
+    """attn_fwd_kernel's query-row split (attention.hip q_mode): a last block of <= 128 valid rows goes to a second launch of 4-wave blocks (T = 257: ViT-L/14,
+    T = 319: the training crop; 384 / 512 + 17 / 129: both launches; 300, 385: boundary cases; 256: no tail).  Every valid row against fp32 softmax attention
+    (fairseq MultiheadAttention with a key-padding mask, speech_encoder_plus.py:52; clip_official.py:209)."""
+    from speechclip_amd import ops
+    B, H = 3, 4
+    D = H * 64
+    dt = torch.float16 if half else torch.bfloat16
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(B * T, 3 * D, generator=g).to("cuda", dt)
+    lens = [T, max(1, T - 61), max(1, T // 2)]
+    kl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    out = ops.attention(qkv, B, T, H, kl)
+    q, k, v = (qkv.float().view(B, T, 3, H, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    s = s.masked_fill((torch.arange(T, device="cuda")[None, :] >= kl[:, None])[:, None, None, :], float("-inf"))
+    want = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, T, D)
+    tol = 2e-3 if half else 2e-2
+    torch.testing.assert_close(out.view(B, T, D).float(), want, atol=tol, rtol=tol)      # every query row of every utterance (padded queries attend to the valid keys too)
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_attention_query_row_split_packed_ragged(drop):
+    """PACKED batches keep ONE launch (the per-utterance split measured slower, attention.hip): per-utterance row counts on both sides of every block boundary
+    (<= 128, 129, 256, 257, 300, 384, 385, 500) against fp32; with dropout: deterministic, finite, unbiased."""
+    from speechclip_amd import ops
+    H = 4
+    D = H * 64
+    rows = [500, 100, 129, 256, 257, 300, 384, 385, 1, 128]
+    B = len(rows)
+    off = [0]
+    for r in rows:
+        off.append(off[-1] + r)
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(off[-1], 3 * D, generator=g).to("cuda", torch.bfloat16)
+    kl = torch.tensor([max(1, r - 3) for r in rows], dtype=torch.int32, device="cuda")
+    off_t = torch.tensor(off, dtype=torch.int32, device="cuda")
+    out = ops.attention_packed(qkv, B, max(rows), H, kl, off_t, drop_p=drop, seed=1234)
+    if drop == 0.0:
+        for b, r in enumerate(rows):
+            x = qkv[off[b]:off[b + 1]].float()
+            q, k, v = (x.view(r, 3, H, 64)[:, i].permute(1, 0, 2) for i in range(3))
+            s = (q @ k.transpose(-1, -2)) * 0.125
+            s[:, :, int(kl[b]):] = float("-inf")
+            want = (torch.softmax(s, -1) @ v).permute(1, 0, 2).reshape(r, D)
+            torch.testing.assert_close(out[off[b]:off[b + 1]].float(), want, atol=2e-2, rtol=2e-2)
+    else:
+        # twice the same call: deterministic; and finite everywhere, row sums of kept probabilities unbiased within 3 %
+        out2 = ops.attention_packed(qkv, B, max(rows), H, kl, off_t, drop_p=drop, seed=1234)
+        assert torch.equal(out, out2) and torch.isfinite(out.float()).all()
+        ref = ops.attention_packed(qkv, B, max(rows), H, kl, off_t)
+        long_rows = slice(off[0], off[1])
+        assert abs((out[long_rows].float() - ref[long_rows].float()).mean().item()) < 3e-3
