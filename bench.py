@@ -413,7 +413,8 @@ def clock_under_load(step, fence, seconds=1.2):
     t0 = time.perf_counter()
     th.start()
     n = 0
-    while time.perf_counter() - t0 < seconds:
+    # (at least `seconds`, and on until four readings are in -- one rocm-smi call takes 0.2-0.8 s depending on the box -- but never beyond 6 s)
+    while time.perf_counter() - t0 < seconds or (len(samples) < 4 and time.perf_counter() - t0 < 6.0):
         step()
         fence()
         n += 1
