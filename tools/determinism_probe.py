@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run-to-run bitwise reproducibility of the forward path on one GPU: N forwards of the same batch, every hidden state of the speech tower, the image
 features and the embeddings compared with the first run; reports the first tensor that differs (layer index, elements, max |diff|).
-usage: python tools/determinism_probe.py [runs] [gemm_mode: -1 default | 26 static tile order | 0 old kernels]"""
+usage: python tools/determinism_probe.py [runs] [gemm_mode: -1 default | 26 static tile order | 0 old kernels] [B] [base | large | cascaded]"""
 import os
 import sys
 import torch
@@ -12,8 +12,9 @@ from speechclip_amd._lib import lib  # noqa: E402
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+kind = sys.argv[4] if len(sys.argv) > 4 else "base"          # base | large | cascaded
 lib().sc_debug_set_gemm_mode(mode)
-model = bench.build_model().cuda().eval()
+model = bench.build_model(large=kind == "large", cascaded=kind == "cascaded").cuda().eval()
 batch, lens = bench.make_batch(B, 160000, 0, "cuda")
 lens = list(lens)
 for i in range(0, B, 7):
@@ -29,7 +30,9 @@ def once():
     torch.cuda.synchronize()
     out = {"hidden%02d" % i: h.clone() for i, h in enumerate(hidden)}
     out["image_feat"] = lf["image_feat"].clone()
-    out["parallel_audio_feat"] = lf["parallel_audio_feat"].clone()
+    for k in ("parallel_audio_feat", "cascaded_audio_feat"):
+        if k in lf and lf[k] is not None:
+            out[k] = lf[k].clone()
     return out
 
 
