@@ -21,6 +21,7 @@ from torch import nn
 from .. import ops, parallel
 
 _OVERLAP_IMAGE_TOWER = os.environ.get("SC_OVERLAP_VIT", "1") != "0"
+_SIDE_PRIORITY = int(os.environ.get("SC_SIDE_PRIORITY", "0"))      # HIP stream priority of the image tower's side stream: 0 = default (lowest), -1 = high (A/B: profiles/r06_side_stream_priority_ab.txt)
 _VIT_START = os.environ.get("SC_VIT_START", "")       # "" = the image tower starts with the step; "extractor" / "layer<i>": behind that stage of the speech tower (A/B);
                                                        # "head": behind the whole speech tower, beside the pooling / keyword head (the cascaded head is ~2.5 ms of small kernels)
 _SIDE_STREAMS = {}
@@ -568,7 +569,7 @@ class KWClip_GeneralTransformer(KWClipBase):
             cur = torch.cuda.current_stream()
             side = _SIDE_STREAMS.get(image.device.index)          # one side stream per device for the whole process (the library path keeps
             if side is None:                                      # one workspace half per stream: vendor_gemm.hip)
-                side = _SIDE_STREAMS[image.device.index] = torch.cuda.Stream(device=image.device)
+                side = _SIDE_STREAMS[image.device.index] = torch.cuda.Stream(device=image.device, priority=_SIDE_PRIORITY)
             def launch_image():
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
