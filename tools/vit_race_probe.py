@@ -37,6 +37,9 @@ def tower(record):
     nf = torch.empty(M, W, device="cuda", dtype=torch.float32) if variant == "ln_generic" else None
 
     def ln(src, g, b):
+        if variant.startswith("ln_v"):            # tools/probes/ln768f_variants.hip: the pre-fix kernel (SLP-packed) and three variants of it
+            assert LV.ln768f_variant(int(variant[4:]), src.data_ptr(), g.data_ptr(), b.data_ptr(), n.data_ptr(), src.shape[0], 1e-5, torch.cuda.current_stream().cuda_stream) == 0
+            return
         if nf is not None:
             ops.layernorm(src, g, b, out=nf)          # generic kernel (fp32 out), then a cast
             n.copy_(nf)
@@ -82,6 +85,14 @@ if variant == "old_gemm":
     lib().sc_debug_set_gemm_mode(0)
 if variant == "static_order":
     lib().sc_debug_set_gemm_mode(26)
+LV = None
+if variant.startswith("ln_v"):
+    import ctypes
+    so_ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "ln768f_variants_bin.so")
+    if not os.path.exists(so_):
+        os.system("/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared %s -o %s" % (so_.replace("_bin.so", ".hip"), so_))
+    LV = ctypes.CDLL(so_)
+    LV.ln768f_variant.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]
 print("variant:", variant)
 torch.cuda.synchronize()
 names, ref = run(True)
